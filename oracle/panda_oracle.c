@@ -1,0 +1,650 @@
+/*
+ * panda_oracle.c -- CPU ORACLE (test infrastructure, never shipped, never on the product path).
+ * See panda_oracle.h for scope and pinning status.  Every function names the reference
+ * lines it restates; nothing here is copied from the reference, it is re-derived from the
+ * behavioural spec and checked against what can be checked.
+ *
+ * Build: gcc -std=c99 -O2 -ffp-contract=off (the reference is built without FMA
+ * contraction, Makefile.am:62-66; x86-64 gcc does not contract by default but we say so).
+ */
+#define _GNU_SOURCE
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "panda_oracle.h"
+
+#ifndef M_LN2
+#define M_LN2 0.69314718055994530942
+#endif
+
+#define NT_N 15
+#define KMER_LEN 8
+
+static inline int clampq(int q) {	/* PHREDCLAMP, prob.h:23 */
+	return q > PO_PHREDMAX ? PO_PHREDMAX : (q < 0 ? 0 : q);
+}
+
+static inline int is_degenerate(unsigned nt) {	/* PANDA_NT_IS_DEGN == popcount != 1, pandaseq-nt.h:55 */
+	return __builtin_popcount(nt & 0xFFu) != 1;
+}
+
+/* ------------------------------------------------------------------ tables */
+
+/* tablebuilder.c:86,124,147 print every entry with "%g"; the C compiler then parses that text.
+ * Round-tripping through the same text reproduces the 6-significant-digit values exactly. */
+static double six_digits(double v) {
+	char buf[64];
+	snprintf(buf, sizeof buf, "%g", v);
+	return strtod(buf, NULL);
+}
+
+static double phred_p(int q) {	/* PROBABILITY, prob.h:21 */
+	return pow(10.0, (-(double) q) / 10.0);
+}
+
+/* mktable.c:23-31 */
+static double f_match(double p, double q) {
+	return (1 - p) * (1 - q) + p * q / 3;
+}
+
+/* mktable.c:33-41 and :84-92 (the rdp_mle mismatch formula is the same expression) */
+static double f_mismatch(double p, double q) {
+	return (1 - p) * q / 3 + (1 - q) * p / 3 + 2 * p * q / 9;
+}
+
+/* mktable.c:43-51 */
+static double f_match_pear(double p, double q) {
+	return (1 - (1 - q) * p / 3 - (1 - p) * q / 3 - 2 * (1 - p) * (1 - q) / 9);
+}
+
+/* mktable.c:53-61 */
+static double f_mismatch_pear(double p, double q) {
+	return (1 - p) * q / 3 + (1 - q) * p / 3 + p * q / 2;
+}
+
+/* mktable.c:94-104 */
+static double f_mismatch_rdp_asm(double p, double q) {
+	double mn = (p <= q) ? p : q;
+	double v = 1 - (mn - p * q / 3.0) / (p + q - 4.0 / 3.0 * p * q);
+	return (v == 0) ? DBL_MIN : v;
+}
+
+void po_build_tables(po_tables *t) {
+	int i, j;
+	t->qual_nn = six_digits(log(0.25));	/* mktable.c:141 + tablebuilder.c:124 -> -1.38629 */
+	for (i = 0; i < PO_NQ; i++) {
+		double p = phred_p(i);
+		/* mktable.c:63-73: Q=0 (p==1) is pinned to -2, not log(0); log_output=false (mktable.c:150) */
+		t->score[i] = six_digits(p == 1 ? -2 : log(1.0 - p));
+		t->score_err[i] = six_digits(log(p));	/* mktable.c:75-82 */
+		for (j = 0; j < PO_NQ; j++) {
+			double q = phred_p(j);
+			/* tablebuilder.c:161-168: formula(P(x), P(y)) then log() */
+			t->match_sb[i][j] = six_digits(log(f_match(p, q)));
+			t->mismatch_sb[i][j] = six_digits(log(f_mismatch(p, q)));
+			t->match_pear[i][j] = six_digits(log(f_match_pear(p, q)));
+			t->mismatch_pear[i][j] = six_digits(log(f_mismatch_pear(p, q)));
+			t->mismatch_rdp[i][j] = six_digits(log(f_mismatch(p, q)));
+			t->mismatch_rdp_asm[i][j] = six_digits(log(f_mismatch_rdp_asm(p, q)));
+		}
+	}
+}
+
+/* ------------------------------------------------------------------ config */
+
+void po_config_set_sb_q(po_config *c, double q) {	/* algo_simple_bayes.c:126-135 */
+	if (q > 0 && q < 1) {
+		c->sb_q = q;
+		c->sb_pmatch = log(0.25 * (1 - 2 * q + q * q));
+		c->sb_pmismatch = log((3 * q - 2 * q * q) / 18.0);
+	}
+}
+
+void po_config_default(po_config *c) {	/* assembler_support.c:61-97 */
+	memset(c, 0, sizeof *c);
+	c->algo = PO_ALGO_SIMPLE_BAYES;
+	po_config_set_sb_q(c, 0.36);	/* algo_simple_bayes.c:113 */
+	c->pear_random_base = log(0.25);	/* algo_pear.c:106 */
+	c->threshold = log(0.6);
+	c->minoverlap = 2;
+	c->maxoverlap = 0;
+	c->num_kmers = 2;
+	c->primer_penalty = 0;
+}
+
+/* ------------------------------------------------------------------ k-mers */
+
+static inline unsigned kcode(unsigned nt) {	/* misc.h:41: T=3 G=2 C=1, everything else 0 */
+	return nt == 8 ? 3u : nt == 4 ? 2u : nt == 2 ? 1u : 0u;
+}
+
+/* misc.h:41-42: position p is emitted iff p >= 8 and no N among the 9 positions ending at p */
+size_t po_kmers_forward(const po_qual *s, size_t len, uint16_t *kmer, uint16_t *posn) {
+	size_t n = 0;
+	unsigned k = 0;
+	int bad = KMER_LEN;
+	for (size_t p = 0; p < len; p++) {
+		k = ((k << 2) | kcode(s[p].nt)) & 0xFFFFu;
+		if (s[p].nt == NT_N) {
+			bad = KMER_LEN;
+		} else if (bad > 0) {
+			bad--;
+		} else {
+			kmer[n] = (uint16_t) k;
+			posn[n] = (uint16_t) p;
+			n++;
+		}
+	}
+	return n;
+}
+
+/* misc.h:43: same walk from len-1 down to 0 */
+size_t po_kmers_reverse(const po_qual *s, size_t len, uint16_t *kmer, uint16_t *posn) {
+	size_t n = 0;
+	unsigned k = 0;
+	int bad = KMER_LEN;
+	for (ptrdiff_t p = (ptrdiff_t) len - 1; p >= 0; p--) {
+		k = ((k << 2) | kcode(s[p].nt)) & 0xFFFFu;
+		if (s[p].nt == NT_N) {
+			bad = KMER_LEN;
+		} else if (bad > 0) {
+			bad--;
+		} else {
+			kmer[n] = (uint16_t) k;
+			posn[n] = (uint16_t) p;
+			n++;
+		}
+	}
+	return n;
+}
+
+/* ------------------------------------------------------------------ scoring */
+
+/* algo_simple_bayes.c:33-66 */
+static double overlap_sb(const po_config *c, const po_tables *t, const po_qual *f, size_t flen, const po_qual *r, size_t rlen, size_t ov) {
+	size_t matches = 0, mismatches = 0, unknowns = 0;
+	for (size_t i = 0; i < ov; i++) {
+		int fi = (int) (flen + i - ov);
+		int ri = (int) (rlen - i - 1);
+		if (fi < 0 || ri < 0 || (size_t) fi >= flen || (size_t) ri >= rlen)
+			continue;
+		unsigned a = f[fi].nt, b = r[ri].nt;
+		if (a == NT_N || b == NT_N)
+			unknowns++;
+		else if ((a & b) != 0)
+			matches++;
+		else
+			mismatches++;
+	}
+	if (ov >= flen && ov >= rlen)
+		return t->qual_nn * unknowns + matches * c->sb_pmatch + mismatches * c->sb_pmismatch;
+	/* size_t arithmetic inside the parenthesis, then converted to double (algo_simple_bayes.c:64) */
+	return t->qual_nn * (flen + rlen - 2 * ov + unknowns) + matches * c->sb_pmatch + mismatches * c->sb_pmismatch;
+}
+
+/* algo_pear.c:32-59.  The second table index is the FORWARD read's quality at rindex (sic, :52,:54).
+ * When rlen > flen that index can run past the forward read: undefined behaviour in the reference;
+ * this restatement (and the device path) define such an out-of-range quality as 0. */
+static double overlap_pear(const po_config *c, const po_tables *t, const po_qual *f, size_t flen, const po_qual *r, size_t rlen, size_t ov) {
+	double p = 0;
+	for (size_t i = 0; i < ov; i++) {
+		int fi = (int) (flen + i - ov);
+		int ri = (int) (rlen - i - 1);
+		if (fi < 0 || ri < 0 || (size_t) fi >= flen || (size_t) ri >= rlen)
+			continue;
+		unsigned a = f[fi].nt, b = r[ri].nt;
+		if (a == NT_N || b == NT_N) {
+			p -= c->pear_random_base;
+		} else {
+			int qa = clampq(f[fi].qual);
+			int qb = (size_t) ri < flen ? clampq(f[ri].qual) : 0;
+			if ((a & b) != 0)
+				p += t->match_pear[qa][qb];
+			else
+				p += t->mismatch_pear[qa][qb];
+		}
+	}
+	return p;
+}
+
+/* algo_rdp_mle.c:43-74: no N case; (table - qual_nn) is formed first, then added */
+static double overlap_rdp(const po_tables *t, const po_qual *f, size_t flen, const po_qual *r, size_t rlen, size_t ov) {
+	double p = 0;
+	for (size_t i = 0; i < ov; i++) {
+		int fi = (int) (flen + i - ov);
+		int ri = (int) (rlen - i - 1);
+		/* the reference tests "> length" here (:58); findex < flen and rindex < rlen always hold, so it never matters */
+		if (fi < 0 || ri < 0 || (size_t) fi >= flen || (size_t) ri >= rlen)
+			continue;
+		int qa = clampq(f[fi].qual), qb = clampq(r[ri].qual);
+		if ((f[fi].nt & r[ri].nt) != 0)
+			p += t->match_sb[qa][qb] - t->qual_nn;
+		else
+			p += t->mismatch_rdp[qa][qb] - t->qual_nn;
+	}
+	return p;
+}
+
+double po_overlap_probability(const po_config *c, const po_tables *t, const po_qual *f, size_t flen, const po_qual *r, size_t rlen, size_t ov) {
+	switch (c->algo) {
+	case PO_ALGO_PEAR:
+		return overlap_pear(c, t, f, flen, r, rlen, ov);
+	case PO_ALGO_RDP_MLE:
+		return overlap_rdp(t, f, flen, r, rlen, ov);
+	default:
+		return overlap_sb(c, t, f, flen, r, rlen, ov);
+	}
+}
+
+/* algo_simple_bayes.c:68-75, algo_pear.c:61-68, algo_rdp_mle.c:29-41 */
+double po_match_probability(const po_config *c, const po_tables *t, int match, int8_t a, int8_t b) {
+	switch (c->algo) {
+	case PO_ALGO_PEAR:
+		return (match ? t->match_pear : t->mismatch_pear)[clampq(a)][clampq(b)];
+	case PO_ALGO_RDP_MLE:
+		if (match) {
+			int8_t mx = (a >= b) ? a : b;	/* raw max, then clamp */
+			return t->score[clampq(mx)];
+		}
+		return t->mismatch_rdp_asm[clampq(a)][clampq(b)];
+	default:
+		return (match ? t->match_sb : t->mismatch_sb)[clampq(a)][clampq(b)];
+	}
+}
+
+/* ------------------------------------------------------------------ primer offset (offset.c:47-112) */
+
+size_t po_compute_offset_qual(const po_tables *t, double threshold, double penalty, const po_qual *seq, size_t len, const uint8_t *primer, size_t plen) {
+	double pr[PO_MAX_LEN];
+	double bestpr = exp(plen * threshold);
+	size_t best = 0;
+	if (plen > len || plen == 0)
+		return 0;
+	for (size_t i = 0; i < plen; i++)
+		pr[i] = -INFINITY;
+	for (size_t index = 0; index < len; index++) {
+		double last = exp(pr[index % plen] / (index + 1)) - index * penalty;
+		if (last > bestpr) {
+			bestpr = last;
+			best = index + 1;
+		}
+		pr[index % plen] = 0;
+		for (ptrdiff_t x = (ptrdiff_t) (plen > index ? index : plen - 1); x >= 0; x--) {
+			if (primer[x] != NT_N) {
+				int q = clampq(seq[index].qual);
+				pr[(index - (size_t) x) % plen] += ((seq[index].nt & primer[x]) != 0) ? t->score[q] : t->score_err[q];
+			}
+		}
+	}
+	return best;
+}
+
+/* ------------------------------------------------------------------ phred of an output base (nt.c:126-150) */
+
+int po_result_phred(const po_tables *t, double p) {
+	int lower = 0, upper = PO_PHREDMAX;
+	if (p <= t->score[0])
+		return 1;
+	while (lower < upper) {
+		int mid = lower + (upper - lower) / 2;
+		if (t->score[mid] == p)
+			return mid;
+		if (mid == lower)
+			return lower;
+		else if (t->score[mid] > p)
+			upper = mid;
+		else if (t->score[mid] < p)
+			lower = mid + 1;
+	}
+	return lower;
+}
+
+/* ------------------------------------------------------------------ align (assembler.c:48-250) */
+
+struct po_scratch {
+	uint16_t *seen;		/* 65536 * 2, zero when idle (assembler_support.c:82,94) */
+};
+
+po_scratch *po_scratch_new(void) {
+	po_scratch *s = malloc(sizeof *s);
+	s->seen = calloc(65536 * 2, sizeof(uint16_t));
+	return s;
+}
+
+void po_scratch_free(po_scratch *s) {
+	if (s) {
+		free(s->seen);
+		free(s);
+	}
+}
+
+#define VEEZ(x) ((x) < 0 ? 0 : (x))
+#define WEDGEZ(x) ((x) > 0 ? 0 : (x))
+
+static int align(const po_config *c, const po_tables *t, po_scratch *sc, const po_qual *F, size_t flen, const po_qual *R, size_t rlen, size_t fo, size_t ro, po_result *res, uint8_t *S_nt, double *S_p) {
+	const size_t minov = (size_t) c->minoverlap;
+	const double NN = t->qual_nn;
+	uint16_t kf[PO_MAX_LEN], pf[PO_MAX_LEN], kr[PO_MAX_LEN], prv[PO_MAX_LEN];
+	uint32_t bits[(2 * PO_MAX_LEN) / 32 + 2];
+
+	/* assembler.c:59, unsigned arithmetic as in the reference */
+	size_t maxov = flen + rlen - minov - fo - ro - 1;
+	double best = NN * (flen + rlen);	/* :60 */
+	ptrdiff_t bo = -1;
+
+	res->slow = 0;
+	if (minov + fo >= flen || minov + ro >= rlen)	/* :73 */
+		return 0;
+	if (c->maxoverlap == 0)	/* :78-82 */
+		maxov = flen < rlen ? flen : rlen;
+	else if (maxov > (size_t) c->maxoverlap)
+		maxov = (size_t) c->maxoverlap;
+	size_t size = minov <= maxov ? maxov - minov + 1 : 1;	/* :84 */
+	size_t words = size / 32 + 1;
+	memset(bits, 0, words * sizeof(uint32_t));
+
+	/* :92-101 forward k-mers: keep the first two positions per k-mer (num_kmers == 2) */
+	size_t nf = po_kmers_forward(F, flen, kf, pf);
+	for (size_t a = 0; a < nf; a++) {
+		uint16_t *slot = &sc->seen[(size_t) kf[a] << 1];
+		if (slot[0] == 0)
+			slot[0] = pf[a];
+		else if (slot[1] == 0)
+			slot[1] = pf[a];
+		/* else: lost k-mer */
+	}
+	/* :104-110 reverse k-mers flag candidate overlaps */
+	size_t nr = po_kmers_reverse(R, rlen, kr, prv);
+	for (size_t a = 0; a < nr; a++) {
+		const uint16_t *slot = &sc->seen[(size_t) kr[a] << 1];
+		for (int j = 0; j < 2 && slot[j] != 0; j++) {
+			int index = (int) (flen + rlen - prv[a] - slot[j] - minov - 1);
+			if (index >= 0 && (size_t) index < size)
+				bits[index / 32] |= 1u << (index % 32);
+		}
+	}
+	/* :113-116 reset */
+	for (size_t a = 0; a < nf; a++) {
+		sc->seen[((size_t) kf[a] << 1)] = 0;
+		sc->seen[((size_t) kf[a] << 1) + 1] = 0;
+	}
+	/* :118 ALL_BITS_IF_NONE */
+	{
+		uint32_t any = 0;
+		for (size_t w = 0; w < words; w++)
+			any |= bits[w];
+		if (any == 0)
+			memset(bits, 0xFF, words * sizeof(uint32_t));
+	}
+
+	/* :120-133 scan in ascending overlap, strict > keeps the smallest overlap on ties */
+	size_t examined = 0;
+	for (size_t counter = 0; counter < size; counter++) {
+		if (!(bits[counter / 32] & (1u << (counter % 32))))
+			continue;
+		size_t ov = counter + minov;
+		double pr = po_overlap_probability(c, t, F, flen, R, rlen, ov);
+		if (pr > best && ov >= minov) {
+			best = pr;
+			bo = (ptrdiff_t) ov;
+		}
+		examined++;
+	}
+	res->examined = (int32_t) examined;
+	if (examined == maxov - minov + 1)	/* :135, unsigned wrap included */
+		res->slow = 1;
+	if (bo == -1)
+		return 0;
+
+	/* :146-155 */
+	ptrdiff_t len = (ptrdiff_t) flen - (ptrdiff_t) fo - bo + (ptrdiff_t) rlen - (ptrdiff_t) ro + 1;
+	if (len <= 0)
+		return 0;
+	if ((size_t) len > 2 * PO_MAX_LEN)
+		return 0;
+	res->seq_len = (int32_t) (len - 1);
+	int degenerates = 0, mism = 0;
+	double fq = 0, oq = 0, rq = 0;
+	ptrdiff_t df = (ptrdiff_t) flen - (ptrdiff_t) fo - bo;
+	ptrdiff_t dr = (ptrdiff_t) rlen - (ptrdiff_t) ro - bo;
+
+	/* :162-173 forward-only part */
+	for (size_t i = 0; i < (size_t) VEEZ(df); i++) {
+		int fi = (int) (i + fo);
+		double q = t->score[clampq(F[fi].qual)];
+		S_nt[i] = F[fi].nt;
+		S_p[i] = q;
+		if (is_degenerate(F[fi].nt))
+			degenerates++;
+		fq += q;
+	}
+	/* :176-177 B-cliff: trailing run of raw quality 2 */
+	size_t uf, ur;
+	for (uf = flen; uf > 0 && F[uf - 1].qual == 2; uf--) ;
+	for (ur = rlen; ur > 0 && R[ur - 1].qual == 2; ur--) ;
+
+	/* :181-228 overlap part */
+	for (size_t i = 0; i < (size_t) (bo + WEDGEZ(df) + WEDGEZ(dr)); i++) {
+		int index = (int) (VEEZ(df) + (ptrdiff_t) i);
+		int fi = (int) ((ptrdiff_t) fo + VEEZ(df) + (ptrdiff_t) i);
+		int ri = (int) ((ptrdiff_t) rlen - (ptrdiff_t) i - 1 + WEDGEZ(df));
+		if (index < 0 || fi < 0 || ri < 0 || (size_t) fi >= flen || (size_t) ri >= rlen)
+			continue;
+		int ismatch = (R[ri].nt & F[fi].nt) != 0;
+		double q;
+		uint8_t nt;
+		if (!ismatch)
+			mism++;
+		if ((size_t) fi >= uf && (size_t) ri >= ur)
+			q = NN;
+		else if ((size_t) fi >= uf)
+			q = t->score[clampq(R[ri].qual)];
+		else if ((size_t) ri >= ur)
+			q = t->score[clampq(F[fi].qual)];
+		else
+			q = po_match_probability(c, t, ismatch, F[fi].qual, R[ri].qual);
+		if (ismatch)
+			nt = R[ri].nt & F[fi].nt;
+		else
+			nt = (F[fi].qual < R[ri].qual) ? R[ri].nt : F[fi].nt;
+		S_nt[index] = nt;
+		S_p[index] = q;
+		if (is_degenerate(nt))
+			degenerates++;
+		oq += q;
+	}
+	/* :231-243 reverse-only part */
+	for (size_t i = 0; i < (size_t) VEEZ(dr); i++) {
+		int index = (int) (df + bo + (ptrdiff_t) i);
+		int ri = (int) ((ptrdiff_t) rlen - bo - (ptrdiff_t) i - 1);
+		double q = t->score[clampq(R[ri].qual)];
+		rq += q;
+		S_nt[index] = R[ri].nt;
+		S_p[index] = q;
+		if (is_degenerate(R[ri].nt))
+			degenerates++;
+	}
+	res->quality = (fq + rq + oq) / len;	/* :244: divided by len = sequence_length + 1 */
+	res->overlap = (int32_t) bo;
+	res->est_prob = best;
+	res->mismatches = mism;
+	res->degenerates = degenerates;
+	return 1;
+}
+
+/* ------------------------------------------------------------------ assemble_seq (assembler.c:252-348) */
+
+static int run_checks(const po_config *c, const po_tables *t, const po_result *res, const double *S_p) {
+	/* module_checkseq, module.c:124-136: in order, first failure wins */
+	for (int m = 0; m < c->n_modules; m++) {
+		const po_module *mod = &c->modules[m];
+		if (mod->kind == PO_MOD_MIN_PHRED) {	/* plugin_min_phred.c:8-22 */
+			for (int j = 0; j < res->seq_len; j++)
+				if (po_result_phred(t, S_p[j]) < mod->phred)
+					return m;
+		} else if (mod->kind == PO_MOD_MIN_OVERLAPBITS) {	/* plugin_min_overlapbits.c:17-23 */
+			if (!(mod->nats <= res->est_prob))
+				return m;
+		}
+	}
+	return -1;
+}
+
+int po_assemble(const po_config *c, const po_tables *t, po_scratch *sc, const po_qual *F, size_t flen, const po_qual *R, size_t rlen, po_result *res, uint8_t *S_nt, double *S_p, po_counters *ctr) {
+	po_counters dummy;
+	if (ctr == NULL) {
+		memset(&dummy, 0, sizeof dummy);
+		ctr = &dummy;
+	}
+	memset(res, 0, sizeof *res);
+	res->reject_module = -1;
+	ctr->count++;
+	if (flen < 2 || rlen < 2) {	/* :255-258 */
+		ctr->badr++;
+		return res->status = PO_BADR;
+	}
+	/* :259 precheck modules: neither in-scope module has one */
+	size_t fo, ro;
+	if (c->fprimer_len > 0) {	/* :263-273 */
+		fo = po_compute_offset_qual(t, c->threshold, c->primer_penalty, F, flen, c->fprimer, (size_t) c->fprimer_len);
+		if (fo == 0) {
+			ctr->nofp++;
+			return res->status = PO_NOFP;
+		}
+		fo--;
+	} else {
+		fo = (size_t) c->ftrim;
+	}
+	res->fwd_offset = (int32_t) fo;
+	if (c->rprimer_len > 0) {	/* :274-284 */
+		ro = po_compute_offset_qual(t, c->threshold, c->primer_penalty, R, rlen, c->rprimer, (size_t) c->rprimer_len);
+		if (ro == 0) {
+			ctr->norp++;
+			return res->status = PO_NORP;
+		}
+		ro--;
+	} else {
+		ro = (size_t) c->rtrim;
+	}
+	res->rev_offset = (int32_t) ro;
+	if ((flen < rlen ? flen : rlen) < (size_t) c->minoverlap) {	/* :289-292 */
+		ctr->badr++;
+		return res->status = PO_BADR;
+	}
+	int ok = align(c, t, sc, F, flen, R, rlen, fo, ro, res, S_nt, S_p);
+	if (res->slow)
+		ctr->slow++;	/* :135-137 sits inside align, before its failure exits */
+	if (!ok) {	/* :293-299 */
+		ctr->noalgn++;
+		res->seq_len = 0;
+		return res->status = PO_NOALGN;
+	}
+	if (res->quality < c->threshold) {	/* :334-338 */
+		ctr->lowq++;
+		return res->status = PO_LOWQ;
+	}
+	int rej = run_checks(c, t, res, S_p);	/* :339 */
+	if (rej >= 0) {
+		ctr->rejected[rej]++;
+		res->reject_module = rej;
+		return res->status = PO_REJECT;
+	}
+	ctr->ok++;	/* :340-345 */
+	ctr->overlapcount[res->overlap]++;
+	if (ctr->longest_overlap < res->overlap)
+		ctr->longest_overlap = res->overlap;
+	return res->status = PO_OK;
+}
+
+void po_assemble_batch(const po_config *c, const po_tables *t, size_t n, const po_qual *fwd, size_t fstride, const po_qual *rev, size_t rstride, const uint16_t *flen, const uint16_t *rlen, po_result *res, uint8_t *seq_nt, double *seq_p, size_t ostride, po_counters *ctr) {
+	po_scratch *sc = po_scratch_new();
+	uint8_t nt_tmp[2 * PO_MAX_LEN];
+	double p_tmp[2 * PO_MAX_LEN];
+	for (size_t i = 0; i < n; i++) {
+		uint8_t *nt = seq_nt ? seq_nt + i * ostride : nt_tmp;
+		double *p = seq_p ? seq_p + i * ostride : p_tmp;
+		if (ostride < 2 * PO_MAX_LEN && (seq_nt || seq_p)) {
+			/* rows may be narrower than the worst case: assemble into scratch, then copy what fits */
+			po_assemble(c, t, sc, fwd + i * fstride, flen[i], rev + i * rstride, rlen[i], &res[i], nt_tmp, p_tmp, ctr);
+			size_t m = (size_t) res[i].seq_len < ostride ? (size_t) res[i].seq_len : ostride;
+			if (res[i].status == PO_NOALGN)
+				m = 0;
+			if (seq_nt)
+				memcpy(nt, nt_tmp, m);
+			if (seq_p)
+				memcpy(p, p_tmp, m * sizeof(double));
+		} else {
+			po_assemble(c, t, sc, fwd + i * fstride, flen[i], rev + i * rstride, rlen[i], &res[i], nt, p, ctr);
+		}
+	}
+	po_scratch_free(sc);
+}
+
+struct mt_job {
+	const po_config *c;
+	const po_tables *t;
+	size_t lo, hi;
+	const po_qual *fwd, *rev;
+	size_t fstride, rstride, ostride;
+	const uint16_t *flen, *rlen;
+	po_result *res;
+	uint8_t *seq_nt;
+	double *seq_p;
+	po_counters ctr;
+};
+
+static void *mt_worker(void *arg) {
+	struct mt_job *j = arg;
+	size_t n = j->hi - j->lo;
+	memset(&j->ctr, 0, sizeof j->ctr);
+	po_assemble_batch(j->c, j->t, n, j->fwd + j->lo * j->fstride, j->fstride, j->rev + j->lo * j->rstride, j->rstride, j->flen + j->lo, j->rlen + j->lo, j->res + j->lo, j->seq_nt ? j->seq_nt + j->lo * j->ostride : NULL, j->seq_p ? j->seq_p + j->lo * j->ostride : NULL, j->ostride, &j->ctr);
+	return NULL;
+}
+
+void po_assemble_batch_mt(const po_config *c, const po_tables *t, size_t n, const po_qual *fwd, size_t fstride, const po_qual *rev, size_t rstride, const uint16_t *flen, const uint16_t *rlen, po_result *res, uint8_t *seq_nt, double *seq_p, size_t ostride, po_counters *ctr, int threads) {
+	if (threads < 1)
+		threads = 1;
+	struct mt_job *jobs = calloc((size_t) threads, sizeof *jobs);
+	pthread_t *tid = calloc((size_t) threads, sizeof *tid);
+	for (int k = 0; k < threads; k++) {
+		struct mt_job *j = &jobs[k];
+		j->c = c;
+		j->t = t;
+		j->lo = n * (size_t) k / (size_t) threads;
+		j->hi = n * (size_t) (k + 1) / (size_t) threads;
+		j->fwd = fwd;
+		j->rev = rev;
+		j->fstride = fstride;
+		j->rstride = rstride;
+		j->ostride = ostride;
+		j->flen = flen;
+		j->rlen = rlen;
+		j->res = res;
+		j->seq_nt = seq_nt;
+		j->seq_p = seq_p;
+		pthread_create(&tid[k], NULL, mt_worker, &jobs[k]);
+	}
+	for (int k = 0; k < threads; k++) {
+		pthread_join(tid[k], NULL);
+		const po_counters *w = &jobs[k].ctr;
+		ctr->count += w->count;
+		ctr->badr += w->badr;
+		ctr->nofp += w->nofp;
+		ctr->norp += w->norp;
+		ctr->noalgn += w->noalgn;
+		ctr->lowq += w->lowq;
+		ctr->ok += w->ok;
+		ctr->slow += w->slow;
+		for (int m = 0; m < PO_MAX_MODULES; m++)
+			ctr->rejected[m] += w->rejected[m];
+		for (int o = 0; o < 2 * PO_MAX_LEN; o++)
+			ctr->overlapcount[o] += w->overlapcount[o];
+		if (w->longest_overlap > ctr->longest_overlap)
+			ctr->longest_overlap = w->longest_overlap;	/* a max, not a sum (assembler.c:342-344) */
+	}
+	free(jobs);
+	free(tid);
+}
