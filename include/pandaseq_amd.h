@@ -1,0 +1,187 @@
+/*
+ * pandaseq_amd.h -- C ABI of the MI355X (gfx950) overlap-assembly hot path.
+ *
+ * This is the drop-in boundary for PANDAseq's per-pair assembly path
+ * (panda_assembler_assemble(), assembler.c:368-383, and the loop body of
+ * panda_assembler_next(), assembler.c:350-366): everything assemble_seq()
+ * (assembler.c:252-348) does for one read pair is done here for a whole batch
+ * of pairs by one HIP kernel launch, one wavefront per pair.
+ *
+ * Plain pointers and sizes only: no torch, no C++ types.  `stream` arguments
+ * are a hipStream_t passed as void* (NULL = the default stream).
+ *
+ * Two layers:
+ *   1. pamd_*            batch API over device (HBM) or host buffers -- the hot path.
+ *   2. panda_assembler_* the reference's own per-assembler API (pandaseq-assembler.h:40-405)
+ *                        re-implemented on top of layer 1; declared in pandaseq_amd_compat.h.
+ *
+ * Every entry point returns 0 on success or a negative PAMD_E* code; the
+ * message is available from pamd_last_error().  There is NO CPU fallback: with
+ * no usable GPU every compute entry point fails with PAMD_ENODEVICE.
+ */
+#ifndef PANDASEQ_AMD_H
+#define PANDASEQ_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAMD_MAX_LEN 450	/* PANDA_MAX_LEN / configure.ac:8 */
+#define PAMD_MAX_MODULES 8
+#define PAMD_NUM_COUNTERS (8 + PAMD_MAX_MODULES + 2 * PAMD_MAX_LEN)
+
+enum {
+	PAMD_OK = 0,
+	PAMD_EINVAL = -1,	/* bad argument / value outside the device domain */
+	PAMD_ENODEVICE = -2,	/* no HIP device, or HIP runtime error */
+	PAMD_ENOMEM = -3,
+	PAMD_EUNSUPPORTED = -4	/* e.g. num_kmers != 2, primers_after: not on the device path */
+};
+
+/* One base.  Byte-identical to panda_qual (pandaseq-common.h:210-219): nt is the one-hot
+ * IUPAC code (A=1 C=2 G=4 T=8, N=15; pandaseq-nt.h:35-59), qual the raw PHRED score.
+ * The reverse read is complemented but NOT reversed, exactly as fastq.c:154 produces it. */
+typedef struct {
+	uint8_t nt;
+	int8_t qual;
+} pamd_qual;
+
+/* replaces the `.name = "simple_bayesian" / "pear" / "rdp_mle"` classes
+ * (algo_simple_bayes.c:100-108, algo_pear.c:93-101, algo_rdp_mle.c:84-92) */
+enum { PAMD_ALGO_SIMPLE_BAYES = 0, PAMD_ALGO_PEAR = 1, PAMD_ALGO_RDP_MLE = 2 };
+
+/* per-pair outcome; one value per rejection counter of assembler.h:59-67 */
+enum {
+	PAMD_ST_OK = 0,
+	PAMD_ST_BADR = 1,	/* badreadcount  (assembler.c:255-258, :289-292) */
+	PAMD_ST_NOFP = 2,	/* nofpcount     (assembler.c:265-268) */
+	PAMD_ST_NORP = 3,	/* norpcount     (assembler.c:276-279) */
+	PAMD_ST_NOALGN = 4,	/* noalgncount   (assembler.c:293-299) */
+	PAMD_ST_LOWQ = 5,	/* lowqcount     (assembler.c:334-338) */
+	PAMD_ST_REJECT = 6	/* a check module rejected it (module.c:124-136) */
+};
+
+/* What panda_result_seq (pandaseq-common.h:277-330) carries per pair, minus the pointers. 48 bytes. */
+typedef struct {
+	double quality;			/* result.quality */
+	double est_overlap_prob;	/* result.estimated_overlap_probability */
+	uint64_t seq_offset;		/* index of the first merged base in seq_nt / seq_p (valid when status == OK) */
+	uint16_t seq_len;		/* result.sequence_length */
+	uint16_t overlap;		/* result.overlap */
+	uint16_t examined;		/* result.overlaps_examined */
+	uint16_t mismatches;		/* result.overlap_mismatches */
+	uint16_t degenerates;		/* result.degenerates */
+	uint16_t fwd_offset;		/* result.forward_offset */
+	uint16_t rev_offset;		/* result.reverse_offset */
+	uint8_t status;			/* PAMD_ST_* */
+	int8_t reject_module;		/* index of the rejecting module, or -1 */
+	uint8_t slow;			/* this pair incremented slowcount (assembler.c:135-137) */
+	uint8_t reserved[7];
+} pamd_pair_result;
+
+/* counter block, int64 each; the layout the STAT all-reduce sums */
+enum {
+	PAMD_CTR_COUNT = 0, PAMD_CTR_BADR, PAMD_CTR_NOFP, PAMD_CTR_NORP, PAMD_CTR_NOALGN,
+	PAMD_CTR_LOWQ, PAMD_CTR_OK, PAMD_CTR_SLOW,
+	PAMD_CTR_REJECTED0 = 8,					/* rejected[module], module.c:131 */
+	PAMD_CTR_OVERLAP0 = 8 + PAMD_MAX_MODULES		/* overlapcount[overlap], assembler.c:341 */
+};
+
+/* A batch of read pairs and where its results go.  All pointers are DEVICE pointers for
+ * pamd_assemble_device() and HOST pointers for pamd_assemble_host().
+ *   fwd / rev     rows of pamd_qual, one row per pair, `*_stride` bases apart (multiple of 8,
+ *                 >= the longest read in the batch, <= 456); row base 16-byte aligned
+ *   flen / rlen   read lengths, each <= PAMD_MAX_LEN
+ *   results       n_pairs records
+ *   seq_nt/seq_p  merged bases (one-hot nt) and per-base log-probabilities of accepted pairs:
+ *                 panda_result.nt / panda_result.p (pandaseq-common.h:221-230), as two arrays
+ *   seq_stride    > 0: pair i writes at i * seq_stride (rows must hold the longest merge);
+ *                 = 0: compact arena -- rows are allocated from *seq_cursor (device word,
+ *                      zero it before the call) in multiples of 16 bases, seq_capacity bases in
+ *                      total; a pair that does not fit is reported as PAMD_EINVAL after the run
+ *   counters      PAMD_NUM_COUNTERS int64, ADDED to (not overwritten); may be NULL */
+typedef struct {
+	size_t n_pairs;
+	const pamd_qual *fwd;
+	size_t fwd_stride;
+	const pamd_qual *rev;
+	size_t rev_stride;
+	const uint16_t *flen;
+	const uint16_t *rlen;
+	pamd_pair_result *results;
+	uint8_t *seq_nt;
+	double *seq_p;
+	size_t seq_stride;
+	size_t seq_capacity;
+	uint64_t *seq_cursor;
+	int64_t *counters;
+} pamd_batch;
+
+/* The configured assembler: the device-side image of struct panda_assembler's
+ * configuration fields (assembler.h:44-57,72-78) plus the probability tables. */
+typedef struct pamd_assembler pamd_assembler;
+
+const char *pamd_last_error(void);
+int pamd_device_count(void);
+
+/* replaces panda_assembler_new (assembler_support.c:27-100): same defaults
+ * (threshold log 0.6, minoverlap 2, maxoverlap 0, simple_bayesian q=0.36, no primers) */
+pamd_assembler *pamd_assembler_create(int device);
+void pamd_assembler_destroy(pamd_assembler *a);
+
+/* replaces panda_assembler_set_algorithm + panda_algorithm_*_new/_set_* (algo_simple_bayes.c:110-135,
+ * algo_pear.c:103-116, algo_rdp_mle.c:94-98).  param: simple_bayes -> error estimation q in (0,1),
+ * pear -> log of the random-base probability; NaN = keep the class default. */
+int pamd_set_algorithm(pamd_assembler *a, int algo, double param);
+/* the setters below mirror assembler_support.c:201-410, including "silently ignore bad values" */
+int pamd_set_threshold(pamd_assembler *a, double threshold);		/* (0,1), stored as log */
+int pamd_set_minimum_overlap(pamd_assembler *a, int overlap);		/* > 1 */
+int pamd_set_maximum_overlap(pamd_assembler *a, int overlap);		/* 0 = min(read lengths) */
+int pamd_set_forward_primer(pamd_assembler *a, const uint8_t *nt, size_t length);
+int pamd_set_reverse_primer(pamd_assembler *a, const uint8_t *nt, size_t length);	/* already complemented, args_assembler.c:222 */
+int pamd_set_forward_trim(pamd_assembler *a, size_t trim);
+int pamd_set_reverse_trim(pamd_assembler *a, size_t trim);
+int pamd_set_primer_penalty(pamd_assembler *a, double penalty);
+/* the two in-scope check modules, fused into the kernel, in the order added
+ * (replaces panda_assembler_add_module of plugin_min_phred.c / plugin_min_overlapbits.c) */
+int pamd_add_module_min_phred(pamd_assembler *a, int phred);
+int pamd_add_module_min_overlapbits(pamd_assembler *a, double bits);
+int pamd_clear_modules(pamd_assembler *a);
+
+/* The probability tables this library computes (host side; works without a GPU).
+ * Order: qual_nn, qual_score[47], qual_score_err[47], then six 47x47 row-major matrices:
+ * match_simple_bayesian, mismatch_simple_bayesian, match_pear, mismatch_pear, mismatch_rdp_mle,
+ * mismatch_assembled_rdp_mle  (table.h as generated by mktable.c:132-155). */
+#define PAMD_TABLE_DOUBLES (1 + 47 + 47 + 6 * 47 * 47)
+int pamd_tables_get(double *out, size_t n_doubles);
+
+/* Enqueue the assembly of one batch on `stream`; returns once launched (asynchronous). */
+int pamd_assemble_device(pamd_assembler *a, const pamd_batch *batch, void *stream);
+/* Same, from/to host memory: uploads, runs, downloads, synchronises. */
+int pamd_assemble_host(pamd_assembler *a, const pamd_batch *batch);
+/* HIP-event time in milliseconds of the most recent pamd_assemble_device() kernel on this
+ * assembler (synchronises on it); < 0 if none. */
+float pamd_last_kernel_ms(pamd_assembler *a);
+/* persistent-launch geometry actually used by the last launch */
+int pamd_last_launch_info(pamd_assembler *a, int *workgroups, int *waves_per_workgroup, int *lds_bytes);
+
+/* Deterministic synthetic pairs [first, first+n) written straight into HBM (pandaseq_amd/synth.py
+ * is the host twin).  thresholds: 64 uint32 device-side substitution thresholds. */
+typedef struct {
+	uint64_t seed;
+	uint32_t read_len, tmin, tmax;
+	int32_t qhi;
+	int32_t novaseq;
+	uint32_t fprimer_len, rprimer_len;
+	uint8_t fprimer[32];	/* base indices 0..3 (ACGT) */
+	uint8_t rprimer[32];
+} pamd_synth_spec;
+int pamd_synth_generate(int device, const pamd_synth_spec *spec, const uint32_t *thresholds_host, uint64_t first, size_t n, pamd_qual *fwd, pamd_qual *rev, size_t stride, uint16_t *flen, uint16_t *rlen, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,220 @@
+"""Host-side mirror of the reference's assembler interface for the hot path.
+
+``Assembler`` carries the same knobs, with the same names and the same "silently ignore bad
+values" behaviour, as the setters of pandaseq-assembler.h:199-405 / assembler_support.c:177-410,
+and drives the HIP kernel through the C ABI (``include/pandaseq_amd.h``).  PyTorch is used only
+for device memory and streams.  There is no CPU path here.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import ALGO, NUM_COUNTERS, RESULT_DTYPE, Batch, check, lib
+
+
+def _torch():
+    import torch
+    return torch
+
+
+@dataclass
+class DeviceBatch:
+    """A batch of read pairs resident in HBM plus the buffers its results go to."""
+    n: int
+    fwd: "object"       # uint8 [n, fstride, 2]   panda_qual rows
+    rev: "object"       # uint8 [n, rstride, 2]
+    flen: "object"      # int16 storage of uint16 [n]
+    rlen: "object"
+    results: "object"   # uint8 [n, 48]  pamd_pair_result records
+    seq_nt: "object"    # uint8 [capacity]
+    seq_p: "object"     # float64 [capacity]
+    cursor: "object"    # int64 [1]   arena cursor (compact mode)
+    counters: "object"  # int64 [NUM_COUNTERS]
+    seq_stride: int = 0
+
+    @property
+    def capacity(self):
+        return int(self.seq_nt.numel())
+
+    def results_numpy(self):
+        return self.results.cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+
+    def counters_dict(self):
+        return counters_to_dict(self.counters.cpu().numpy())
+
+
+def counters_to_dict(c):
+    c = np.asarray(c)
+    d = {k: int(c[i]) for k, i in _lib.CTR.items()}
+    d["rejected"] = [int(x) for x in c[_lib.CTR_REJECTED0:_lib.CTR_REJECTED0 + _lib.MAX_MODULES]]
+    ov = c[_lib.CTR_OVERLAP0:_lib.CTR_OVERLAP0 + 2 * _lib.MAX_LEN]
+    d["overlapcount"] = ov.astype(np.int64)
+    nz = np.nonzero(ov)[0]
+    # longest_overlap is a running max in the reference (assembler.c:342-344); after summing
+    # histograms it is the highest non-empty bin
+    d["longest_overlap"] = int(nz[-1]) if nz.size else 0
+    return d
+
+
+def alloc_outputs(n, capacity, device, seq_stride=0):
+    torch = _torch()
+    cap = ((int(capacity) + 15) // 16) * 16 + 16
+    return dict(
+        results=torch.empty((n, 48), dtype=torch.uint8, device=device),
+        seq_nt=torch.empty(cap, dtype=torch.uint8, device=device),
+        seq_p=torch.empty(cap, dtype=torch.float64, device=device),
+        cursor=torch.zeros(1, dtype=torch.int64, device=device),
+        counters=torch.zeros(NUM_COUNTERS, dtype=torch.int64, device=device),
+        seq_stride=seq_stride,
+    )
+
+
+def upload_batch(fwd, rev, flen, rlen, device="cuda:0", seq_stride=None, capacity=None):
+    """numpy panda_qual rows -> DeviceBatch.  seq_stride=None picks strided output rows wide enough
+    for any merge; seq_stride=0 selects the compact arena (capacity bases)."""
+    torch = _torch()
+    fwd = np.ascontiguousarray(fwd, dtype=np.uint8)
+    rev = np.ascontiguousarray(rev, dtype=np.uint8)
+    n = fwd.shape[0]
+    fl = np.ascontiguousarray(flen, dtype=np.uint16)
+    rl = np.ascontiguousarray(rlen, dtype=np.uint16)
+    if seq_stride is None:
+        seq_stride = min(2 * _lib.MAX_LEN, fwd.shape[1] + rev.shape[1])
+        seq_stride = ((seq_stride + 15) // 16) * 16
+    if capacity is None:
+        capacity = n * (seq_stride if seq_stride else ((min(900, fwd.shape[1] + rev.shape[1]) + 15) // 16) * 16) + 16384 * 4096
+    outs = alloc_outputs(n, capacity if seq_stride == 0 else n * seq_stride, device, seq_stride)
+    return DeviceBatch(
+        n=n,
+        fwd=torch.from_numpy(fwd).to(device), rev=torch.from_numpy(rev).to(device),
+        flen=torch.from_numpy(fl.view(np.int16)).to(device), rlen=torch.from_numpy(rl.view(np.int16)).to(device),
+        **outs)
+
+
+class Assembler:
+    """The configured overlap assembler on one GPU (mirror of PandaAssembler's hot-path surface)."""
+
+    def __init__(self, device: int = 0):
+        self._h = lib().pamd_assembler_create(int(device))
+        if not self._h:
+            raise _lib.PamdError(lib().pamd_last_error().decode())
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pamd_assembler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- configuration: names follow pandaseq-assembler.h ----
+    def set_algorithm(self, name: str, param: Optional[float] = None):
+        """`-A name[:param]` (args_assembler.c:26-60). param: simple_bayesian -> q; pear -> random-base
+        probability (NOT its log; algo_pear.c:84-89 takes the log)."""
+        if name not in ALGO:
+            raise _lib.PamdError(f"algorithm {name!r} is not on the device path (simple_bayesian, pear, rdp_mle)")
+        p = float("nan") if param is None else float(param)
+        if name == "pear" and param is not None:
+            p = math.log(param)
+        check(lib().pamd_set_algorithm(self._h, ALGO[name], p))
+
+    def set_threshold(self, t: float):
+        check(lib().pamd_set_threshold(self._h, float(t)))
+
+    def set_minimum_overlap(self, v: int):
+        check(lib().pamd_set_minimum_overlap(self._h, int(v)))
+
+    def set_maximum_overlap(self, v: int):
+        check(lib().pamd_set_maximum_overlap(self._h, int(v)))
+
+    def set_forward_primer(self, nt):
+        a = np.ascontiguousarray(nt, dtype=np.uint8)
+        check(lib().pamd_set_forward_primer(self._h, a.ctypes.data, a.size))
+
+    def set_reverse_primer(self, nt):
+        a = np.ascontiguousarray(nt, dtype=np.uint8)
+        check(lib().pamd_set_reverse_primer(self._h, a.ctypes.data, a.size))
+
+    def set_forward_trim(self, n: int):
+        check(lib().pamd_set_forward_trim(self._h, int(n)))
+
+    def set_reverse_trim(self, n: int):
+        check(lib().pamd_set_reverse_trim(self._h, int(n)))
+
+    def set_primer_penalty(self, p: float):
+        check(lib().pamd_set_primer_penalty(self._h, float(p)))
+
+    def add_module(self, spec: str):
+        """`-C name:args` for the two fused check modules (module.c:244-247 splits name from args)."""
+        name, _, args = spec.partition(":")
+        if name == "min_phred":
+            check(lib().pamd_add_module_min_phred(self._h, int(args)))
+        elif name == "min_overlapbits":
+            check(lib().pamd_add_module_min_overlapbits(self._h, float(args) if args else 15.0))
+        else:
+            raise _lib.PamdError(f"module {name!r} is not fused on the device path")
+
+    def clear_modules(self):
+        check(lib().pamd_clear_modules(self._h))
+
+    # ---- the hot path ----
+    def assemble_device(self, b: DeviceBatch, stream=None):
+        """Enqueue the assembly of a device-resident batch on the current (or given) torch stream."""
+        torch = _torch()
+        st = stream if stream is not None else torch.cuda.current_stream(b.fwd.device)
+        cb = Batch()
+        cb.n_pairs = b.n
+        cb.fwd, cb.fwd_stride = b.fwd.data_ptr(), b.fwd.shape[1]
+        cb.rev, cb.rev_stride = b.rev.data_ptr(), b.rev.shape[1]
+        cb.flen, cb.rlen = b.flen.data_ptr(), b.rlen.data_ptr()
+        cb.results = b.results.data_ptr()
+        cb.seq_nt, cb.seq_p = b.seq_nt.data_ptr(), b.seq_p.data_ptr()
+        cb.seq_stride = b.seq_stride
+        cb.seq_capacity = b.capacity - 16
+        cb.seq_cursor = b.cursor.data_ptr()
+        cb.counters = b.counters.data_ptr()
+        check(lib().pamd_assemble_device(self._h, C.byref(cb), C.c_void_p(st.cuda_stream)))
+
+    def last_kernel_ms(self) -> float:
+        return float(lib().pamd_last_kernel_ms(self._h))
+
+    def last_launch_info(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(lib().pamd_last_launch_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"workgroups": a.value, "waves_per_workgroup": b.value, "lds_bytes": c.value}
+
+    def assemble_host(self, fwd, rev, flen, rlen, seq_stride=None):
+        """numpy in, numpy out, through pamd_assemble_host (upload, kernel, download)."""
+        fwd = np.ascontiguousarray(fwd, dtype=np.uint8)
+        rev = np.ascontiguousarray(rev, dtype=np.uint8)
+        fl = np.ascontiguousarray(flen, dtype=np.uint16)
+        rl = np.ascontiguousarray(rlen, dtype=np.uint16)
+        n = fwd.shape[0]
+        if seq_stride is None:
+            seq_stride = ((min(900, fwd.shape[1] + rev.shape[1]) + 15) // 16) * 16
+        cap = n * seq_stride if seq_stride else n * 912 + 16384 * 4096
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        seq_nt = np.zeros(cap, dtype=np.uint8)
+        seq_p = np.zeros(cap, dtype=np.float64)
+        ctr = np.zeros(NUM_COUNTERS, dtype=np.int64)
+        cur = np.zeros(1, dtype=np.uint64)
+        cb = Batch()
+        cb.n_pairs = n
+        cb.fwd, cb.fwd_stride = fwd.ctypes.data, fwd.shape[1]
+        cb.rev, cb.rev_stride = rev.ctypes.data, rev.shape[1]
+        cb.flen, cb.rlen = fl.ctypes.data, rl.ctypes.data
+        cb.results = res.ctypes.data
+        cb.seq_nt, cb.seq_p = seq_nt.ctypes.data, seq_p.ctypes.data
+        cb.seq_stride, cb.seq_capacity = seq_stride, cap
+        cb.seq_cursor = cur.ctypes.data
+        cb.counters = ctr.ctypes.data
+        check(lib().pamd_assemble_host(self._h, C.byref(cb)))
+        return res, seq_nt, seq_p, counters_to_dict(ctr)

@@ -1,0 +1,561 @@
+// pamd_api.cpp -- the C ABI declared in include/pandaseq_amd.h.
+//
+// Host side of the hot path: owns the assembler configuration (the fields of struct
+// panda_assembler that align()/assemble_seq() read, assembler.h:44-57,72-78), keeps the
+// probability tables and primers resident in HBM, sizes the persistent launch and its LDS
+// carve-up for each batch, and enqueues the kernel.  There is no CPU implementation behind
+// these entry points: without a GPU they fail.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "pamd_internal.h"
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+#define HIP_TRY(call)                                                                       \
+	do {                                                                                \
+		hipError_t e_ = (call);                                                     \
+		if (e_ != hipSuccess) {                                                     \
+			pamd_set_error("%s: %s", #call, hipGetErrorString(e_));             \
+			return PAMD_ENODEVICE;                                              \
+		}                                                                           \
+	} while (0)
+
+constexpr size_t LDS_LIMIT = 160 * 1024;	// per CU on gfx950
+constexpr int MAX_WAVES_PER_WG = 16;
+
+inline uint32_t up16(uint32_t v) {
+	return (v + 15u) & ~15u;
+}
+
+}	// namespace
+
+void pamd_set_error(const char *fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_error, sizeof g_error, fmt, ap);
+	va_end(ap);
+}
+
+struct pamd_assembler {
+	int device = 0;
+	int cu_count = 0;
+	// configuration
+	int algo = PAMD_ALGO_SIMPLE_BAYES;
+	double sb_q = 0.36, sb_pmatch = 0, sb_pmismatch = 0;
+	double pear_random_base = 0;
+	double threshold = 0;
+	int minoverlap = 2;
+	int maxoverlap = 0;
+	uint8_t primers[912];
+	int fprimer_len = 0, rprimer_len = 0;
+	int ftrim = 0, rtrim = 0;
+	double primer_penalty = 0;
+	int n_modules = 0;
+	PamdModule modules[PAMD_MAX_MODULES];
+	// tables
+	PamdTables tabs;
+	double *d_tables = nullptr;	// image for the current algorithm
+	int d_tables_algo = -1;
+	uint8_t *d_primers = nullptr;
+	bool primers_dirty = true;
+	unsigned long long *d_error = nullptr;
+	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+	bool timed = false;
+	int last_wgs = 0, last_waves = 0, last_lds = 0;
+};
+
+extern "C" {
+
+const char *pamd_last_error(void) {
+	return g_error;
+}
+
+int pamd_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+int pamd_tables_get(double *out, size_t n_doubles) {
+	if (out == nullptr || n_doubles < PAMD_TABLE_DOUBLES) {
+		pamd_set_error("pamd_tables_get: need room for %d doubles", PAMD_TABLE_DOUBLES);
+		return PAMD_EINVAL;
+	}
+	PamdTables *t = new (std::nothrow) PamdTables;
+	if (t == nullptr)
+		return PAMD_ENOMEM;
+	pamd_build_tables(t);
+	double *o = out;
+	*o++ = t->qual_nn;
+	memcpy(o, t->score, sizeof t->score);
+	o += PAMD_NQ;
+	memcpy(o, t->score_err, sizeof t->score_err);
+	o += PAMD_NQ;
+	const double *mats[6] = { t->match_sb, t->mismatch_sb, t->match_pear, t->mismatch_pear, t->mismatch_rdp, t->mismatch_rdp_asm };
+	for (int m = 0; m < 6; m++) {
+		memcpy(o, mats[m], sizeof(double) * PAMD_TAB);
+		o += PAMD_TAB;
+	}
+	delete t;
+	return PAMD_OK;
+}
+
+static void set_sb_q(pamd_assembler *a, double q) {	// algo_simple_bayes.c:126-135
+	if (q > 0 && q < 1) {
+		a->sb_q = q;
+		a->sb_pmatch = std::log(0.25 * (1 - 2 * q + q * q));
+		a->sb_pmismatch = std::log((3 * q - 2 * q * q) / 18.0);
+	}
+}
+
+pamd_assembler *pamd_assembler_create(int device) {
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) {
+		pamd_set_error("no HIP device available (%s); the overlap assembler has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+		return nullptr;
+	}
+	if (device < 0 || device >= n) {
+		pamd_set_error("device %d out of range (0..%d)", device, n - 1);
+		return nullptr;
+	}
+	pamd_assembler *a = new (std::nothrow) pamd_assembler;
+	if (a == nullptr)
+		return nullptr;
+	a->device = device;
+	hipDeviceProp_t prop;
+	if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+		pamd_set_error("cannot query device %d", device);
+		delete a;
+		return nullptr;
+	}
+	a->cu_count = prop.multiProcessorCount;
+	pamd_build_tables(&a->tabs);
+	set_sb_q(a, 0.36);	// algo_simple_bayes.c:113
+	a->pear_random_base = std::log(0.25);	// algo_pear.c:106
+	a->threshold = std::log(0.6);	// assembler_support.c:76
+	memset(a->primers, 0, sizeof a->primers);
+	if (hipMalloc(&a->d_tables, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_primers, sizeof a->primers) != hipSuccess || hipMalloc(&a->d_error, sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_error, 0, sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&a->ev_start) != hipSuccess || hipEventCreate(&a->ev_stop) != hipSuccess) {
+		pamd_set_error("device allocation failed on device %d", device);
+		pamd_assembler_destroy(a);
+		return nullptr;
+	}
+	return a;
+}
+
+void pamd_assembler_destroy(pamd_assembler *a) {
+	if (a == nullptr)
+		return;
+	(void) hipSetDevice(a->device);
+	if (a->d_tables)
+		(void) hipFree(a->d_tables);
+	if (a->d_primers)
+		(void) hipFree(a->d_primers);
+	if (a->d_error)
+		(void) hipFree(a->d_error);
+	if (a->ev_start)
+		(void) hipEventDestroy(a->ev_start);
+	if (a->ev_stop)
+		(void) hipEventDestroy(a->ev_stop);
+	delete a;
+}
+
+int pamd_set_algorithm(pamd_assembler *a, int algo, double param) {
+	if (a == nullptr || algo < 0 || algo > PAMD_ALGO_RDP_MLE) {
+		pamd_set_error("pamd_set_algorithm: unknown algorithm %d (only simple_bayesian, pear, rdp_mle run on the device)", algo);
+		return PAMD_EUNSUPPORTED;
+	}
+	a->algo = algo;
+	if (algo == PAMD_ALGO_SIMPLE_BAYES) {
+		set_sb_q(a, std::isnan(param) ? 0.36 : param);
+	} else if (algo == PAMD_ALGO_PEAR) {
+		a->pear_random_base = std::isnan(param) ? std::log(0.25) : param;
+	}
+	return PAMD_OK;
+}
+
+int pamd_set_threshold(pamd_assembler *a, double threshold) {	// assembler_support.c:391-397
+	if (threshold > 0 && threshold < 1)
+		a->threshold = std::log(threshold);
+	return PAMD_OK;
+}
+
+int pamd_set_minimum_overlap(pamd_assembler *a, int overlap) {	// assembler_support.c:276-282
+	if (overlap > 1 && overlap < 2 * PAMD_MAX_LEN)
+		a->minoverlap = overlap;
+	return PAMD_OK;
+}
+
+int pamd_set_maximum_overlap(pamd_assembler *a, int overlap) {	// assembler_support.c:289-295
+	if (overlap >= 0 && overlap < 2 * PAMD_MAX_LEN)
+		a->maxoverlap = overlap;
+	return PAMD_OK;
+}
+
+int pamd_set_forward_primer(pamd_assembler *a, const uint8_t *nt, size_t length) {	// assembler_support.c:201-213
+	if (length < PAMD_MAX_LEN) {
+		if (length > 0)
+			memcpy(a->primers, nt, length);
+		a->fprimer_len = (int) length;
+		a->ftrim = 0;
+		a->primers_dirty = true;
+	}
+	return PAMD_OK;
+}
+
+int pamd_set_reverse_primer(pamd_assembler *a, const uint8_t *nt, size_t length) {	// assembler_support.c:347-359
+	if (length < PAMD_MAX_LEN) {
+		if (length > 0)
+			memcpy(a->primers + 456, nt, length);
+		a->rprimer_len = (int) length;
+		a->rtrim = 0;
+		a->primers_dirty = true;
+	}
+	return PAMD_OK;
+}
+
+int pamd_set_forward_trim(pamd_assembler *a, size_t trim) {	// assembler_support.c:244-249
+	a->ftrim = (int) (trim > 65535 ? 65535 : trim);
+	a->fprimer_len = 0;
+	return PAMD_OK;
+}
+
+int pamd_set_reverse_trim(pamd_assembler *a, size_t trim) {	// assembler_support.c:374-379
+	a->rtrim = (int) (trim > 65535 ? 65535 : trim);
+	a->rprimer_len = 0;
+	return PAMD_OK;
+}
+
+int pamd_set_primer_penalty(pamd_assembler *a, double penalty) {	// assembler_support.c:404-410
+	if (penalty >= 0 && penalty < 1)
+		a->primer_penalty = penalty;
+	return PAMD_OK;
+}
+
+int pamd_add_module_min_phred(pamd_assembler *a, int phred) {	// plugin_min_phred.c:24-44
+	if (a->n_modules >= PAMD_MAX_MODULES || phred < 0 || phred > 127) {
+		pamd_set_error("min_phred: value must be 0..127 and at most %d modules", PAMD_MAX_MODULES);
+		return PAMD_EINVAL;
+	}
+	a->modules[a->n_modules].kind = 1;
+	a->modules[a->n_modules].phred = phred;
+	a->modules[a->n_modules].nats = 0;
+	a->n_modules++;
+	return PAMD_OK;
+}
+
+int pamd_add_module_min_overlapbits(pamd_assembler *a, double bits) {	// plugin_min_overlapbits.c:25-53
+	const double nats = bits * 0.69314718055994530942;	// M_LN2
+	if (a->n_modules >= PAMD_MAX_MODULES || !(nats >= 0)) {
+		pamd_set_error("min_overlapbits: value out of range or more than %d modules", PAMD_MAX_MODULES);
+		return PAMD_EINVAL;
+	}
+	a->modules[a->n_modules].kind = 2;
+	a->modules[a->n_modules].phred = 0;
+	a->modules[a->n_modules].nats = nats;
+	a->n_modules++;
+	return PAMD_OK;
+}
+
+int pamd_clear_modules(pamd_assembler *a) {
+	a->n_modules = 0;
+	return PAMD_OK;
+}
+
+static int upload_tables(pamd_assembler *a, hipStream_t st) {
+	if (a->d_tables_algo != a->algo) {
+		std::vector<double> img(PAMD_LT_C + PAMD_TAB, 0.0);
+		memcpy(&img[PAMD_LT_SCORE], a->tabs.score, sizeof a->tabs.score);
+		memcpy(&img[PAMD_LT_ERR], a->tabs.score_err, sizeof a->tabs.score_err);
+		const double *A, *B, *C = nullptr;
+		switch (a->algo) {
+		case PAMD_ALGO_PEAR:	// algo_pear.c:52-54,67
+			A = a->tabs.match_pear;
+			B = a->tabs.mismatch_pear;
+			break;
+		case PAMD_ALGO_RDP_MLE:	// algo_rdp_mle.c:68-70 (scan), :39 (merge)
+			A = a->tabs.match_sb;
+			B = a->tabs.mismatch_rdp;
+			C = a->tabs.mismatch_rdp_asm;
+			break;
+		default:	// algo_simple_bayes.c:74
+			A = a->tabs.match_sb;
+			B = a->tabs.mismatch_sb;
+			break;
+		}
+		memcpy(&img[PAMD_LT_A], A, sizeof(double) * PAMD_TAB);
+		memcpy(&img[PAMD_LT_B], B, sizeof(double) * PAMD_TAB);
+		if (C)
+			memcpy(&img[PAMD_LT_C], C, sizeof(double) * PAMD_TAB);
+		// synchronous on purpose: `img` is a stack-lifetime host buffer
+		HIP_TRY(hipMemcpy(a->d_tables, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
+		a->d_tables_algo = a->algo;
+	}
+	if (a->primers_dirty) {
+		HIP_TRY(hipMemcpy(a->d_primers, a->primers, sizeof a->primers, hipMemcpyHostToDevice));
+		a->primers_dirty = false;
+	}
+	(void) st;
+	return PAMD_OK;
+}
+
+int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
+	if (a == nullptr || b == nullptr) {
+		pamd_set_error("pamd_assemble_device: null argument");
+		return PAMD_EINVAL;
+	}
+	HIP_TRY(hipSetDevice(a->device));
+	if (b->n_pairs == 0)
+		return PAMD_OK;
+	if (b->fwd == nullptr || b->rev == nullptr || b->flen == nullptr || b->rlen == nullptr || b->results == nullptr || b->seq_nt == nullptr || b->seq_p == nullptr) {
+		pamd_set_error("pamd_assemble_device: batch has null buffers");
+		return PAMD_EINVAL;
+	}
+	if (b->fwd_stride % 8 || b->rev_stride % 8 || b->fwd_stride == 0 || b->rev_stride == 0 || b->fwd_stride > 456 || b->rev_stride > 456) {
+		pamd_set_error("row strides must be multiples of 8 bases in [8,456] (got %zu, %zu)", b->fwd_stride, b->rev_stride);
+		return PAMD_EINVAL;
+	}
+	if (((uintptr_t) b->fwd | (uintptr_t) b->rev | (uintptr_t) b->seq_nt | (uintptr_t) b->seq_p) & 15u) {
+		pamd_set_error("fwd, rev, seq_nt and seq_p must be 16-byte aligned");
+		return PAMD_EINVAL;
+	}
+	if (b->seq_stride % 16) {
+		pamd_set_error("seq_stride must be a multiple of 16 (got %zu)", b->seq_stride);
+		return PAMD_EINVAL;
+	}
+	if (b->seq_stride == 0 && b->seq_cursor == nullptr) {
+		pamd_set_error("compact output (seq_stride == 0) needs seq_cursor");
+		return PAMD_EINVAL;
+	}
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	int rc = upload_tables(a, st);
+	if (rc != PAMD_OK)
+		return rc;
+
+	PamdKernelParams p;
+	memset(&p, 0, sizeof p);
+	p.fwd = reinterpret_cast<const uint8_t *>(b->fwd);
+	p.rev = reinterpret_cast<const uint8_t *>(b->rev);
+	p.flen = b->flen;
+	p.rlen = b->rlen;
+	p.results = b->results;
+	p.seq_nt = b->seq_nt;
+	p.seq_p = b->seq_p;
+	p.seq_cursor = reinterpret_cast<unsigned long long *>(b->seq_cursor);
+	p.counters = reinterpret_cast<unsigned long long *>(b->counters);
+	p.error_flag = a->d_error;
+	p.tables = a->d_tables;
+	p.primers = a->d_primers;
+	p.n_pairs = b->n_pairs;
+	p.seq_stride = b->seq_stride;
+	p.seq_capacity = b->seq_capacity;
+	p.fwd_row_bytes = (uint32_t) b->fwd_stride * 2u;
+	p.rev_row_bytes = (uint32_t) b->rev_stride * 2u;
+	p.algo = a->algo;
+	p.minoverlap = a->minoverlap;
+	p.maxoverlap = a->maxoverlap;
+	p.fprimer_len = a->fprimer_len;
+	p.rprimer_len = a->rprimer_len;
+	p.ftrim = a->ftrim;
+	p.rtrim = a->rtrim;
+	p.n_modules = a->n_modules;
+	p.threshold = a->threshold;
+	p.primer_penalty = a->primer_penalty;
+	p.qual_nn = a->tabs.qual_nn;
+	p.sb_pmatch = a->sb_pmatch;
+	p.sb_pmismatch = a->sb_pmismatch;
+	p.pear_random_base = a->pear_random_base;
+	memcpy(p.modules, a->modules, sizeof p.modules);
+
+	// LDS carve-up (DESIGN.md "LDS layout")
+	const uint32_t smax = (uint32_t) (b->fwd_stride > b->rev_stride ? b->fwd_stride : b->rev_stride);
+	uint32_t mmax = 2 * smax;
+	if (mmax > 2 * PAMD_MAX_LEN)
+		mmax = 2 * PAMD_MAX_LEN;
+	mmax = up16(mmax);
+	p.smax = smax;
+	p.mmax = mmax;
+	p.lds_table_doubles = (a->algo == PAMD_ALGO_RDP_MLE) ? (PAMD_LT_C + PAMD_TAB) : PAMD_LT_C;
+	p.lds_ctr_off = up16(p.lds_table_doubles * 8u);
+	p.lds_alloc_off = 0;
+	p.lds_wave_off = up16(p.lds_ctr_off + PAMD_NUM_COUNTERS * 4u);
+	uint32_t o = 0;
+	p.w_fwd = o;
+	o += smax * 2u;
+	p.w_rev = o;
+	o += smax * 2u;
+	p.w_fc = o;
+	o += 128;
+	p.w_rc = o;
+	o += 128;
+	p.w_fn = o;
+	o += 64;
+	p.w_rn = o;
+	o += 64;
+	p.w_bits = o;
+	o += 128;
+	p.w_nt = o;
+	o += mmax;
+	p.w_p = o;
+	o += (mmax * 8u > 2048u ? mmax * 8u : 2048u);
+	p.lds_wave_bytes = up16(o);
+
+	int waves = (int) ((LDS_LIMIT - p.lds_wave_off) / p.lds_wave_bytes);
+	if (waves > MAX_WAVES_PER_WG)
+		waves = MAX_WAVES_PER_WG;
+	if (waves < 1) {
+		pamd_set_error("batch does not fit in LDS");
+		return PAMD_EINVAL;
+	}
+	size_t want_wgs = (b->n_pairs + (size_t) waves - 1) / (size_t) waves;
+	int wgs = a->cu_count > 0 ? a->cu_count : 256;
+	if ((size_t) wgs > want_wgs)
+		wgs = (int) want_wgs;
+	const size_t lds_bytes = p.lds_wave_off + (size_t) waves * p.lds_wave_bytes;
+	a->last_wgs = wgs;
+	a->last_waves = waves;
+	a->last_lds = (int) lds_bytes;
+
+	HIP_TRY(hipEventRecord(a->ev_start, st));
+	rc = pamd_launch_assemble(p, wgs, waves, lds_bytes, stream);
+	if (rc != PAMD_OK)
+		return rc;
+	HIP_TRY(hipEventRecord(a->ev_stop, st));
+	a->timed = true;
+	return PAMD_OK;
+}
+
+float pamd_last_kernel_ms(pamd_assembler *a) {
+	if (a == nullptr || !a->timed)
+		return -1.0f;
+	float ms = -1.0f;
+	if (hipEventSynchronize(a->ev_stop) != hipSuccess)
+		return -1.0f;
+	if (hipEventElapsedTime(&ms, a->ev_start, a->ev_stop) != hipSuccess)
+		return -1.0f;
+	return ms;
+}
+
+int pamd_last_launch_info(pamd_assembler *a, int *workgroups, int *waves_per_workgroup, int *lds_bytes) {
+	if (a == nullptr)
+		return PAMD_EINVAL;
+	if (workgroups)
+		*workgroups = a->last_wgs;
+	if (waves_per_workgroup)
+		*waves_per_workgroup = a->last_waves;
+	if (lds_bytes)
+		*lds_bytes = a->last_lds;
+	return PAMD_OK;
+}
+
+int pamd_assemble_host(pamd_assembler *a, const pamd_batch *hb) {
+	if (a == nullptr || hb == nullptr) {
+		pamd_set_error("pamd_assemble_host: null argument");
+		return PAMD_EINVAL;
+	}
+	HIP_TRY(hipSetDevice(a->device));
+	const size_t n = hb->n_pairs;
+	if (n == 0)
+		return PAMD_OK;
+	const size_t cap = hb->seq_stride ? hb->seq_stride * n : hb->seq_capacity;
+	pamd_batch d = *hb;
+	void *dfwd = nullptr, *drev = nullptr, *dfl = nullptr, *drl = nullptr, *dres = nullptr, *dnt = nullptr, *dp = nullptr, *dcur = nullptr, *dctr = nullptr;
+	int rc = PAMD_OK;
+	auto fail = [&](int code) {
+		void *all[] = { dfwd, drev, dfl, drl, dres, dnt, dp, dcur, dctr };
+		for (void *q : all)
+			if (q)
+				(void) hipFree(q);
+		return code;
+	};
+#define HIP_TRY2(call)                                                          \
+	do {                                                                    \
+		hipError_t e_ = (call);                                         \
+		if (e_ != hipSuccess) {                                         \
+			pamd_set_error("%s: %s", #call, hipGetErrorString(e_)); \
+			return fail(PAMD_ENODEVICE);                            \
+		}                                                               \
+	} while (0)
+	HIP_TRY2(hipMalloc(&dfwd, n * hb->fwd_stride * 2));
+	HIP_TRY2(hipMalloc(&drev, n * hb->rev_stride * 2));
+	HIP_TRY2(hipMalloc(&dfl, n * 2));
+	HIP_TRY2(hipMalloc(&drl, n * 2));
+	HIP_TRY2(hipMalloc(&dres, n * sizeof(pamd_pair_result)));
+	HIP_TRY2(hipMalloc(&dnt, cap + 16));
+	HIP_TRY2(hipMalloc(&dp, (cap + 16) * sizeof(double)));
+	HIP_TRY2(hipMalloc(&dcur, 8));
+	HIP_TRY2(hipMalloc(&dctr, PAMD_NUM_COUNTERS * 8));
+	HIP_TRY2(hipMemcpy(dfwd, hb->fwd, n * hb->fwd_stride * 2, hipMemcpyHostToDevice));
+	HIP_TRY2(hipMemcpy(drev, hb->rev, n * hb->rev_stride * 2, hipMemcpyHostToDevice));
+	HIP_TRY2(hipMemcpy(dfl, hb->flen, n * 2, hipMemcpyHostToDevice));
+	HIP_TRY2(hipMemcpy(drl, hb->rlen, n * 2, hipMemcpyHostToDevice));
+	HIP_TRY2(hipMemset(dcur, 0, 8));
+	HIP_TRY2(hipMemset(dctr, 0, PAMD_NUM_COUNTERS * 8));
+	HIP_TRY2(hipMemset(a->d_error, 0, 8));
+	d.fwd = static_cast<const pamd_qual *>(dfwd);
+	d.rev = static_cast<const pamd_qual *>(drev);
+	d.flen = static_cast<const uint16_t *>(dfl);
+	d.rlen = static_cast<const uint16_t *>(drl);
+	d.results = static_cast<pamd_pair_result *>(dres);
+	d.seq_nt = static_cast<uint8_t *>(dnt);
+	d.seq_p = static_cast<double *>(dp);
+	d.seq_cursor = static_cast<uint64_t *>(dcur);
+	d.counters = static_cast<int64_t *>(dctr);
+	d.seq_capacity = cap;
+	rc = pamd_assemble_device(a, &d, nullptr);
+	if (rc != PAMD_OK)
+		return fail(rc);
+	HIP_TRY2(hipDeviceSynchronize());
+	unsigned long long overflow = 0;
+	HIP_TRY2(hipMemcpy(&overflow, a->d_error, 8, hipMemcpyDeviceToHost));
+	HIP_TRY2(hipMemcpy(hb->results, dres, n * sizeof(pamd_pair_result), hipMemcpyDeviceToHost));
+	HIP_TRY2(hipMemcpy(hb->seq_nt, dnt, cap, hipMemcpyDeviceToHost));
+	HIP_TRY2(hipMemcpy(hb->seq_p, dp, cap * sizeof(double), hipMemcpyDeviceToHost));
+	if (hb->seq_cursor)
+		HIP_TRY2(hipMemcpy(hb->seq_cursor, dcur, 8, hipMemcpyDeviceToHost));
+	if (hb->counters) {
+		std::vector<int64_t> tmp(PAMD_NUM_COUNTERS);
+		HIP_TRY2(hipMemcpy(tmp.data(), dctr, PAMD_NUM_COUNTERS * 8, hipMemcpyDeviceToHost));
+		for (int i = 0; i < PAMD_NUM_COUNTERS; i++)
+			hb->counters[i] += tmp[i];
+	}
+	fail(0);
+	if (overflow) {
+		pamd_set_error("output arena too small: %llu accepted pairs did not fit in seq_capacity=%zu bases", overflow, cap);
+		return PAMD_EINVAL;
+	}
+	return PAMD_OK;
+}
+
+int pamd_synth_generate(int device, const pamd_synth_spec *spec, const uint32_t *thresholds_host, uint64_t first, size_t n, pamd_qual *fwd, pamd_qual *rev, size_t stride, uint16_t *flen, uint16_t *rlen, void *stream) {
+	if (spec == nullptr || thresholds_host == nullptr || fwd == nullptr || rev == nullptr || flen == nullptr || rlen == nullptr) {
+		pamd_set_error("pamd_synth_generate: null argument");
+		return PAMD_EINVAL;
+	}
+	if (spec->read_len == 0 || spec->read_len > PAMD_MAX_LEN || stride < spec->read_len || spec->tmin < spec->read_len || spec->tmax < spec->tmin || spec->tmax > 1024 || spec->fprimer_len > 32 || spec->rprimer_len > 32) {
+		pamd_set_error("pamd_synth_generate: spec out of range");
+		return PAMD_EINVAL;
+	}
+	HIP_TRY(hipSetDevice(device));
+	PamdSynthParams p;
+	p.spec = *spec;
+	memcpy(p.thr, thresholds_host, sizeof p.thr);
+	p.first = first;
+	p.n = n;
+	p.fwd = reinterpret_cast<uint8_t *>(fwd);
+	p.rev = reinterpret_cast<uint8_t *>(rev);
+	p.flen = flen;
+	p.rlen = rlen;
+	p.stride = (uint32_t) stride;
+	return pamd_launch_synth(p, stream);
+}
+
+}	// extern "C"
