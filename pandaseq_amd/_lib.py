@@ -80,6 +80,14 @@ def lib():
         raise LibraryMissing(
             f"{LIB_PATH} is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C pandaseq_amd/csrc`). There is no CPU fallback for the assembly path.")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 (same SONAME as /opt/rocm's).
+    # Importing torch first makes the loader bind our NEEDED libamdhip64.so.7 to that copy; loading
+    # ours first would pull in /opt/rocm's and torch would then bring a second runtime that sees
+    # no devices ("No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.pamd_last_error.restype = C.c_char_p
     L.pamd_device_count.restype = C.c_int
