@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- merged read-pairs/s of the overlap-assembly hot path on MI355X.
+
+A "step" is one pass of the hot path (one pamd_assemble_device launch) over one batch of synthetic
+read pairs that is already resident in HBM.  Default workload = BASELINE.json configs[1]:
+50 M synthetic 2x250 bp pairs, -A simple_bayesian, one GPU.  With --gpus N every rank owns its own
+50 M-pair shard (weak scaling); the only collective is one RCCL all-reduce of the STAT counters per
+step.  Rank 0 prints ONE JSON line.
+
+    python bench.py                     # N=1, defaults
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           --master-port 29500 bench.py --gpus 8 --steps 5 --warmup 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+CONFIGS = {
+    0: dict(algo="simple_bayesian", pairs=10_000, name="10k synthetic 2x150 bp pairs, 40 bp overlap, simple_bayesian"),
+    1: dict(algo="simple_bayesian", pairs=50_000_000, name="50M synthetic 2x250 bp pairs, simple_bayesian"),
+    2: dict(algo="pear", pairs=50_000_000, name="50M MiSeq-style 2x300 bp pairs with primers (-p/-q), pear"),
+    3: dict(algo="rdp_mle", pairs=50_000_000, name="2x250 bp pairs, rdp_mle + min_phred + min_overlapbits (50M per GPU)"),
+    4: dict(algo="simple_bayesian", pairs=125_000_000, name="NovaSeq-style 2x150 bp pairs, simple_bayesian (125M per GPU)"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs[] index")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (0 = the config's size)")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-clock target of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--traffic-bytes", type=float, default=None, help="PMC-measured HBM bytes per launch (from profiles/)")
+    return ap.parse_args()
+
+
+def setup_assembler(pa, synth, cfg_index, device_index):
+    asm = pa.Assembler(device_index)
+    spec = synth.config_spec(cfg_index)
+    c = CONFIGS[cfg_index]
+    asm.set_algorithm(c["algo"])
+    if cfg_index == 2:
+        asm.set_forward_primer(synth.nt_codes(spec.fprimer))
+        asm.set_reverse_primer(synth.nt_codes(spec.rprimer, complement=True))
+    if cfg_index == 3:
+        asm.add_module("min_phred:2")
+        asm.add_module("min_overlapbits:15")
+    return asm, spec
+
+
+def oracle_config(po, synth, cfg_index):
+    spec = synth.config_spec(cfg_index)
+    kw = {}
+    if cfg_index == 2:
+        kw = dict(fprimer=synth.nt_codes(spec.fprimer), rprimer=synth.nt_codes(spec.rprimer, complement=True))
+    if cfg_index == 3:
+        kw = dict(modules=[("min_phred", 2), ("min_overlapbits", 15)])
+    return po.make_config(CONFIGS[cfg_index]["algo"], **kw)
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    import pandaseq_amd as pa
+    from pandaseq_amd import _lib, synth
+    from pandaseq_amd.stats import allreduce_counters
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with that many ranks (WORLD_SIZE={world})")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    cfg_index = args.config
+    n = args.pairs or CONFIGS[cfg_index]["pairs"]
+    asm, spec = setup_assembler(pa, synth, cfg_index, local)
+    L = spec.read_len
+
+    # ---- calibrate the arena on the first pairs, then build the full shard in HBM ----
+    ncal = min(n, 1 << 20)
+    first = rank * n  # contiguous shards of the global pair index space
+
+    def make_batch(count, start, capacity):
+        f, r, fl, rl = synth.generate_device(spec, start, count, device=dev)
+        outs = pa.alloc_outputs(count, capacity, dev, seq_stride=0)
+        return pa.DeviceBatch(n=count, fwd=f, rev=r, flen=fl, rlen=rl, **outs)
+
+    cal = make_batch(ncal, first, ncal * 912)
+    asm.assemble_device(cal)
+    torch.cuda.synchronize()
+    used = int(cal.cursor.item())
+    per_pair = used / ncal
+    del cal
+    torch.cuda.empty_cache()
+    while True:
+        try:
+            capacity = int(n * per_pair * 1.03) + (1 << 27)
+            batch = make_batch(n, first, capacity)
+            break
+        except torch.OutOfMemoryError:
+            torch.cuda.empty_cache()
+            n //= 2
+            if n < 1024:
+                raise
+    torch.cuda.synchronize()
+
+    def one_step(ev0=None, ev1=None):
+        batch.cursor.zero_()
+        batch.counters.zero_()
+        if ev0 is not None:
+            ev0.record()
+        asm.assemble_device(batch)
+        if ev1 is not None:
+            ev1.record()
+        if dist is not None:
+            allreduce_counters(batch.counters)  # the ONE collective: STAT counters, int64 x 916
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(*evs[k])
+    fence()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: nothing overflowed, every pair was seen
+    ctr = batch.counters_dict()
+    total_expected = n * world if dist is not None else n
+    assert ctr["count"] == total_expected, (ctr["count"], total_expected)
+    assert int(batch.cursor.item()) <= batch.capacity - 16, "output arena overflow"
+
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+    avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
+
+    # algorithmic bytes per launch: 2*(Lf+Lr) + 9*M + 64 per pair, M = merged length of accepted pairs
+    res = batch.results
+    seq_len = res[:, 24:26].contiguous().view(torch.int16).to(torch.int64).flatten() & 0xFFFF
+    status = res[:, 38].to(torch.int64)
+    merged_bases = int((seq_len * (status == 0)).sum().item())
+    lens = int((batch.flen.to(torch.int64) & 0xFFFF).sum().item() + (batch.rlen.to(torch.int64) & 0xFFFF).sum().item())
+    algo_bytes = 2 * lens + 9 * merged_bases + 64 * n
+    achieved = algo_bytes / avg_kernel_s / 1e9
+
+    value = n * world * args.steps / elapsed
+    out = {
+        "metric": "merged read-pairs/sec",
+        "value": value,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8+f64",
+        "data": "synthetic",
+        "config": {
+            "workload": CONFIGS[cfg_index]["name"],
+            "config_index": cfg_index,
+            "pairs_per_gpu": n,
+            "read_len": L,
+            "algorithm": CONFIGS[cfg_index]["algo"],
+            "sharding": f"{world} contiguous shard(s), one RCCL all-reduce of STAT counters per step" if world > 1 else "single GPU",
+            "output": "compact arena, nt u8 + log-p f64 per merged base",
+            "launch": asm.last_launch_info(),
+        },
+        "stat": {k: ctr[k] for k in ("count", "ok", "noalgn", "lowq", "badr", "nofp", "norp", "slow")},
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "pamd_assemble_kernel",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": args.traffic_bytes,
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "bytes_per_pair": algo_bytes / n,
+            "kernel_ms_avg": avg_kernel_s * 1e3,
+        },
+    }
+    if ctr["rejected"][0] or ctr["rejected"][1]:
+        out["stat"]["rejected"] = ctr["rejected"][:2]
+
+    # ---- CPU baseline: the oracle (a scalar C port of the reference path) on this host's cores ----
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import pyoracle as po
+        threads = len(os.sched_getaffinity(0))
+        ocfg = oracle_config(po, synth, cfg_index)
+        probe = 20000
+        hf = batch.fwd[:probe].cpu().numpy()
+        hr = batch.rev[:probe].cpu().numpy()
+        hfl = batch.flen[:probe].cpu().numpy().view(np.uint16)
+        hrl = batch.rlen[:probe].cpu().numpy().view(np.uint16)
+        c0 = time.perf_counter()
+        po.assemble_batch(ocfg, hf, hr, hfl, hrl, want_seq=False, threads=1)
+        rate1 = probe / (time.perf_counter() - c0)
+        sample = int(min(n, max(probe, rate1 * threads * args.cpu_seconds)))
+        sample = min(sample, 4_000_000)
+        hf = batch.fwd[:sample].cpu().numpy()
+        hr = batch.rev[:sample].cpu().numpy()
+        hfl = batch.flen[:sample].cpu().numpy().view(np.uint16)
+        hrl = batch.rlen[:sample].cpu().numpy().view(np.uint16)
+        c0 = time.perf_counter()
+        o_res, _, _, o_ctr = po.assemble_batch(ocfg, hf, hr, hfl, hrl, want_seq=True if sample <= 200_000 else False, threads=threads)
+        cpu_s = time.perf_counter() - c0
+        # the sample doubles as an at-scale parity check of statuses and overlaps
+        dres = batch.results[:sample].cpu().numpy().view(_lib.RESULT_DTYPE).reshape(-1)
+        same = bool((dres["status"] == o_res["status"]).all() and (dres["overlap"][o_res["status"] == 0] == o_res["overlap"][o_res["status"] == 0]).all())
+        out["cpu_baseline"] = {
+            "value": sample / cpu_s,
+            "unit": "pairs/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": f"first {sample} pairs of the same batch, oracle C port, {threads} pthreads over contiguous slices, in-memory (no FASTQ parsing), merged sequence {'kept' if sample <= 200_000 else 'discarded'}",
+            "single_thread_pairs_per_s": rate1,
+            "matches_gpu_on_sample": same,
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
