@@ -165,6 +165,10 @@ int pamd_assemble_host(pamd_assembler *a, const pamd_batch *batch);
 /* HIP-event time in milliseconds of the most recent pamd_assemble_device() kernel on this
  * assembler (synchronises on it); < 0 if none. */
 float pamd_last_kernel_ms(pamd_assembler *a);
+/* Debug aid: per-phase shader-cycle totals accumulated by a -DPAMD_PHASE_TIMING build of the
+ * library (all zero in the shipped build). out10: stage, offsets, seed-fwd, seed-rev, scan, merge,
+ * sums, filters+write, (unused), whole-wave. */
+int pamd_debug_phase_cycles(pamd_assembler *a, unsigned long long *out10, int reset);
 /* persistent-launch geometry actually used by the last launch */
 int pamd_last_launch_info(pamd_assembler *a, int *workgroups, int *waves_per_workgroup, int *lds_bytes);
 

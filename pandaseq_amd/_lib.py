@@ -68,7 +68,7 @@ SYMBOLS = [
     "pamd_set_forward_primer", "pamd_set_reverse_primer", "pamd_set_forward_trim", "pamd_set_reverse_trim",
     "pamd_set_primer_penalty", "pamd_add_module_min_phred", "pamd_add_module_min_overlapbits",
     "pamd_clear_modules", "pamd_tables_get", "pamd_assemble_device", "pamd_assemble_host",
-    "pamd_last_kernel_ms", "pamd_last_launch_info", "pamd_synth_generate",
+    "pamd_last_kernel_ms", "pamd_last_launch_info", "pamd_synth_generate", "pamd_debug_phase_cycles",
 ]
 
 
@@ -76,9 +76,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("PAMD_LIB", LIB_PATH)
+    if not os.path.exists(path):
         raise LibraryMissing(
-            f"{LIB_PATH} is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C pandaseq_amd/csrc`). There is no CPU fallback for the assembly path.")
     # One HIP runtime per process: PyTorch ships its own libamdhip64 (same SONAME as /opt/rocm's).
     # Importing torch first makes the loader bind our NEEDED libamdhip64.so.7 to that copy; loading
@@ -88,7 +89,7 @@ def lib():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     L.pamd_last_error.restype = C.c_char_p
     L.pamd_device_count.restype = C.c_int
     L.pamd_assembler_create.restype = C.c_void_p
@@ -111,6 +112,7 @@ def lib():
     L.pamd_assemble_host.argtypes = [C.c_void_p, C.POINTER(Batch)]
     L.pamd_last_kernel_ms.restype = C.c_float
     L.pamd_last_kernel_ms.argtypes = [C.c_void_p]
+    L.pamd_debug_phase_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.pamd_last_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.pamd_synth_generate.argtypes = [C.c_int, C.POINTER(SynthSpecC), C.c_void_p, C.c_uint64, C.c_size_t,
                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]

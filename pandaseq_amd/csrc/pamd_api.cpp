@@ -66,6 +66,7 @@ struct pamd_assembler {
 	uint8_t *d_primers = nullptr;
 	bool primers_dirty = true;
 	unsigned long long *d_error = nullptr;
+	unsigned long long *d_phase = nullptr;	// 10 words, only written by -DPAMD_PHASE_TIMING builds
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 	bool timed = false;
 	int last_wgs = 0, last_waves = 0, last_lds = 0;
@@ -143,7 +144,7 @@ pamd_assembler *pamd_assembler_create(int device) {
 	a->pear_random_base = std::log(0.25);	// algo_pear.c:106
 	a->threshold = std::log(0.6);	// assembler_support.c:76
 	memset(a->primers, 0, sizeof a->primers);
-	if (hipMalloc(&a->d_tables, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_primers, sizeof a->primers) != hipSuccess || hipMalloc(&a->d_error, sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_error, 0, sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&a->ev_start) != hipSuccess || hipEventCreate(&a->ev_stop) != hipSuccess) {
+	if (hipMalloc(&a->d_tables, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_primers, sizeof a->primers) != hipSuccess || hipMalloc(&a->d_error, sizeof(unsigned long long)) != hipSuccess || hipMalloc(&a->d_phase, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_phase, 0, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_error, 0, sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&a->ev_start) != hipSuccess || hipEventCreate(&a->ev_stop) != hipSuccess) {
 		pamd_set_error("device allocation failed on device %d", device);
 		pamd_assembler_destroy(a);
 		return nullptr;
@@ -161,6 +162,8 @@ void pamd_assembler_destroy(pamd_assembler *a) {
 		(void) hipFree(a->d_primers);
 	if (a->d_error)
 		(void) hipFree(a->d_error);
+	if (a->d_phase)
+		(void) hipFree(a->d_phase);
 	if (a->ev_start)
 		(void) hipEventDestroy(a->ev_start);
 	if (a->ev_stop)
@@ -352,6 +355,7 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.seq_cursor = reinterpret_cast<unsigned long long *>(b->seq_cursor);
 	p.counters = reinterpret_cast<unsigned long long *>(b->counters);
 	p.error_flag = a->d_error;
+	p.phase_cycles = a->d_phase;
 	p.tables = a->d_tables;
 	p.primers = a->d_primers;
 	p.n_pairs = b->n_pairs;
@@ -385,8 +389,8 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.mmax = mmax;
 	p.lds_table_doubles = (a->algo == PAMD_ALGO_RDP_MLE) ? (PAMD_LT_C + PAMD_TAB) : PAMD_LT_C;
 	p.lds_ctr_off = up16(p.lds_table_doubles * 8u);
-	p.lds_alloc_off = 0;
-	p.lds_wave_off = up16(p.lds_ctr_off + PAMD_NUM_COUNTERS * 4u);
+	p.lds_primer_off = up16(p.lds_ctr_off + PAMD_NUM_COUNTERS * 4u);
+	p.lds_wave_off = up16(p.lds_primer_off + 912u);
 	uint32_t o = 0;
 	p.w_fwd = o;
 	o += smax * 2u;
@@ -407,6 +411,16 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.w_p = o;
 	o += (mmax * 8u > 2048u ? mmax * 8u : 2048u);
 	p.lds_wave_bytes = up16(o);
+	{
+		const uint32_t region = (mmax * 8u > 2048u ? mmax * 8u : 2048u);
+		uint32_t slots = 512, shift = 23;
+		while (slots * 2u * 4u <= region && slots < 2048u) {
+			slots *= 2u;
+			shift--;
+		}
+		p.hash_slots = slots;
+		p.hash_shift = shift;
+	}
 
 	int waves = (int) ((LDS_LIMIT - p.lds_wave_off) / p.lds_wave_bytes);
 	if (waves > MAX_WAVES_PER_WG)
@@ -442,6 +456,17 @@ float pamd_last_kernel_ms(pamd_assembler *a) {
 	if (hipEventElapsedTime(&ms, a->ev_start, a->ev_stop) != hipSuccess)
 		return -1.0f;
 	return ms;
+}
+
+int pamd_debug_phase_cycles(pamd_assembler *a, unsigned long long *out10, int reset) {
+	if (a == nullptr || out10 == nullptr)
+		return PAMD_EINVAL;
+	HIP_TRY(hipSetDevice(a->device));
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipMemcpy(out10, a->d_phase, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	if (reset)
+		HIP_TRY(hipMemset(a->d_phase, 0, 10 * sizeof(unsigned long long)));
+	return PAMD_OK;
 }
 
 int pamd_last_launch_info(pamd_assembler *a, int *workgroups, int *waves_per_workgroup, int *lds_bytes) {

@@ -22,12 +22,28 @@
 
 namespace {
 
-constexpr unsigned HASH_SLOTS = 512;	// > 442 = most forward k-mers a 450-base read can emit
+// k-mer table slots per wave: a power of two >= 512 (> 442 = most forward k-mers a 450-base read
+// can emit), as many as fit in the log-p staging area it shares (PamdKernelParams::hash_slots)
 constexpr unsigned HASH_EMPTY = 0xFFFFFFFFu;
 constexpr unsigned NT_N = 15;
 constexpr unsigned long long ARENA_CHUNK = 16384;	// bases a wave reserves from the output arena at a time
 
 typedef unsigned long long u64;
+
+// Optional per-phase cycle accounting (build with -DPAMD_PHASE_TIMING; see tools/phase_timing.py).
+// Costs a few % itself, so it is never compiled into the shipped library.
+#ifdef PAMD_PHASE_TIMING
+#define PH_DECL u64 ph_t0 = __builtin_amdgcn_s_memtime(), ph_t1
+#define PH_MARK(k)                                   \
+	do {                                         \
+		ph_t1 = __builtin_amdgcn_s_memtime(); \
+		ph_acc[k] += ph_t1 - ph_t0;          \
+		ph_t0 = ph_t1;                       \
+	} while (0)
+#else
+#define PH_DECL
+#define PH_MARK(k)
+#endif
 
 __device__ __forceinline__ void wave_sync() {
 	// Lanes of one wavefront exchange data through LDS.  The LDS unit executes one wave's DS
@@ -67,8 +83,8 @@ __device__ __forceinline__ int clampq(int q) {	// PHREDCLAMP, prob.h:23
 	return q > 46 ? 46 : (q < 0 ? 0 : q);
 }
 
-__device__ __forceinline__ unsigned kmer_hash(unsigned kmer) {
-	return (kmer * 0x9E3779B1u) >> 23;	// top 9 bits -> [0,512)
+__device__ __forceinline__ unsigned kmer_hash(unsigned kmer, unsigned shift) {
+	return (kmer * 0x9E3779B1u) >> shift;	// top log2(slots) bits
 }
 
 __device__ __forceinline__ int nt_of(unsigned v) {
@@ -95,11 +111,16 @@ struct WaveLds {
 
 // ---- load one read, stage it, derive its packed k-mer inputs --------------------------------
 // Returns the B-cliff length: read length minus the trailing run of raw quality 2 (assembler.c:176-177).
+// Branch-free so the compiler can count it in s_waitcnt vmcnt(N): every lane loads 16 B of the row,
+// lanes past the row end re-read its last 16 bytes (rows are whole multiples of 16 B).
+__device__ __forceinline__ uint4 load_read(const uint8_t *row, unsigned row_bytes, int lane) {
+	unsigned off = (unsigned) lane * 16u;
+	off = off < row_bytes ? off : row_bytes - 16u;
+	return *reinterpret_cast<const uint4 *>(row + off);
+}
+
 template <bool FORWARD>
-__device__ __forceinline__ int stage_read(const uint8_t *row, int len, int lane, uint16_t *dst, uint32_t *codes, uint32_t *nmap) {
-	uint4 v = make_uint4(0, 0, 0, 0);
-	if (lane * 8 < len)
-		v = reinterpret_cast<const uint4 *>(row)[lane];
+__device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint16_t *dst, uint32_t *codes, uint32_t *nmap) {
 	if (lane * 8 < len)
 		reinterpret_cast<uint4 *>(dst)[lane] = v;
 	const unsigned w[4] = { v.x, v.y, v.z, v.w };
@@ -234,7 +255,20 @@ __device__ __forceinline__ double score_overlap(const PamdKernelParams &P, const
 		wave_sync();
 		double acc = 0.0;
 		if (lane == 0) {
-			for (int i = 0; i < ov; i++)
+			int i = 0;
+			for (; i + 8 <= ov; i += 8) {
+				const double v0 = L.ps[i], v1 = L.ps[i + 1], v2 = L.ps[i + 2], v3 = L.ps[i + 3];
+				const double v4 = L.ps[i + 4], v5 = L.ps[i + 5], v6 = L.ps[i + 6], v7 = L.ps[i + 7];
+				acc += v0;
+				acc += v1;
+				acc += v2;
+				acc += v3;
+				acc += v4;
+				acc += v5;
+				acc += v6;
+				acc += v7;
+			}
+			for (; i < ov; i++)
 				acc += L.ps[i];
 		}
 		wave_sync();
@@ -269,10 +303,15 @@ struct WaveArena {
 
 // ---- one pair ---------------------------------------------------------------------------------
 template <int ALGO>
-__device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, unsigned *lctr, const WaveLds &L, WaveArena &arena, u64 pair, int lane) {
-	const int flen = uni((int) P.flen[pair]);
-	const int rlen = uni((int) P.rlen[pair]);
+__device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, unsigned *lctr, const WaveLds &L, WaveArena &arena, u64 pair, int lane, const int flen, const int rlen, const uint4 fregs, const uint4 rregs
+#ifdef PAMD_PHASE_TIMING
+	, u64 *ph_acc
+#endif
+) {
+	PH_DECL;
 	const int minov = P.minoverlap;
+	const unsigned hmask = P.hash_slots - 1u;
+	const unsigned hshift = P.hash_shift;
 
 	pamd_pair_result out;
 	out.quality = 0.0;
@@ -303,19 +342,20 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, uns
 		}
 		// previous pair's readers are done with this wave's LDS
 		wave_sync();
-		const int uf = stage_read<true>(P.fwd + pair * P.fwd_row_bytes, flen, lane, L.F, L.fc, L.fn);
-		const int ur = stage_read<false>(P.rev + pair * P.rev_row_bytes, rlen, lane, L.R, L.rc, L.rn);
+		const int uf = stage_read<true>(fregs, flen, lane, L.F, L.fc, L.fn);
+		const int ur = stage_read<false>(rregs, rlen, lane, L.R, L.rc, L.rn);
 		// clear the k-mer table (aliases the log-p staging area) and the candidate bitmap
-		reinterpret_cast<uint4 *>(L.hash)[lane] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
-		reinterpret_cast<uint4 *>(L.hash)[lane + 64] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
+		for (unsigned s4 = lane; s4 < P.hash_slots / 4; s4 += 64)
+			reinterpret_cast<uint4 *>(L.hash)[s4] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
 		if (lane < 32)
 			L.bits[lane] = 0;
 		wave_sync();
+		PH_MARK(0);
 
 		// ---- primer offsets / trims (assembler.c:262-288) ----
 		int fo, ro;
 		if (P.fprimer_len > 0) {
-			const int r = primer_offset(P, ltab, L.F, flen, P.primers, P.fprimer_len, lane);
+			const int r = primer_offset(P, ltab, L.F, flen, lprimers, P.fprimer_len, lane);
 			if (r == 0) {
 				status = PAMD_ST_NOFP;
 				break;
@@ -326,7 +366,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, uns
 		}
 		out.fwd_offset = (uint16_t) fo;
 		if (P.rprimer_len > 0) {
-			const int r = primer_offset(P, ltab, L.R, rlen, P.primers + 456, P.rprimer_len, lane);
+			const int r = primer_offset(P, ltab, L.R, rlen, lprimers + 456, P.rprimer_len, lane);
 			if (r == 0) {
 				status = PAMD_ST_NORP;
 				break;
@@ -355,6 +395,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, uns
 		const int maxov = (int) maxov64;	// <= 2 * PAMD_MAX_LEN by construction
 		const int size = minov <= maxov ? maxov - minov + 1 : 1;
 
+		PH_MARK(1);
 		// ---- seed: forward k-mers into the LDS table (assembler.c:92-101) ----
 		// The reference keeps, per k-mer, the first two forward positions.  We insert every
 		// (k-mer, position) into a linear-probing multiset and let the reverse probe pick the two
@@ -372,12 +413,13 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, uns
 				const u64 win = ((u64) L.fc[s >> 4] << 32) | (u64) L.fc[(s >> 4) + 1];
 				const unsigned kmer = (unsigned) (win >> (48 - 2 * (s & 15))) & 0xFFFFu;
 				const unsigned word = (kmer << 16) | (unsigned) p;
-				unsigned slot = kmer_hash(kmer);
+				unsigned slot = kmer_hash(kmer, hshift);
 				while (atomicCAS(&L.hash[slot], HASH_EMPTY, word) != HASH_EMPTY)
-					slot = (slot + 1) & (HASH_SLOTS - 1);
+					slot = (slot + 1) & hmask;
 			}
 		}
 		wave_sync();
+		PH_MARK(2);
 		// ---- seed: reverse k-mers flag candidate overlaps (assembler.c:104-110) ----
 		for (int base = 0; base < rlen; base += 64) {
 			const int p = base + lane;
@@ -389,7 +431,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, uns
 			if (ok) {
 				const u64 win = ((u64) L.rc[(p >> 4) + 1] << 32) | (u64) L.rc[p >> 4];
 				const unsigned kmer = (unsigned) (win >> (2 * (p & 15))) & 0xFFFFu;
-				unsigned slot = kmer_hash(kmer);
+				unsigned slot = kmer_hash(kmer, hshift);
 				unsigned m1 = 0xFFFFu, m2 = 0xFFFFu;
 				unsigned wd;
 				while ((wd = L.hash[slot]) != HASH_EMPTY) {
@@ -402,7 +444,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, uns
 							m2 = pos;
 						}
 					}
-					slot = (slot + 1) & (HASH_SLOTS - 1);
+					slot = (slot + 1) & hmask;
 				}
 				if (m1 != 0xFFFFu) {
 					const int idx = flen + rlen - p - (int) m1 - minov - 1;	// assembler.c:107
@@ -417,6 +459,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, uns
 			}
 		}
 		wave_sync();
+		PH_MARK(3);
 
 		// ---- scan + argmax (assembler.c:118-143) ----
 		const int lastw = size >> 5;
@@ -453,6 +496,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, uns
 			break;
 		}
 
+		PH_MARK(4);
 		// ---- merge (assembler.c:146-247) ----
 		const int len = flen - fo - bo + rlen - ro + 1;
 		if (len <= 0 || len > 2 * PAMD_MAX_LEN) {
@@ -523,6 +567,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, uns
 		}
 		(void) Bn;
 		wave_sync();
+		PH_MARK(5);
 		// ordered sums: lane 0 forward-only, lane 1 reverse-only, lane 2 overlap
 		double acc = 0.0;
 		{
@@ -537,9 +582,25 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, uns
 				lo = A;
 				hi = A + novl;
 			}
-			for (int j = lo; j < hi; j++)
+			// same left-to-right order as the reference; the loads of a block are issued together so
+			// the chain pays one LDS round trip per 8 adds instead of one per add
+			int j = lo;
+			for (; j + 8 <= hi; j += 8) {
+				const double v0 = L.ps[j], v1 = L.ps[j + 1], v2 = L.ps[j + 2], v3 = L.ps[j + 3];
+				const double v4 = L.ps[j + 4], v5 = L.ps[j + 5], v6 = L.ps[j + 6], v7 = L.ps[j + 7];
+				acc += v0;
+				acc += v1;
+				acc += v2;
+				acc += v3;
+				acc += v4;
+				acc += v5;
+				acc += v6;
+				acc += v7;
+			}
+			for (; j < hi; j++)
 				acc += L.ps[j];
 		}
+		PH_MARK(6);
 		const double fquality = lane_f64(acc, 0);
 		const double rquality = lane_f64(acc, 1);
 		const double oquality = lane_f64(acc, 2);
@@ -620,6 +681,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, uns
 	}
 	out.status = (uint8_t) status;
 	out.reject_module = (int8_t) reject;
+	PH_MARK(7);
 	if (lane == 0) {
 		P.results[pair] = out;
 		// workgroup-local counters (assembler.h:59-67,75); flushed once per workgroup
@@ -667,6 +729,10 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		ltab[i] = P.tables[i];
 	for (unsigned i = tid; i < PAMD_NUM_COUNTERS; i += blockDim.x)
 		lctr[i] = 0;
+	uint8_t *lprimers = lds + P.lds_primer_off;	// both primers, staged once per workgroup
+	if (P.fprimer_len > 0 || P.rprimer_len > 0)
+		for (unsigned i = tid; i < 912; i += blockDim.x)
+			lprimers[i] = P.primers[i];
 	__syncthreads();
 
 	unsigned char *wb = lds + P.lds_wave_off + (size_t) wave * P.lds_wave_bytes;
@@ -686,9 +752,45 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	arena.cur = 0;
 	arena.end = 0;
 	const u64 total_waves = (u64) gridDim.x * (u64) nwaves;
-	for (u64 pair = (u64) blockIdx.x * (u64) nwaves + (u64) wave; pair < P.n_pairs; pair += total_waves)
-		assemble_pair<ALGO>(P, ltab, lctr, L, arena, pair, lane);
-
+#ifdef PAMD_PHASE_TIMING
+	u64 ph_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	const u64 ph_begin = __builtin_amdgcn_s_memtime();
+#endif
+	// Persistent loop with a one-pair software prefetch: the four loads of pair k+1 (two lengths,
+	// two read rows) are issued before pair k is assembled and are first touched when k is done.
+	// No branch surrounds them (indices are clamped instead), so the waits stay counted.
+	u64 pair = (u64) blockIdx.x * (u64) nwaves + (u64) wave;
+	const u64 last = P.n_pairs - 1;
+	u64 q = pair < P.n_pairs ? pair : last;
+	int flen_v = P.flen[q];
+	int rlen_v = P.rlen[q];
+	uint4 fregs = load_read(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+	uint4 rregs = load_read(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
+	while (pair < P.n_pairs) {
+		const u64 next = pair + total_waves;
+		q = next < P.n_pairs ? next : last;
+		const int nflen_v = P.flen[q];
+		const int nrlen_v = P.rlen[q];
+		const uint4 nf = load_read(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+		const uint4 nr = load_read(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
+		const int flen = uni(flen_v), rlen = uni(rlen_v);
+#ifdef PAMD_PHASE_TIMING
+		assemble_pair<ALGO>(P, ltab, lprimers, lctr, L, arena, pair, lane, flen, rlen, fregs, rregs, ph_acc);
+#else
+		assemble_pair<ALGO>(P, ltab, lprimers, lctr, L, arena, pair, lane, flen, rlen, fregs, rregs);
+#endif
+		pair = next;
+		flen_v = nflen_v;
+		rlen_v = nrlen_v;
+		fregs = nf;
+		rregs = nr;
+	}
+#ifdef PAMD_PHASE_TIMING
+	ph_acc[9] = __builtin_amdgcn_s_memtime() - ph_begin;
+	if (lane == 0 && P.phase_cycles != nullptr)
+		for (int k = 0; k < 10; k++)
+			atomicAdd(&P.phase_cycles[k], ph_acc[k]);
+#endif
 	__syncthreads();
 	if (P.counters != nullptr) {
 		for (unsigned i = tid; i < PAMD_NUM_COUNTERS; i += blockDim.x) {
