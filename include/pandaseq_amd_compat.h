@@ -1,0 +1,193 @@
+/*
+ * pandaseq_amd_compat.h -- the reference's own per-assembler API for the hot path
+ * (pandaseq-assembler.h:40-405 + the types of pandaseq-common.h it needs), implemented on top of
+ * the batch ABI of pandaseq_amd.h.  A program written against <pandaseq.h> that only uses the
+ * functions below can be re-linked against libpandaseq_amd.so and get the GPU path:
+ *
+ *   panda_assembler_next()      assembler.c:350-366   pulls a BATCH of pairs from the PandaNextSeq
+ *                                                     source, assembles it in one kernel launch and
+ *                                                     hands results back one at a time, in source order
+ *   panda_assembler_assemble()  assembler.c:368-383   one caller-supplied pair (a batch of one)
+ *
+ * Struct layouts are ABI-identical to the reference (sizes checked by static asserts in
+ * pamd_compat.cpp: panda_qual 2, panda_result 16, panda_seq_identifier 368, panda_result_seq 480).
+ * struct panda_assembler / panda_algorithm / panda_module are private in the reference
+ * (assembler.h:28, algo.h:28, module.c:84) and are private here too.
+ *
+ * When this library is linked INTO libpandaseq, build it with
+ * -DPAMD_WITH_REFERENCE_OBJECTS: the panda_algorithm_* and panda_module_* definitions below are
+ * then left to the reference's algo.c / algo_*.c / module.c.
+ */
+#ifndef PANDASEQ_AMD_COMPAT_H
+#define PANDASEQ_AMD_COMPAT_H
+
+#include <stdbool.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef PANDA_TAG_LEN
+#define PANDA_TAG_LEN 50	/* pandaseq-common.h:45 */
+#endif
+#define PANDA_DEFAULT_NUM_KMERS 2	/* pandaseq-assembler.h:51 */
+
+typedef char panda_nt;	/* pandaseq-common.h:166 */
+
+typedef struct {	/* pandaseq-common.h:210-219 */
+	panda_nt nt;
+	char qual;
+} panda_qual;
+
+typedef struct {	/* pandaseq-common.h:221-230 */
+	panda_nt nt;
+	double p;
+} panda_result;
+
+typedef struct {	/* pandaseq-common.h:235-244 */
+	char instrument[100];
+	char run[100];
+	char flowcell[100];
+	int lane;
+	int tile;
+	int x;
+	int y;
+	char tag[PANDA_TAG_LEN];
+} panda_seq_identifier;
+
+typedef struct {	/* pandaseq-common.h:277-330 */
+	double quality;
+	size_t degenerates;
+	panda_seq_identifier name;
+	panda_result *sequence;
+	size_t sequence_length;
+	panda_qual const *forward;
+	size_t forward_length;
+	panda_qual const *reverse;
+	size_t reverse_length;
+	size_t forward_offset;
+	size_t reverse_offset;
+	size_t overlap_mismatches;
+	size_t overlaps_examined;
+	size_t overlap;
+	double estimated_overlap_probability;
+} panda_result_seq;
+
+typedef struct panda_assembler *PandaAssembler;	/* pandaseq-common.h:66 */
+typedef struct panda_algorithm *PandaAlgorithm;	/* pandaseq-common.h:56 */
+typedef const struct panda_algorithm_class *PandaAlgorithmClass;	/* pandaseq-common.h:61 */
+typedef struct panda_module *PandaModule;	/* pandaseq-common.h:98 */
+typedef struct panda_log_proxy *PandaLogProxy;	/* pandaseq-common.h:93; opaque, passed through to callbacks */
+
+/* callback types, pandaseq-common.h:338-522 */
+typedef void (*PandaDestroy) (void *user_data);
+typedef bool (*PandaNextSeq) (panda_seq_identifier *id, const panda_qual **forward, size_t *forward_length, const panda_qual **reverse, size_t *reverse_length, void *user_data);
+typedef void (*PandaFailAlign) (PandaAssembler assembler, const panda_seq_identifier *id, const panda_qual *forward, size_t forward_length, const panda_qual *reverse, size_t reverse_length, void *user_data);
+typedef bool (*PandaCheck) (PandaLogProxy logger, const panda_result_seq *sequence, void *user_data);
+typedef bool (*PandaPreCheck) (PandaLogProxy logger, const panda_seq_identifier *id, const panda_qual *forward, size_t forward_length, const panda_qual *reverse, size_t reverse_length, void *user_data);
+typedef bool (*PandaModuleCallback) (PandaAssembler assembler, PandaModule module, size_t rejected, void *data);
+typedef const panda_result_seq *(*PandaAssemble) (void *user_data, panda_seq_identifier *id, const panda_qual *forward, size_t forward_length, const panda_qual *reverse, size_t reverse_length);
+typedef PandaAlgorithm (*PandaAlgorithmCreate) (const char *args);
+typedef double (*PandaComputeMatch) (void *private_data, bool match, char a, char b);
+typedef double (*PandaComputeOverlap) (void *private_data, const panda_qual *forward, size_t forward_length, const panda_qual *reverse, size_t reverse_length, size_t overlap);
+
+struct panda_algorithm_class {	/* pandaseq-common.h:594-605 */
+	size_t data_size;
+	const char *name;
+	PandaAlgorithmCreate create;
+	PandaDestroy data_destroy;
+	PandaComputeOverlap overlap_probability;	/* NULL in this library: the scoring runs on the GPU */
+	PandaComputeMatch match_probability;	/* NULL in this library */
+	const double prob_unpaired;
+};
+
+/* ---- constructors / lifetime (pandaseq-assembler.h:40-66,183-192) ---- */
+PandaAssembler panda_assembler_new(PandaNextSeq next, void *next_data, PandaDestroy next_destroy, PandaLogProxy logger);
+PandaAssembler panda_assembler_new_kmer(PandaNextSeq next, void *next_data, PandaDestroy next_destroy, PandaLogProxy logger, size_t num_kmers);
+PandaAssembler panda_assembler_ref(PandaAssembler assembler);
+void panda_assembler_unref(PandaAssembler assembler);
+void panda_assembler_copy_configuration(PandaAssembler dest, PandaAssembler src);	/* :147 */
+
+/* ---- the two entry points of the hot path ---- */
+const panda_result_seq *panda_assembler_assemble(PandaAssembler assembler, panda_seq_identifier *id, const panda_qual *forward, size_t forward_length, const panda_qual *reverse, size_t reverse_length);	/* :134 */
+const panda_result_seq *panda_assembler_next(PandaAssembler assembler);	/* :175 */
+
+/* ---- modules (pandaseq-assembler.h:112-167, pandaseq-module.h) ---- */
+PandaModule panda_module_new(const char *name, PandaCheck check, PandaPreCheck precheck, void *user_data, PandaDestroy cleanup);	/* module.c:300-321 */
+/* "min_phred:10" / "min_overlapbits:15" -> a module the kernel applies itself (replaces dlopen-ing
+ * plugin_min_phred.c / plugin_min_overlapbits.c through module.c:227-298); anything else -> NULL */
+PandaModule panda_module_load(PandaLogProxy logger, const char *path);
+PandaModule panda_module_ref(PandaModule module);
+void panda_module_unref(PandaModule module);
+const char *panda_module_get_name(PandaModule module);
+bool panda_assembler_add_module(PandaAssembler assembler, PandaModule module);
+size_t panda_assembler_add_modules(PandaAssembler assembler, PandaModule *modules, size_t modules_length);
+bool panda_assembler_foreach_module(PandaAssembler assembler, PandaModuleCallback callback, void *callback_data);
+void panda_assembler_module_stats(PandaAssembler assembler);
+
+/* ---- algorithms (pandaseq-algorithm.h; algo.c:34-94, algo_*.c) ---- */
+extern const struct panda_algorithm_class panda_algorithm_simple_bayes_class;
+extern const struct panda_algorithm_class panda_algorithm_pear_class;
+extern const struct panda_algorithm_class panda_algorithm_rdp_mle_class;
+PandaAlgorithm panda_algorithm_new(PandaAlgorithmClass clazz);
+PandaAlgorithm panda_algorithm_ref(PandaAlgorithm algo);
+void panda_algorithm_unref(PandaAlgorithm algo);
+bool panda_algorithm_is_a(PandaAlgorithm algo, PandaAlgorithmClass clazz);
+PandaAlgorithmClass panda_algorithm_class(PandaAlgorithm algo);
+void *panda_algorithm_data(PandaAlgorithm algo);
+PandaAlgorithm panda_algorithm_simple_bayes_new(void);
+double panda_algorithm_simple_bayes_get_error_estimation(PandaAlgorithm algorithm);
+void panda_algorithm_simple_bayes_set_error_estimation(PandaAlgorithm algorithm, double q);
+PandaAlgorithm panda_algorithm_pear_new(void);
+double panda_algorithm_pear_get_random_base_log_p(PandaAlgorithm algorithm);
+void panda_algorithm_pear_set_random_base_log_p(PandaAlgorithm algorithm, double log_p);
+PandaAlgorithm panda_algorithm_rdp_mle_new(void);
+
+/* ---- getters / setters (pandaseq-assembler.h:199-405, assembler_support.c:177-410) ---- */
+PandaAlgorithm panda_assembler_get_algorithm(PandaAssembler assembler);
+void panda_assembler_set_algorithm(PandaAssembler assembler, PandaAlgorithm algorithm);
+long panda_assembler_get_bad_read_count(PandaAssembler assembler);
+long panda_assembler_get_count(PandaAssembler assembler);
+void panda_assembler_set_fail_alignment(PandaAssembler assembler, PandaFailAlign handler, void *handler_data, PandaDestroy handler_destroy);
+long panda_assembler_get_failed_alignment_count(PandaAssembler assembler);
+panda_nt *panda_assembler_get_forward_primer(PandaAssembler assembler, size_t *length);
+void panda_assembler_set_forward_primer(PandaAssembler assembler, panda_nt *sequence, size_t length);
+size_t panda_assembler_get_forward_trim(PandaAssembler assembler);
+void panda_assembler_set_forward_trim(PandaAssembler assembler, size_t trim);
+size_t panda_assembler_get_longest_overlap(PandaAssembler assembler);
+long panda_assembler_get_low_quality_count(PandaAssembler assembler);
+int panda_assembler_get_minimum_overlap(PandaAssembler assembler);
+void panda_assembler_set_minimum_overlap(PandaAssembler assembler, int overlap);
+int panda_assembler_get_maximum_overlap(PandaAssembler assembler);
+void panda_assembler_set_maximum_overlap(PandaAssembler assembler, int overlap);
+const char *panda_assembler_get_name(PandaAssembler assembler);
+void panda_assembler_set_name(PandaAssembler assembler, const char *name);
+long panda_assembler_get_no_forward_primer_count(PandaAssembler assembler);
+long panda_assembler_get_no_reverse_primer_count(PandaAssembler assembler);
+size_t panda_assembler_get_num_kmer(PandaAssembler assembler);
+long panda_assembler_get_ok_count(PandaAssembler assembler);
+long panda_assembler_get_overlap_count(PandaAssembler assembler, size_t overlap);
+bool panda_assembler_get_primers_after(PandaAssembler assembler);
+void panda_assembler_set_primers_after(PandaAssembler assembler, bool after);
+panda_nt *panda_assembler_get_reverse_primer(PandaAssembler assembler, size_t *length);
+void panda_assembler_set_reverse_primer(PandaAssembler assembler, panda_nt *sequence, size_t length);
+size_t panda_assembler_get_reverse_trim(PandaAssembler assembler);
+void panda_assembler_set_reverse_trim(PandaAssembler assembler, size_t trim);
+long panda_assembler_get_slow_count(PandaAssembler assembler);
+double panda_assembler_get_threshold(PandaAssembler assembler);
+void panda_assembler_set_threshold(PandaAssembler assembler, double threshold);
+PandaLogProxy panda_assembler_get_logger(PandaAssembler assembler);
+double panda_assembler_get_primer_penalty(PandaAssembler assembler);
+void panda_assembler_set_primer_penalty(PandaAssembler assembler, double threshold);
+
+/* ---- extensions (not in the reference) ---- */
+/* which GPU new assemblers are created on (default 0), and how many pairs panda_assembler_next()
+ * pulls from the source per kernel launch (default 16384) */
+void pamd_compat_set_device(int device);
+void pamd_compat_set_batch_pairs(size_t pairs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,841 @@
+// pamd_compat.cpp -- the reference's per-assembler API (include/pandaseq_amd_compat.h) on top of the
+// batch ABI.  Host-side bookkeeping only: pulling pairs from the PandaNextSeq source, replaying
+// per-pair callbacks and counters in source order (assembler.c:252-366), and the getters/setters of
+// assembler_support.c.  All assembly arithmetic happens in the HIP kernel; nothing here scores,
+// merges or sums anything.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "pamd_internal.h"
+#include "../../include/pandaseq_amd_compat.h"
+
+static_assert(sizeof(panda_qual) == 2, "panda_qual ABI");
+static_assert(sizeof(panda_result) == 16 && offsetof(panda_result, p) == 8, "panda_result ABI");
+static_assert(sizeof(panda_seq_identifier) == 368, "panda_seq_identifier ABI");
+static_assert(sizeof(panda_result_seq) == 480 && offsetof(panda_result_seq, sequence) == 384 && offsetof(panda_result_seq, overlap) == 464, "panda_result_seq ABI");
+static_assert(sizeof(panda_qual) == sizeof(pamd_qual), "panda_qual == pamd_qual");
+
+namespace {
+int g_device = 0;
+size_t g_batch_pairs = 16384;
+std::mutex g_ref_lock;	// one lock for all refcounts, like module.c:38-41
+constexpr size_t ROW = 456;	// staging row stride in bases (>= PANDA_MAX_LEN, multiple of 8)
+constexpr size_t OUT_ROW = 912;	// strided output row (>= 2 * PANDA_MAX_LEN, multiple of 16)
+}
+
+// ---------------------------------------------------------------- algorithms (algo.c, algo_*.c)
+#ifndef PAMD_WITH_REFERENCE_OBJECTS
+struct panda_algorithm {	// algo.h:28-35
+	const struct panda_algorithm_class *clazz;
+	size_t refcnt;
+	double data[3];	// simple_bayes: q, pmatch, pmismatch (algo_simple_bayes.c:27-31); pear: random_base
+};
+
+static PandaAlgorithm sb_create(const char *arg) {	// algo_simple_bayes.c:77-98
+	PandaAlgorithm a = panda_algorithm_simple_bayes_new();
+	if (arg != nullptr) {
+		char *end;
+		double q = strtod(arg, &end);
+		if (*end != '\0' || q < 0 || q > 1) {
+			panda_algorithm_unref(a);
+			return nullptr;
+		}
+		panda_algorithm_simple_bayes_set_error_estimation(a, q);
+	}
+	return a;
+}
+
+static PandaAlgorithm pear_create(const char *arg) {	// algo_pear.c:70-91
+	PandaAlgorithm a = panda_algorithm_pear_new();
+	if (arg != nullptr) {
+		char *end;
+		double p = strtod(arg, &end);
+		if (*end != '\0' || p < 0 || p > 1) {
+			panda_algorithm_unref(a);
+			return nullptr;
+		}
+		panda_algorithm_pear_set_random_base_log_p(a, std::log(p));
+	}
+	return a;
+}
+
+static PandaAlgorithm rdp_create(const char *arg) {	// algo_rdp_mle.c:76-82
+	if (arg == nullptr || strlen(arg) == 0)
+		return panda_algorithm_rdp_mle_new();
+	return nullptr;
+}
+
+extern "C" {
+const struct panda_algorithm_class panda_algorithm_simple_bayes_class = { 3 * sizeof(double), "simple_bayesian", sb_create, nullptr, nullptr, nullptr, -1.38629 };
+const struct panda_algorithm_class panda_algorithm_pear_class = { sizeof(double), "pear", pear_create, nullptr, nullptr, nullptr, -1.38629 };
+const struct panda_algorithm_class panda_algorithm_rdp_mle_class = { 0, "rdp_mle", rdp_create, nullptr, nullptr, nullptr, -1.38629 };
+
+PandaAlgorithm panda_algorithm_new(PandaAlgorithmClass clazz) {	// algo.c:85-94
+	PandaAlgorithm a = static_cast<PandaAlgorithm>(calloc(1, sizeof(struct panda_algorithm)));
+	a->clazz = clazz;
+	a->refcnt = 1;
+	return a;
+}
+
+PandaAlgorithm panda_algorithm_ref(PandaAlgorithm a) {
+	std::lock_guard<std::mutex> g(g_ref_lock);
+	a->refcnt++;
+	return a;
+}
+
+void panda_algorithm_unref(PandaAlgorithm a) {
+	if (a == nullptr)
+		return;
+	size_t c;
+	{
+		std::lock_guard<std::mutex> g(g_ref_lock);
+		c = --a->refcnt;
+	}
+	if (c == 0)
+		free(a);
+}
+
+bool panda_algorithm_is_a(PandaAlgorithm a, PandaAlgorithmClass clazz) {	// algo.c:44-48
+	return a != nullptr && a->clazz == clazz;
+}
+
+PandaAlgorithmClass panda_algorithm_class(PandaAlgorithm a) {
+	return a->clazz;
+}
+
+void *panda_algorithm_data(PandaAlgorithm a) {
+	return a->data;
+}
+
+PandaAlgorithm panda_algorithm_simple_bayes_new(void) {	// algo_simple_bayes.c:110-115
+	PandaAlgorithm a = panda_algorithm_new(&panda_algorithm_simple_bayes_class);
+	panda_algorithm_simple_bayes_set_error_estimation(a, 0.36);
+	return a;
+}
+
+double panda_algorithm_simple_bayes_get_error_estimation(PandaAlgorithm a) {
+	return panda_algorithm_is_a(a, &panda_algorithm_simple_bayes_class) ? a->data[0] : -1;
+}
+
+void panda_algorithm_simple_bayes_set_error_estimation(PandaAlgorithm a, double q) {	// algo_simple_bayes.c:126-135
+	if (q > 0 && q < 1 && panda_algorithm_is_a(a, &panda_algorithm_simple_bayes_class)) {
+		a->data[0] = q;
+		a->data[1] = std::log(0.25 * (1 - 2 * q + q * q));
+		a->data[2] = std::log((3 * q - 2 * q * q) / 18.0);
+	}
+}
+
+PandaAlgorithm panda_algorithm_pear_new(void) {	// algo_pear.c:103-108
+	PandaAlgorithm a = panda_algorithm_new(&panda_algorithm_pear_class);
+	a->data[0] = std::log(0.25);
+	return a;
+}
+
+double panda_algorithm_pear_get_random_base_log_p(PandaAlgorithm a) {
+	return panda_algorithm_is_a(a, &panda_algorithm_pear_class) ? a->data[0] : 1;
+}
+
+void panda_algorithm_pear_set_random_base_log_p(PandaAlgorithm a, double log_p) {
+	if (panda_algorithm_is_a(a, &panda_algorithm_pear_class))
+		a->data[0] = log_p;
+}
+
+PandaAlgorithm panda_algorithm_rdp_mle_new(void) {
+	return panda_algorithm_new(&panda_algorithm_rdp_mle_class);
+}
+}	// extern "C"
+
+// ---------------------------------------------------------------- modules (module.c)
+struct panda_module {
+	size_t refcnt;
+	PandaCheck check;
+	PandaPreCheck precheck;
+	PandaDestroy destroy;
+	void *user_data;
+	char *name;
+	int fused_kind;	// 0 = host callbacks; 1 = min_phred, 2 = min_overlapbits (run inside the kernel)
+	int fused_phred;
+	double fused_bits;
+};
+
+extern "C" {
+PandaModule panda_module_new(const char *name, PandaCheck check, PandaPreCheck precheck, void *user_data, PandaDestroy cleanup) {	// module.c:300-321
+	if (check == nullptr && precheck == nullptr)
+		return nullptr;
+	PandaModule m = static_cast<PandaModule>(calloc(1, sizeof(struct panda_module)));
+	m->refcnt = 1;
+	m->check = check;
+	m->precheck = precheck;
+	m->destroy = cleanup;
+	m->user_data = user_data;
+	m->name = strdup(name);
+	return m;
+}
+
+PandaModule panda_module_load(PandaLogProxy logger, const char *path) {
+	(void) logger;
+	if (path == nullptr)
+		return nullptr;
+	// "name:args" (module.c:244-247); only the two modules the kernel implements are known here
+	const char *colon = strchr(path, ':');
+	std::string name = colon ? std::string(path, colon - path) : std::string(path);
+	const char *args = colon ? colon + 1 : nullptr;
+	PandaModule m = static_cast<PandaModule>(calloc(1, sizeof(struct panda_module)));
+	m->refcnt = 1;
+	m->name = strdup(name.c_str());
+	if (name == "min_phred") {	// plugin_min_phred.c:24-44
+		char *end = nullptr;
+		long v = (args && *args) ? strtol(args, &end, 10) : -1;
+		if (args == nullptr || *args == '\0' || (end && *end != '\0') || v < 0 || v > 127) {
+			panda_module_unref(m);
+			return nullptr;
+		}
+		m->fused_kind = 1;
+		m->fused_phred = (int) v;
+	} else if (name == "min_overlapbits") {	// plugin_min_overlapbits.c:25-53
+		double bits = 15;
+		if (args != nullptr) {
+			char *end = nullptr;
+			bits = strtod(args, &end);
+			if (*end != '\0' || bits < 0) {
+				panda_module_unref(m);
+				return nullptr;
+			}
+		}
+		m->fused_kind = 2;
+		m->fused_bits = bits;
+	} else {
+		pamd_set_error("module %s is not built into the device path; wrap its check function with panda_module_new()", name.c_str());
+		panda_module_unref(m);
+		return nullptr;
+	}
+	return m;
+}
+
+PandaModule panda_module_ref(PandaModule m) {
+	std::lock_guard<std::mutex> g(g_ref_lock);
+	m->refcnt++;
+	return m;
+}
+
+void panda_module_unref(PandaModule m) {
+	if (m == nullptr)
+		return;
+	size_t c;
+	{
+		std::lock_guard<std::mutex> g(g_ref_lock);
+		c = --m->refcnt;
+	}
+	if (c == 0) {
+		if (m->destroy != nullptr && m->user_data != nullptr)
+			m->destroy(m->user_data);
+		free(m->name);
+		free(m);
+	}
+}
+
+const char *panda_module_get_name(PandaModule m) {
+	return m->name;
+}
+}	// extern "C"
+#endif	// PAMD_WITH_REFERENCE_OBJECTS
+
+// ---------------------------------------------------------------- the assembler
+struct panda_assembler {
+	size_t refcnt = 1;
+	PandaNextSeq next = nullptr;
+	void *next_data = nullptr;
+	PandaDestroy next_destroy = nullptr;
+	PandaFailAlign noalgn = nullptr;
+	void *noalgn_data = nullptr;
+	PandaDestroy noalgn_destroy = nullptr;
+	PandaLogProxy logger = nullptr;
+	pamd_assembler *dev = nullptr;
+	bool dev_dirty = true;	// configuration changed since it was last pushed to `dev`
+	// configuration (assembler.h:44-57,72-78)
+	double threshold = std::log(0.6);
+	int minoverlap = 2, maxoverlap = 0;
+	size_t num_kmers = 2;
+	PandaAlgorithm algo = nullptr;
+	panda_nt forward_primer[PAMD_MAX_LEN], reverse_primer[PAMD_MAX_LEN];
+	size_t forward_primer_length = 0, reverse_primer_length = 0, forward_trim = 0, reverse_trim = 0;
+	bool post_primers = false;
+	double primer_penalty = 0;
+	char name[PAMD_MAX_LEN] = "";
+	std::vector<PandaModule> modules;
+	std::vector<size_t> rejected;
+	size_t fused_prefix = 0;	// modules[0..fused_prefix) run inside the kernel
+	// counters (assembler.h:59-67,75-76)
+	long nofpcount = 0, norpcount = 0, okcount = 0, lowqcount = 0, noalgncount = 0, badreadcount = 0, slowcount = 0, count = 0;
+	long overlapcount[2 * PAMD_MAX_LEN] = { 0 };
+	size_t longest_overlap = 0;
+	// the result handed back (valid until the next call)
+	panda_result_seq result;
+	panda_result result_seq[2 * PAMD_MAX_LEN];
+	// batch staging (host)
+	std::vector<pamd_qual> h_fwd, h_rev;
+	std::vector<uint16_t> h_flen, h_rlen;
+	std::vector<panda_seq_identifier> h_id;
+	std::vector<int> h_pre;	// -2 = sent to the device, -1 = short read (BADR), >= 0 = rejected by precheck module k
+	std::vector<pamd_pair_result> h_res;
+	std::vector<uint8_t> h_nt;
+	std::vector<double> h_p;
+	size_t batch_n = 0, batch_pos = 0;
+	bool eof = false;
+};
+
+namespace {
+
+int push_config(PandaAssembler a) {
+	if (!a->dev_dirty)
+		return PAMD_OK;
+	if (a->post_primers) {
+		pamd_set_error("primers_after (-a) is not implemented on the device path");
+		return PAMD_EUNSUPPORTED;
+	}
+	int algo;
+	double param = NAN;
+	if (panda_algorithm_is_a(a->algo, &panda_algorithm_simple_bayes_class)) {
+		algo = PAMD_ALGO_SIMPLE_BAYES;
+		param = panda_algorithm_simple_bayes_get_error_estimation(a->algo);
+	} else if (panda_algorithm_is_a(a->algo, &panda_algorithm_pear_class)) {
+		algo = PAMD_ALGO_PEAR;
+		param = panda_algorithm_pear_get_random_base_log_p(a->algo);
+	} else if (panda_algorithm_is_a(a->algo, &panda_algorithm_rdp_mle_class)) {
+		algo = PAMD_ALGO_RDP_MLE;
+	} else {
+		pamd_set_error("algorithm %s has no device implementation (simple_bayesian, pear, rdp_mle only)", a->algo ? panda_algorithm_class(a->algo)->name : "(null)");
+		return PAMD_EUNSUPPORTED;
+	}
+	pamd_assembler *d = a->dev;
+	pamd_set_algorithm(d, algo, param);
+	pamd_set_threshold(d, std::exp(a->threshold));
+	pamd_set_minimum_overlap(d, a->minoverlap);
+	pamd_set_maximum_overlap(d, a->maxoverlap);
+	pamd_set_primer_penalty(d, a->primer_penalty);
+	if (a->forward_primer_length > 0)
+		pamd_set_forward_primer(d, reinterpret_cast<const uint8_t *>(a->forward_primer), a->forward_primer_length);
+	else
+		pamd_set_forward_trim(d, a->forward_trim);
+	if (a->reverse_primer_length > 0)
+		pamd_set_reverse_primer(d, reinterpret_cast<const uint8_t *>(a->reverse_primer), a->reverse_primer_length);
+	else
+		pamd_set_reverse_trim(d, a->reverse_trim);
+	// only a leading run of kernel-implemented modules can be fused without changing which module
+	// gets the blame for a rejection (module.c:128-134 stops at the first failure)
+	pamd_clear_modules(d);
+	a->fused_prefix = 0;
+	for (PandaModule m : a->modules) {
+		if (m->fused_kind == 1 && a->fused_prefix < PAMD_MAX_MODULES)
+			pamd_add_module_min_phred(d, m->fused_phred);
+		else if (m->fused_kind == 2 && a->fused_prefix < PAMD_MAX_MODULES)
+			pamd_add_module_min_overlapbits(d, m->fused_bits);
+		else
+			break;
+		a->fused_prefix++;
+	}
+	for (size_t i = a->fused_prefix; i < a->modules.size(); i++) {
+		if (a->modules[i]->fused_kind != 0) {
+			pamd_set_error("module %s follows a host-callback module; kernel-implemented modules must come first", a->modules[i]->name);
+			return PAMD_EUNSUPPORTED;
+		}
+	}
+	a->dev_dirty = false;
+	return PAMD_OK;
+}
+
+// Run the staged pairs [0, batch_n) through the device.
+int run_batch(PandaAssembler a) {
+	int rc = push_config(a);
+	if (rc != PAMD_OK)
+		return rc;
+	std::vector<size_t> sent;
+	for (size_t i = 0; i < a->batch_n; i++)
+		if (a->h_pre[i] == -2)
+			sent.push_back(i);
+	const size_t n = sent.size();
+	if (n == 0)
+		return PAMD_OK;
+	// compact the pairs that go to the device to the front of the staging rows (order kept)
+	for (size_t k = 0; k < n; k++) {
+		const size_t i = sent[k];
+		if (i != k) {
+			memcpy(&a->h_fwd[k * ROW], &a->h_fwd[i * ROW], ROW * sizeof(pamd_qual));
+			memcpy(&a->h_rev[k * ROW], &a->h_rev[i * ROW], ROW * sizeof(pamd_qual));
+			a->h_flen[k] = a->h_flen[i];
+			a->h_rlen[k] = a->h_rlen[i];
+		}
+	}
+	a->h_res.resize(n);
+	a->h_nt.resize(n * OUT_ROW);
+	a->h_p.resize(n * OUT_ROW);
+	pamd_batch b;
+	memset(&b, 0, sizeof b);
+	b.n_pairs = n;
+	b.fwd = a->h_fwd.data();
+	b.rev = a->h_rev.data();
+	b.fwd_stride = b.rev_stride = ROW;
+	b.flen = a->h_flen.data();
+	b.rlen = a->h_rlen.data();
+	b.results = a->h_res.data();
+	b.seq_nt = a->h_nt.data();
+	b.seq_p = a->h_p.data();
+	b.seq_stride = OUT_ROW;
+	b.seq_capacity = n * OUT_ROW;
+	rc = pamd_assemble_host(a->dev, &b);
+	if (rc != PAMD_OK)
+		return rc;
+	// map results back: h_pre[i] == -2 pairs take results in order; remember the slot in h_pre as -(k+3)
+	for (size_t k = 0; k < n; k++)
+		a->h_pre[sent[k]] = -(int) k - 3;
+	return PAMD_OK;
+}
+
+// Replay staged pair `i` the way assemble_seq() would have (assembler.c:252-348).  Returns the
+// result pointer or NULL if the pair was rejected.  `f`/`r` are the caller-visible read buffers.
+const panda_result_seq *replay(PandaAssembler a, size_t i, const panda_qual *f, const panda_qual *r) {
+	a->count++;
+	const int pre = a->h_pre[i];
+	if (pre == -1) {
+		a->badreadcount++;
+		return nullptr;
+	}
+	if (pre >= 0) {
+		a->rejected[pre]++;
+		return nullptr;
+	}
+	const size_t k = (size_t) (-pre - 3);
+	const pamd_pair_result &d = a->h_res[k];
+	panda_result_seq &res = a->result;
+	res.name = a->h_id[i];
+	res.forward = f;
+	res.reverse = r;
+	res.forward_length = a->h_flen[k];
+	res.reverse_length = a->h_rlen[k];
+	res.forward_offset = d.fwd_offset;
+	res.reverse_offset = d.rev_offset;
+	res.overlaps_examined = d.examined;
+	if (d.slow)
+		a->slowcount++;
+	switch (d.status) {
+	case PAMD_ST_BADR:
+		a->badreadcount++;
+		return nullptr;
+	case PAMD_ST_NOFP:
+		a->nofpcount++;
+		return nullptr;
+	case PAMD_ST_NORP:
+		a->norpcount++;
+		return nullptr;
+	case PAMD_ST_NOALGN:
+		if (a->noalgn != nullptr)	// assembler.c:294-296
+			a->noalgn(a, &res.name, f, res.forward_length, r, res.reverse_length, a->noalgn_data);
+		a->noalgncount++;
+		return nullptr;
+	default:
+		break;
+	}
+	res.quality = d.quality;
+	res.degenerates = d.degenerates;
+	res.sequence = a->result_seq;
+	res.sequence_length = d.seq_len;
+	res.overlap_mismatches = d.mismatches;
+	res.overlap = d.overlap;
+	res.estimated_overlap_probability = d.est_overlap_prob;
+	if (d.status == PAMD_ST_LOWQ) {
+		a->lowqcount++;
+		return nullptr;
+	}
+	if (d.status == PAMD_ST_REJECT) {
+		a->rejected[d.reject_module]++;
+		return nullptr;
+	}
+	// accepted by the kernel: materialise panda_result[] (16 B/base AoS) from the two device arrays
+	const uint8_t *nt = &a->h_nt[d.seq_offset];
+	const double *p = &a->h_p[d.seq_offset];
+	for (size_t j = 0; j < d.seq_len; j++) {
+		a->result_seq[j].nt = (panda_nt) nt[j];
+		a->result_seq[j].p = p[j];
+	}
+	// remaining (host-callback) check modules, in order (module.c:124-136)
+	for (size_t m = a->fused_prefix; m < a->modules.size(); m++) {
+		PandaModule mod = a->modules[m];
+		if (mod->check != nullptr && !mod->check(a->logger, &res, mod->user_data)) {
+			a->rejected[m]++;
+			return nullptr;
+		}
+	}
+	a->okcount++;
+	a->overlapcount[res.overlap]++;
+	if (a->longest_overlap < res.overlap)
+		a->longest_overlap = res.overlap;
+	return &res;
+}
+
+// Stage one pair at slot i; decides what assemble_seq() decides before align() on the host side
+// only where it must (length < 2, precheck callbacks -- assembler.c:255-261).
+void stage_pair(PandaAssembler a, size_t i, const panda_seq_identifier *id, const panda_qual *f, size_t flen, const panda_qual *r, size_t rlen) {
+	a->h_id[i] = *id;
+	a->h_flen[i] = (uint16_t) flen;
+	a->h_rlen[i] = (uint16_t) rlen;
+	memcpy(&a->h_fwd[i * ROW], f, flen * sizeof(panda_qual));
+	memcpy(&a->h_rev[i * ROW], r, rlen * sizeof(panda_qual));
+	int pre = -2;
+	if (flen < 2 || rlen < 2) {
+		pre = -1;
+	} else {
+		for (size_t m = 0; m < a->modules.size(); m++) {	// module_precheckseq, module.c:138-154
+			PandaModule mod = a->modules[m];
+			if (mod->precheck != nullptr && !mod->precheck(a->logger, id, f, flen, r, rlen, mod->user_data)) {
+				pre = (int) m;
+				break;
+			}
+		}
+	}
+	a->h_pre[i] = pre;
+}
+
+void ensure_staging(PandaAssembler a, size_t pairs) {
+	if (a->h_flen.size() < pairs) {
+		a->h_fwd.resize(pairs * ROW);
+		a->h_rev.resize(pairs * ROW);
+		a->h_flen.resize(pairs);
+		a->h_rlen.resize(pairs);
+		a->h_id.resize(pairs);
+		a->h_pre.resize(pairs);
+	}
+}
+
+}	// namespace
+
+extern "C" {
+
+void pamd_compat_set_device(int device) {
+	g_device = device;
+}
+
+void pamd_compat_set_batch_pairs(size_t pairs) {
+	g_batch_pairs = pairs ? pairs : 1;
+}
+
+PandaAssembler panda_assembler_new(PandaNextSeq next, void *next_data, PandaDestroy next_destroy, PandaLogProxy logger) {
+	return panda_assembler_new_kmer(next, next_data, next_destroy, logger, PANDA_DEFAULT_NUM_KMERS);
+}
+
+PandaAssembler panda_assembler_new_kmer(PandaNextSeq next, void *next_data, PandaDestroy next_destroy, PandaLogProxy logger, size_t num_kmers) {
+	pamd_assembler *dev = nullptr;
+	if (num_kmers != 2) {
+		// the reference's own table indexing only works for 2 (assembler.c:94 vs :99)
+		pamd_set_error("num_kmers = %zu is not supported on the device path (only 2)", num_kmers);
+	} else {
+		dev = pamd_assembler_create(g_device);
+	}
+	if (dev == nullptr) {
+		if (next_destroy != nullptr)
+			next_destroy(next_data);
+		fprintf(stderr, "pandaseq_amd: %s\n", pamd_last_error());
+		return nullptr;
+	}
+	PandaAssembler a = new panda_assembler;
+	a->next = next;
+	a->next_data = next_data;
+	a->next_destroy = next_destroy;
+	a->logger = logger;
+	a->dev = dev;
+	a->num_kmers = num_kmers;
+	a->algo = panda_algorithm_simple_bayes_new();	// assembler_support.c:77
+	memset(&a->result, 0, sizeof a->result);
+	a->result.sequence = a->result_seq;
+	return a;
+}
+
+PandaAssembler panda_assembler_ref(PandaAssembler a) {
+	std::lock_guard<std::mutex> g(g_ref_lock);
+	a->refcnt++;
+	return a;
+}
+
+void panda_assembler_unref(PandaAssembler a) {	// assembler_support.c:151-175
+	if (a == nullptr)
+		return;
+	size_t c;
+	{
+		std::lock_guard<std::mutex> g(g_ref_lock);
+		c = --a->refcnt;
+	}
+	if (c != 0)
+		return;
+	for (PandaModule m : a->modules)
+		panda_module_unref(m);
+	if (a->next_destroy != nullptr && a->next != nullptr)
+		a->next_destroy(a->next_data);
+	if (a->noalgn_destroy != nullptr && a->noalgn != nullptr)
+		a->noalgn_destroy(a->noalgn_data);
+	panda_algorithm_unref(a->algo);
+	pamd_assembler_destroy(a->dev);
+	delete a;
+}
+
+void panda_assembler_copy_configuration(PandaAssembler dest, PandaAssembler src) {	// assembler_support.c:119-137
+	for (PandaModule m : src->modules)
+		panda_assembler_add_module(dest, m);
+	panda_assembler_set_forward_primer(dest, src->forward_primer, src->forward_primer_length);
+	panda_assembler_set_reverse_primer(dest, src->reverse_primer, src->reverse_primer_length);
+	dest->forward_trim = src->forward_trim;
+	dest->reverse_trim = src->reverse_trim;
+	dest->threshold = src->threshold;
+	dest->minoverlap = src->minoverlap;
+	dest->maxoverlap = src->maxoverlap;
+	dest->post_primers = src->post_primers;
+	panda_algorithm_unref(dest->algo);
+	dest->algo = panda_algorithm_ref(src->algo);
+	dest->primer_penalty = src->primer_penalty;
+	dest->dev_dirty = true;
+}
+
+const panda_result_seq *panda_assembler_assemble(PandaAssembler a, panda_seq_identifier *id, const panda_qual *forward, size_t forward_length, const panda_qual *reverse, size_t reverse_length) {
+	if (forward_length > PAMD_MAX_LEN || reverse_length > PAMD_MAX_LEN) {	// the reference asserts (assembler.c:375-376)
+		fprintf(stderr, "pandaseq_amd: read longer than PANDA_MAX_LEN\n");
+		abort();
+	}
+	// a pending prefetched batch of panda_assembler_next() shares the staging area: refuse to mix
+	if (a->batch_pos < a->batch_n) {
+		fprintf(stderr, "pandaseq_amd: panda_assembler_assemble() called while panda_assembler_next() has prefetched pairs pending\n");
+		return nullptr;
+	}
+	ensure_staging(a, 1);
+	stage_pair(a, 0, id, forward, forward_length, reverse, reverse_length);
+	a->batch_n = 1;
+	a->batch_pos = 1;
+	if (run_batch(a) != PAMD_OK) {
+		fprintf(stderr, "pandaseq_amd: %s\n", pamd_last_error());
+		abort();	// no CPU fallback: a device failure is fatal, never silently wrong
+	}
+	return replay(a, 0, forward, reverse);
+}
+
+const panda_result_seq *panda_assembler_next(PandaAssembler a) {
+	if (a->next == nullptr)
+		return nullptr;
+	while (true) {
+		if (a->batch_pos == a->batch_n) {
+			if (a->eof)
+				return nullptr;
+			// pull the next batch from the source; its buffers are only valid until the next call
+			// (pandaseq-common.h:486-487), so every pair is copied into the staging rows
+			ensure_staging(a, g_batch_pairs);
+			size_t n = 0;
+			while (n < g_batch_pairs) {
+				panda_seq_identifier id;
+				const panda_qual *f = nullptr, *r = nullptr;
+				size_t fl = 0, rl = 0;
+				if (!a->next(&id, &f, &fl, &r, &rl, a->next_data)) {
+					a->eof = true;
+					break;
+				}
+				if (fl > PAMD_MAX_LEN || rl > PAMD_MAX_LEN) {	// assembler.c:359-360
+					fprintf(stderr, "pandaseq_amd: read longer than PANDA_MAX_LEN\n");
+					abort();
+				}
+				stage_pair(a, n, &id, f, fl, r, rl);
+				n++;
+			}
+			a->batch_n = n;
+			a->batch_pos = 0;
+			if (n == 0)
+				return nullptr;
+			// keep an untouched copy of the reads for result.forward / result.reverse: run_batch compacts rows
+			if (run_batch(a) != PAMD_OK) {
+				fprintf(stderr, "pandaseq_amd: %s\n", pamd_last_error());
+				abort();
+			}
+		}
+		const size_t i = a->batch_pos++;
+		// result.forward/reverse point at this assembler's copy of the reads (valid until the next call)
+		const int pre = a->h_pre[i];
+		const size_t row = pre <= -3 ? (size_t) (-pre - 3) : i;
+		const panda_result_seq *res = replay(a, i, reinterpret_cast<const panda_qual *>(&a->h_fwd[row * ROW]), reinterpret_cast<const panda_qual *>(&a->h_rev[row * ROW]));
+		if (res != nullptr)
+			return res;
+	}
+}
+
+bool panda_assembler_add_module(PandaAssembler a, PandaModule module) {	// module.c:156-180
+	if (module == nullptr)
+		return false;
+	a->modules.push_back(panda_module_ref(module));
+	a->rejected.push_back(0);
+	a->dev_dirty = true;
+	return true;
+}
+
+size_t panda_assembler_add_modules(PandaAssembler a, PandaModule *modules, size_t modules_length) {
+	size_t it;
+	for (it = 0; it < modules_length; it++)
+		if (!panda_assembler_add_module(a, modules[it]))
+			return it;
+	return it;
+}
+
+bool panda_assembler_foreach_module(PandaAssembler a, PandaModuleCallback callback, void *data) {
+	for (size_t it = 0; it < a->modules.size(); it++)
+		if (!callback(a, a->modules[it], a->rejected[it], data))
+			return false;
+	return true;
+}
+
+void panda_assembler_module_stats(PandaAssembler a) {	// module.c:208-216 (STAT lines; here to stderr)
+	for (size_t it = 0; it < a->modules.size(); it++)
+		if (a->rejected[it] > 0)
+			fprintf(stderr, "%s%sSTAT\t%s\t%zu\n", a->name, a->name[0] ? "\t" : "", a->modules[it]->name, a->rejected[it]);
+}
+
+PandaAlgorithm panda_assembler_get_algorithm(PandaAssembler a) {
+	return a->algo;
+}
+
+void panda_assembler_set_algorithm(PandaAssembler a, PandaAlgorithm algorithm) {
+	if (algorithm == nullptr)
+		return;
+	panda_algorithm_unref(a->algo);
+	a->algo = panda_algorithm_ref(algorithm);
+	a->dev_dirty = true;
+}
+
+long panda_assembler_get_bad_read_count(PandaAssembler a) { return a->badreadcount; }
+long panda_assembler_get_count(PandaAssembler a) { return a->count; }
+
+void panda_assembler_set_fail_alignment(PandaAssembler a, PandaFailAlign handler, void *handler_data, PandaDestroy handler_destroy) {
+	if (a->noalgn_destroy != nullptr && a->noalgn != nullptr)
+		a->noalgn_destroy(a->noalgn_data);
+	a->noalgn = handler;
+	a->noalgn_data = handler_data;
+	a->noalgn_destroy = handler_destroy;
+}
+
+long panda_assembler_get_failed_alignment_count(PandaAssembler a) { return a->noalgncount; }
+
+panda_nt *panda_assembler_get_forward_primer(PandaAssembler a, size_t *length) {
+	if (length != nullptr)
+		*length = a->forward_primer_length;
+	return a->forward_primer_length == 0 ? nullptr : a->forward_primer;
+}
+
+void panda_assembler_set_forward_primer(PandaAssembler a, panda_nt *sequence, size_t length) {
+	if (length < PAMD_MAX_LEN) {
+		for (size_t it = 0; it < length; it++)
+			a->forward_primer[it] = sequence[it];
+		a->forward_primer_length = length;
+		a->forward_trim = 0;
+		a->dev_dirty = true;
+	}
+}
+
+size_t panda_assembler_get_forward_trim(PandaAssembler a) { return a->forward_trim; }
+
+void panda_assembler_set_forward_trim(PandaAssembler a, size_t trim) {
+	a->forward_trim = trim;
+	a->forward_primer_length = 0;
+	a->dev_dirty = true;
+}
+
+size_t panda_assembler_get_longest_overlap(PandaAssembler a) { return a->longest_overlap; }
+long panda_assembler_get_low_quality_count(PandaAssembler a) { return a->lowqcount; }
+int panda_assembler_get_minimum_overlap(PandaAssembler a) { return a->minoverlap; }
+
+void panda_assembler_set_minimum_overlap(PandaAssembler a, int overlap) {
+	if (overlap > 1 && (size_t) overlap < 2 * PAMD_MAX_LEN) {
+		a->minoverlap = overlap;
+		a->dev_dirty = true;
+	}
+}
+
+int panda_assembler_get_maximum_overlap(PandaAssembler a) { return a->maxoverlap; }
+
+void panda_assembler_set_maximum_overlap(PandaAssembler a, int overlap) {
+	if (overlap >= 0 && (size_t) overlap < 2 * PAMD_MAX_LEN) {
+		a->maxoverlap = overlap;
+		a->dev_dirty = true;
+	}
+}
+
+const char *panda_assembler_get_name(PandaAssembler a) {
+	if (a == nullptr || a->name[0] == '\0')
+		return nullptr;
+	return a->name;
+}
+
+void panda_assembler_set_name(PandaAssembler a, const char *name) {
+	if (name == nullptr) {
+		a->name[0] = '\0';
+		return;
+	}
+	strncpy(a->name, name, PAMD_MAX_LEN);
+	a->name[PAMD_MAX_LEN - 1] = '\0';
+}
+
+long panda_assembler_get_no_forward_primer_count(PandaAssembler a) { return a->nofpcount; }
+long panda_assembler_get_no_reverse_primer_count(PandaAssembler a) { return a->norpcount; }
+size_t panda_assembler_get_num_kmer(PandaAssembler a) { return a->num_kmers; }
+long panda_assembler_get_ok_count(PandaAssembler a) { return a->okcount; }
+
+long panda_assembler_get_overlap_count(PandaAssembler a, size_t overlap) {
+	return (overlap < 2 * PAMD_MAX_LEN) ? a->overlapcount[overlap] : -1;
+}
+
+bool panda_assembler_get_primers_after(PandaAssembler a) { return a->post_primers; }
+
+void panda_assembler_set_primers_after(PandaAssembler a, bool after) {
+	a->post_primers = after;
+	a->dev_dirty = true;
+}
+
+panda_nt *panda_assembler_get_reverse_primer(PandaAssembler a, size_t *length) {
+	if (length != nullptr)
+		*length = a->reverse_primer_length;
+	return a->reverse_primer_length == 0 ? nullptr : a->reverse_primer;
+}
+
+void panda_assembler_set_reverse_primer(PandaAssembler a, panda_nt *sequence, size_t length) {
+	if (length < PAMD_MAX_LEN) {
+		for (size_t it = 0; it < length; it++)
+			a->reverse_primer[it] = sequence[it];
+		a->reverse_primer_length = length;
+		a->reverse_trim = 0;
+		a->dev_dirty = true;
+	}
+}
+
+size_t panda_assembler_get_reverse_trim(PandaAssembler a) { return a->reverse_trim; }
+
+void panda_assembler_set_reverse_trim(PandaAssembler a, size_t trim) {
+	a->reverse_trim = trim;
+	a->reverse_primer_length = 0;
+	a->dev_dirty = true;
+}
+
+long panda_assembler_get_slow_count(PandaAssembler a) { return a->slowcount; }
+double panda_assembler_get_threshold(PandaAssembler a) { return std::exp(a->threshold); }
+
+void panda_assembler_set_threshold(PandaAssembler a, double threshold) {
+	if (threshold > 0 && threshold < 1) {
+		a->threshold = std::log(threshold);
+		a->dev_dirty = true;
+	}
+}
+
+PandaLogProxy panda_assembler_get_logger(PandaAssembler a) { return a->logger; }
+double panda_assembler_get_primer_penalty(PandaAssembler a) { return std::exp(a->primer_penalty); }	// sic, assembler_support.c:399-402
+
+void panda_assembler_set_primer_penalty(PandaAssembler a, double threshold) {
+	if (threshold >= 0 && threshold < 1) {
+		a->primer_penalty = threshold;
+		a->dev_dirty = true;
+	}
+}
+
+}	// extern "C"

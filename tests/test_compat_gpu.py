@@ -1,0 +1,105 @@
+"""The reference's own per-assembler API (panda_assembler_next / _assemble), re-linked against
+libpandaseq_amd.so by a plain-C client, compared with the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build_client(tmp):
+    exe = os.path.join(tmp, "test_compat")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "test_compat.c"), "-o", exe,
+                           "-L", os.path.join(ROOT, "pandaseq_amd"), "-lpandaseq_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "pandaseq_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def _read_record(buf, o):
+    h = struct.unpack_from("<8I", buf, o)
+    o += 32
+    q, e = struct.unpack_from("<2d", buf, o)
+    o += 16
+    m = h[2]
+    nt = np.frombuffer(buf, np.uint8, m, o)
+    o += m
+    p = np.frombuffer(buf, np.float64, m, o)
+    o += 8 * m
+    return dict(index=h[0], overlap=h[1], seq_len=m, mism=h[3], degen=h[4], fo=h[5], ro=h[6], examined=h[7], quality=q, est=e, nt=nt, p=p), o
+
+
+@pytest.mark.parametrize("algo,mode", [("simple_bayesian", 0), ("pear", 0), ("rdp_mle", 1)])
+def test_reference_api_client(built, tmp_path, algo, mode):
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    from util import adversarial_pairs
+    spec = synth.config_spec(1)
+    n = 2500
+    fwd, rev, flen, rlen = adversarial_pairs(spec, n, seed=21)
+    if algo == "pear":
+        rlen = np.minimum(rlen, flen)
+    stride = fwd.shape[1]
+    blob = bytearray(struct.pack("<2I", n, stride))
+    for i in range(n):
+        blob += struct.pack("<2H", int(flen[i]), int(rlen[i])) + fwd[i].tobytes() + rev[i].tobytes()
+    pin = tmp_path / "pairs.bin"
+    pout = tmp_path / "out.bin"
+    pin.write_bytes(bytes(blob))
+    exe = _build_client(str(tmp_path))
+    subprocess.check_call([exe, str(pin), str(pout), algo, str(mode)], timeout=300)
+    buf = pout.read_bytes()
+
+    mods = [("min_overlapbits", 15)] if mode == 1 else []
+    o_res, o_nt, o_p, o_ctr = po.assemble_batch(po.make_config(algo, modules=mods), fwd, rev, flen, rlen)
+    # expected sequence of returned results, replaying the host-side modules of the client
+    expected = []
+    rej_host = rej_pre = 0
+    for i in range(n):
+        if flen[i] < 2 or rlen[i] < 2:
+            continue
+        if mode == 1 and i % 11 == 0:
+            rej_pre += 1
+            continue
+        if o_res["status"][i] != 0:
+            continue
+        if mode == 1 and o_res["mismatches"][i] > 3:
+            rej_host += 1
+            continue
+        expected.append(i)
+    o = 0
+    got = []
+    while struct.unpack_from("<I", buf, o)[0] != 0xFFFFFFFF:
+        rec, o = _read_record(buf, o)
+        got.append(rec)
+    o += 4
+    counters = struct.unpack_from("<10q", buf, o)
+    o += 80
+    assert [g["index"] for g in got] == expected, "results must come back in source order"
+    for g in got:
+        i = g["index"]
+        assert g["overlap"] == o_res["overlap"][i] and g["seq_len"] == o_res["seq_len"][i]
+        assert g["mism"] == o_res["mismatches"][i] and g["degen"] == o_res["degenerates"][i] and g["examined"] == o_res["examined"][i]
+        assert g["quality"] == o_res["quality"][i] and g["est"] == o_res["est_prob"][i]
+        assert np.array_equal(g["nt"], o_nt[i, :g["seq_len"]]) and np.array_equal(g["p"], o_p[i, :g["seq_len"]])
+    count, ok, noalgn, lowq, badr, slow, longest, noalgn_cb = counters[:8]
+    assert count == n and ok == len(expected) and noalgn_cb == noalgn
+    if mode == 0:
+        assert (noalgn, lowq, badr, slow) == (o_ctr["noalgn"], o_ctr["lowq"], o_ctr["badr"], o_ctr["slow"])
+        assert longest == o_ctr["longest_overlap"]
+    # single-pair entry point
+    m = struct.unpack_from("<I", buf, o)[0]
+    o += 4
+    for i in range(m):
+        flag = struct.unpack_from("<I", buf, o)[0]
+        o += 4
+        should = i in expected
+        assert bool(flag) == should, i
+        if flag:
+            rec, o = _read_record(buf, o)
+            assert rec["overlap"] == o_res["overlap"][i] and rec["quality"] == o_res["quality"][i]
+            assert np.array_equal(rec["nt"], o_nt[i, :rec["seq_len"]]) and np.array_equal(rec["p"], o_p[i, :rec["seq_len"]])
