@@ -404,6 +404,10 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	o += 64;
 	p.w_rn = o;
 	o += 64;
+	p.w_fpl = o;
+	o += 320;
+	p.w_rpl = o;
+	o += 320;
 	p.w_bits = o;
 	o += 128;
 	p.w_nt = o;

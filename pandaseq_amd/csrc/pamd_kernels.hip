@@ -26,6 +26,8 @@ namespace {
 // can emit), as many as fit in the log-p staging area it shares (PamdKernelParams::hash_slots)
 constexpr unsigned HASH_EMPTY = 0xFFFFFFFFu;
 constexpr unsigned NT_N = 15;
+constexpr unsigned PLANE_STRIDE = 80;	// one zero dword in front, 64 bytes of bits (512 positions), zero tail
+constexpr unsigned PLANE_BYTES = 4 * PLANE_STRIDE;
 constexpr unsigned long long ARENA_CHUNK = 16384;	// bases a wave reserves from the output arena at a time
 
 typedef unsigned long long u64;
@@ -103,6 +105,8 @@ struct WaveLds {
 	uint32_t *rc;	// reverse 2-bit codes, 16 per word, first base in the LOW bits
 	uint32_t *fn;	// forward N bitmap
 	uint32_t *rn;	// reverse N bitmap
+	uint8_t *fpl;	// forward one-hot bit planes A,C,G,T: 4 x PLANE_STRIDE bytes, bit p = base p has that bit
+	uint8_t *rpl;	// reverse one-hot bit planes (natural read order)
 	uint32_t *bits;	// candidate overlaps (BITS_INIT, assembler.c:41,84)
 	uint8_t *nts;	// merged nt staging
 	double *ps;	// merged log-p staging; the k-mer table lives here while seeding
@@ -120,23 +124,42 @@ __device__ __forceinline__ uint4 load_read(const uint8_t *row, unsigned row_byte
 }
 
 template <bool FORWARD>
-__device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint16_t *dst, uint32_t *codes, uint32_t *nmap) {
+__device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint16_t *dst, uint32_t *codes, uint32_t *nmap, uint8_t *planes) {
 	if (lane * 8 < len)
 		reinterpret_cast<uint4 *>(dst)[lane] = v;
 	const unsigned w[4] = { v.x, v.y, v.z, v.w };
-	unsigned code16 = 0, nbits = 0, not2 = 0;
+	// Branch-free on purpose (straight-line bit arithmetic; ?: chains here compile to exec-mask
+	// branches per base).  nt is 0..15 in the device domain.
+	//   2-bit code (misc.h:41: T=3 G=2 C=1, anything else 0) = two bits of a constant indexed by nt
+	//   N          = (nt + 1) >> 4
+	//   qual == 2  = bit 8 of ((qual ^ 2) - 1) taken as an unsigned byte
+	//   one-hot planes: bit b of nt, gathered over the lane's 8 bases into one byte per plane
+	unsigned code16 = 0, is2 = 0, pa = 0, pc = 0, pg = 0, pt = 0;
 #pragma unroll
 	for (int k = 0; k < 8; k++) {
 		const unsigned e = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
 		const unsigned nt = e & 0xFFu;
-		const int q = (int) (int8_t) (e >> 8);
-		const bool in = lane * 8 + k < len;
-		// misc.h:41: T=3 G=2 C=1, anything else (A, ambiguity codes, N) = 0
-		const unsigned c = in ? (nt == 8 ? 3u : nt == 4 ? 2u : nt == 2 ? 1u : 0u) : 0u;
+		const unsigned c = (0x00030210u >> ((nt & 15u) * 2u)) & 3u;
 		code16 |= FORWARD ? (c << (14 - 2 * k)) : (c << (2 * k));
-		nbits |= (in && nt == NT_N) ? (1u << k) : 0u;
-		not2 |= (in && q != 2) ? (1u << k) : 0u;
+		pa |= (nt & 1u) << k;
+		pc |= ((nt >> 1) & 1u) << k;
+		pg |= ((nt >> 2) & 1u) << k;
+		pt |= ((nt >> 3) & 1u) << k;
+		is2 |= (((((e >> 8) ^ 2u) & 0xFFu) - 1u) >> 8 & 1u) << k;
 	}
+	unsigned nbits = pa & pc & pg & pt;	// nt == 15
+	// bases at or beyond the read length contribute nothing
+	int cnt = len - lane * 8;
+	cnt = cnt < 0 ? 0 : (cnt > 8 ? 8 : cnt);
+	const unsigned inmask = (1u << cnt) - 1u;	// bit k set <=> base k of this lane exists
+	nbits &= inmask;
+	planes[4 + lane] = (uint8_t) (pa & inmask);
+	planes[4 + PLANE_STRIDE + lane] = (uint8_t) (pc & inmask);
+	planes[4 + 2 * PLANE_STRIDE + lane] = (uint8_t) (pg & inmask);
+	planes[4 + 3 * PLANE_STRIDE + lane] = (uint8_t) (pt & inmask);
+	const unsigned not2 = ~is2 & inmask;
+	const unsigned cmask = FORWARD ? ~(0xFFFFu >> (2 * cnt)) & 0xFFFFu : (1u << (2 * cnt)) - 1u;
+	code16 &= cmask;
 	// 16 codes per u32.  Forward reads are packed big-endian inside the word so that a k-mer
 	// extracted from them has its OLDEST base in the top bits like FOREACH_KMER's rolling value;
 	// reverse reads are packed little-endian, which gives FOREACH_KMER_REVERSE's value directly.
@@ -196,6 +219,56 @@ __device__ int primer_offset(const PamdKernelParams &P, const double *ltab, cons
 		}
 	}
 	return uni(besti);
+}
+
+// ---- simple_bayesian overlap_probability for up to 4 candidates at once (algo_simple_bayes.c:33-66) ----
+// The three counts are popcounts over one-hot bit planes.  Lane (row, c): row = lane >> 4 picks the
+// candidate, c = lane & 15 the 32-position chunk i in [32c, 32c + 32) of the overlap walk
+// (fi = flen - ov + i ascending in the forward planes, ri = rlen - 1 - i descending in the reverse
+// planes, so the reverse chunk is extracted at its mirrored position and bit-reversed).
+__device__ __forceinline__ unsigned plane_word(const uint8_t *plane, int start_bit) {
+	// 32 bits of a plane starting at bit `start_bit` (>= -32; the dword in front of the plane is zero)
+	const uint32_t *w = reinterpret_cast<const uint32_t *>(plane) + 1 + (start_bit >> 5);
+	return __builtin_amdgcn_alignbit(w[1], w[0], (unsigned) start_bit & 31u);
+}
+
+__device__ __forceinline__ double score_sb_planes(const PamdKernelParams &P, const WaveLds &L, int flen, int rlen, int ov, bool active, int lane) {
+	const int c = lane & 15;
+	const int i0 = 32 * c;
+	// positions that exist on both reads: max(0, ov - flen) <= i < min(ov, rlen)
+	int lo_i = ov - flen;
+	lo_i = lo_i < 0 ? 0 : lo_i;
+	const int hi_i = ov < rlen ? ov : rlen;
+	int lo = lo_i - i0, hi = hi_i - i0;
+	lo = lo < 0 ? 0 : (lo > 32 ? 32 : lo);
+	hi = hi < 0 ? 0 : (hi > 32 ? 32 : hi);
+	const unsigned below_hi = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u);
+	const unsigned below_lo = lo >= 32 ? 0xFFFFFFFFu : ((1u << lo) - 1u);
+	unsigned vmask = active ? (below_hi & ~below_lo) : 0u;
+	unsigned packed = 0;
+	if (vmask != 0) {
+		const int fs = flen - ov + i0;	// >= -31 here
+		const int rs = rlen - 32 - i0;	// >= -31 here
+		const unsigned fa = plane_word(L.fpl, fs), fc = plane_word(L.fpl + PLANE_STRIDE, fs);
+		const unsigned fg = plane_word(L.fpl + 2 * PLANE_STRIDE, fs), ft = plane_word(L.fpl + 3 * PLANE_STRIDE, fs);
+		const unsigned ra = __builtin_bitreverse32(plane_word(L.rpl, rs)), rc = __builtin_bitreverse32(plane_word(L.rpl + PLANE_STRIDE, rs));
+		const unsigned rg = __builtin_bitreverse32(plane_word(L.rpl + 2 * PLANE_STRIDE, rs)), rt = __builtin_bitreverse32(plane_word(L.rpl + 3 * PLANE_STRIDE, rs));
+		const unsigned match = (fa & ra) | (fc & rc) | (fg & rg) | (ft & rt);
+		const unsigned isn = (fa & fc & fg & ft) | (ra & rc & rg & rt);
+		const unsigned unknowns = __popc(vmask & isn);
+		const unsigned matches = __popc(vmask & ~isn & match);
+		const unsigned mismatches = __popc(vmask & ~isn & ~match);
+		packed = unknowns | (matches << 10) | (mismatches << 20);	// each count <= 450 < 1024
+	}
+	// sum over the 16 lanes of the row (rotate-and-add inside the DPP row)
+	packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x128, 0xF, 0xF, false);	// row_ror:8
+	packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x124, 0xF, 0xF, false);	// row_ror:4
+	packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x122, 0xF, 0xF, false);	// row_ror:2
+	packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x121, 0xF, 0xF, false);	// row_ror:1
+	const unsigned unknowns = packed & 1023u, matches = (packed >> 10) & 1023u, mismatches = packed >> 20;
+	// size_t arithmetic inside the parenthesis (algo_simple_bayes.c:61-65), wrap included
+	const u64 free_bases = (ov >= flen && ov >= rlen) ? (u64) unknowns : (u64) flen + (u64) rlen - 2ull * (u64) ov + (u64) unknowns;
+	return P.qual_nn * (double) free_bases + (double) matches * P.sb_pmatch + (double) mismatches * P.sb_pmismatch;
 }
 
 // ---- overlap_probability, one candidate ------------------------------------------------------
@@ -302,8 +375,16 @@ struct WaveArena {
 };
 
 // ---- one pair ---------------------------------------------------------------------------------
+struct PairOut {
+	pamd_pair_result rec;
+	int status;
+	int reject;
+	int seqlen;
+};
+
+// Everything up to (not including) the HBM stores of one pair.
 template <int ALGO>
-__device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, unsigned *lctr, const WaveLds &L, WaveArena &arena, u64 pair, int lane, const int flen, const int rlen, const uint4 fregs, const uint4 rregs
+__device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, const WaveLds &L, int lane, const int flen, const int rlen, const uint4 fregs, const uint4 rregs, PairOut &po
 #ifdef PAMD_PHASE_TIMING
 	, u64 *ph_acc
 #endif
@@ -313,7 +394,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 	const unsigned hmask = P.hash_slots - 1u;
 	const unsigned hshift = P.hash_shift;
 
-	pamd_pair_result out;
+	pamd_pair_result &out = po.rec;
 	out.quality = 0.0;
 	out.est_overlap_prob = 0.0;
 	out.seq_offset = ~0ull;
@@ -342,8 +423,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		}
 		// previous pair's readers are done with this wave's LDS
 		wave_sync();
-		const int uf = stage_read<true>(fregs, flen, lane, L.F, L.fc, L.fn);
-		const int ur = stage_read<false>(rregs, rlen, lane, L.R, L.rc, L.rn);
+		const int uf = stage_read<true>(fregs, flen, lane, L.F, L.fc, L.fn, L.fpl);
+		const int ur = stage_read<false>(rregs, rlen, lane, L.R, L.rc, L.rn, L.rpl);
 		// clear the k-mer table (aliases the log-p staging area) and the candidate bitmap
 		for (unsigned s4 = lane; s4 < P.hash_slots / 4; s4 += 64)
 			reinterpret_cast<uint4 *>(L.hash)[s4] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
@@ -474,18 +555,51 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		double best = P.qual_nn * (double) (flen + rlen);	// assembler.c:60
 		int bo = -1;
 		int examined = 0;
-		for (int w = 0; w <= lastw; w++) {
-			unsigned m = (unsigned) __builtin_amdgcn_readlane((int) mybits, w);
-			while (m) {
-				const int b = __builtin_ctz(m);
-				m &= m - 1;
-				const int ov = w * 32 + b + minov;
-				const double pr = score_overlap<ALGO>(P, ltab, L, flen, rlen, ov, lane);
-				if (pr > best) {	// strict: ascending scan keeps the smallest overlap on ties
-					best = pr;
-					bo = ov;
+		if (ALGO == PAMD_ALGO_SIMPLE_BAYES) {
+			// four candidates per step, one per 16-lane row, still judged in ascending overlap order
+			const int row = lane >> 4;
+			int myov = 0;	// this row's candidate
+			int pending = 0;
+			for (int w = 0; w <= lastw + 1; w++) {
+				unsigned m = w <= lastw ? (unsigned) __builtin_amdgcn_readlane((int) mybits, w) : 0u;
+				const bool flush = w > lastw;
+				while (m != 0 || (flush && pending > 0)) {
+					if (m != 0) {
+						const int b = __builtin_ctz(m);
+						m &= m - 1;
+						const int ov = w * 32 + b + minov;
+						myov = row == pending ? ov : myov;
+						pending++;
+					}
+					if (pending == 4 || (flush && m == 0)) {
+						const double sc = score_sb_planes(P, L, flen, rlen, myov, row < pending, lane);
+						for (int r = 0; r < pending; r++) {
+							const double pr = lane_f64(sc, 16 * r);
+							const int ov = __builtin_amdgcn_readlane(myov, 16 * r);
+							if (pr > best) {	// strict: ascending scan keeps the smallest overlap on ties
+								best = pr;
+								bo = ov;
+							}
+						}
+						examined += pending;
+						pending = 0;
+					}
 				}
-				examined++;
+			}
+		} else {
+			for (int w = 0; w <= lastw; w++) {
+				unsigned m = (unsigned) __builtin_amdgcn_readlane((int) mybits, w);
+				while (m) {
+					const int b = __builtin_ctz(m);
+					m &= m - 1;
+					const int ov = w * 32 + b + minov;
+					const double pr = score_overlap<ALGO>(P, ltab, L, flen, rlen, ov, lane);
+					if (pr > best) {	// strict: ascending scan keeps the smallest overlap on ties
+						best = pr;
+						bo = ov;
+					}
+					examined++;
+				}
 			}
 		}
 		out.examined = (uint16_t) examined;
@@ -639,7 +753,18 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		}
 	} while (0);
 
-	// ---- write the merged sequence of accepted pairs ----
+	po.status = status;
+	po.reject = reject;
+	po.seqlen = seqlen;
+	out.status = (uint8_t) status;
+	out.reject_module = (int8_t) reject;
+	PH_MARK(7);
+}
+
+// The HBM stores of one pair: merged row (accepted pairs only), 48-byte record, workgroup counters.
+__device__ void emit_pair(const PamdKernelParams &P, unsigned *lctr, const WaveLds &L, WaveArena &arena, u64 pair, int lane, PairOut &po) {
+	pamd_pair_result &out = po.rec;
+	const int status = po.status, reject = po.reject, seqlen = po.seqlen;
 	if (status == PAMD_ST_OK) {
 		const u64 need = ((u64) seqlen + 15ull) & ~15ull;
 		u64 off;
@@ -679,9 +804,6 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			atomicAdd(P.error_flag, 1ull);
 		}
 	}
-	out.status = (uint8_t) status;
-	out.reject_module = (int8_t) reject;
-	PH_MARK(7);
 	if (lane == 0) {
 		P.results[pair] = out;
 		// workgroup-local counters (assembler.h:59-67,75); flushed once per workgroup
@@ -743,6 +865,10 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	L.rc = reinterpret_cast<uint32_t *>(wb + P.w_rc);
 	L.fn = reinterpret_cast<uint32_t *>(wb + P.w_fn);
 	L.rn = reinterpret_cast<uint32_t *>(wb + P.w_rn);
+	L.fpl = wb + P.w_fpl;
+	L.rpl = wb + P.w_rpl;
+	for (unsigned i = lane; i < 2 * PLANE_BYTES / 4; i += 64)
+		reinterpret_cast<uint32_t *>(wb + P.w_fpl)[i] = 0;	// plane pads stay zero for the whole kernel
 	L.bits = reinterpret_cast<uint32_t *>(wb + P.w_bits);
 	L.nts = reinterpret_cast<uint8_t *>(wb + P.w_nt);
 	L.ps = reinterpret_cast<double *>(wb + P.w_p);
@@ -766,6 +892,10 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	int rlen_v = P.rlen[q];
 	uint4 fregs = load_read(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
 	uint4 rregs = load_read(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
+	// settle the prologue loads before the loop so that, at the loop header, the carried registers
+	// are known-ready on both incoming edges (otherwise every use inside the loop gets a vmcnt wait
+	// that also waits for the previous pair's stores)
+	asm volatile("" : "+v"(flen_v), "+v"(rlen_v), "+v"(fregs.x), "+v"(fregs.y), "+v"(fregs.z), "+v"(fregs.w), "+v"(rregs.x), "+v"(rregs.y), "+v"(rregs.z), "+v"(rregs.w));
 	while (pair < P.n_pairs) {
 		const u64 next = pair + total_waves;
 		q = next < P.n_pairs ? next : last;
@@ -774,16 +904,22 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		const uint4 nf = load_read(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
 		const uint4 nr = load_read(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
 		const int flen = uni(flen_v), rlen = uni(rlen_v);
+		PairOut po;
 #ifdef PAMD_PHASE_TIMING
-		assemble_pair<ALGO>(P, ltab, lprimers, lctr, L, arena, pair, lane, flen, rlen, fregs, rregs, ph_acc);
+		assemble_pair<ALGO>(P, ltab, lprimers, L, lane, flen, rlen, fregs, rregs, po, ph_acc);
 #else
-		assemble_pair<ALGO>(P, ltab, lprimers, lctr, L, arena, pair, lane, flen, rlen, fregs, rregs);
+		assemble_pair<ALGO>(P, ltab, lprimers, L, lane, flen, rlen, fregs, rregs, po);
 #endif
-		pair = next;
+		// Rotate the prefetched registers in BEFORE this pair's stores are issued: vmcnt counts loads
+		// and stores in one in-order queue, so waiting for the (long finished) loads here is free,
+		// while waiting for them at the top of the next iteration would also wait for the stores.
 		flen_v = nflen_v;
 		rlen_v = nrlen_v;
 		fregs = nf;
 		rregs = nr;
+		asm volatile("" : "+v"(flen_v), "+v"(rlen_v), "+v"(fregs.x), "+v"(fregs.y), "+v"(fregs.z), "+v"(fregs.w), "+v"(rregs.x), "+v"(rregs.y), "+v"(rregs.z), "+v"(rregs.w));
+		emit_pair(P, lctr, L, arena, pair, lane, po);
+		pair = next;
 	}
 #ifdef PAMD_PHASE_TIMING
 	ph_acc[9] = __builtin_amdgcn_s_memtime() - ph_begin;
