@@ -378,6 +378,9 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.sb_pmismatch = a->sb_pmismatch;
 	p.pear_random_base = a->pear_random_base;
 	memcpy(p.modules, a->modules, sizeof p.modules);
+	for (int m = 0; m < a->n_modules; m++)
+		if (a->modules[m].kind == 1)
+			p.has_min_phred = 1;
 
 	// LDS carve-up (DESIGN.md "LDS layout")
 	const uint32_t smax = (uint32_t) (b->fwd_stride > b->rev_stride ? b->fwd_stride : b->rev_stride);
@@ -410,8 +413,8 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	o += 320;
 	p.w_bits = o;
 	o += 128;
-	p.w_nt = o;
-	o += mmax;
+	p.w_pend = o;
+	o += 16 * 80;	// GROUP parked records of 80 bytes
 	p.w_p = o;
 	o += (mmax * 8u > 2048u ? mmax * 8u : 2048u);
 	p.lds_wave_bytes = up16(o);

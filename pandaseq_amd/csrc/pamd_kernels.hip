@@ -108,7 +108,6 @@ struct WaveLds {
 	uint8_t *fpl;	// forward one-hot bit planes A,C,G,T: 4 x PLANE_STRIDE bytes, bit p = base p has that bit
 	uint8_t *rpl;	// reverse one-hot bit planes (natural read order)
 	uint32_t *bits;	// candidate overlaps (BITS_INIT, assembler.c:41,84)
-	uint8_t *nts;	// merged nt staging
 	double *ps;	// merged log-p staging; the k-mer table lives here while seeding
 	uint32_t *hash;
 };
@@ -131,6 +130,7 @@ __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint
 	// Branch-free on purpose (straight-line bit arithmetic; ?: chains here compile to exec-mask
 	// branches per base).  nt is 0..15 in the device domain.
 	//   2-bit code (misc.h:41: T=3 G=2 C=1, anything else 0) = two bits of a constant indexed by nt
+	//              (the reverse read stores C=2 G=1, see below)
 	//   N          = (nt + 1) >> 4
 	//   qual == 2  = bit 8 of ((qual ^ 2) - 1) taken as an unsigned byte
 	//   one-hot planes: bit b of nt, gathered over the lane's 8 bases into one byte per plane
@@ -139,8 +139,8 @@ __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint
 	for (int k = 0; k < 8; k++) {
 		const unsigned e = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
 		const unsigned nt = e & 0xFFu;
-		const unsigned c = (0x00030210u >> ((nt & 15u) * 2u)) & 3u;
-		code16 |= FORWARD ? (c << (14 - 2 * k)) : (c << (2 * k));
+		const unsigned c = ((FORWARD ? 0x00030210u : 0x00030120u) >> ((nt & 15u) * 2u)) & 3u;
+		code16 |= c << (2 * k);
 		pa |= (nt & 1u) << k;
 		pc |= ((nt >> 1) & 1u) << k;
 		pg |= ((nt >> 2) & 1u) << k;
@@ -158,12 +158,14 @@ __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint
 	planes[4 + 2 * PLANE_STRIDE + lane] = (uint8_t) (pg & inmask);
 	planes[4 + 3 * PLANE_STRIDE + lane] = (uint8_t) (pt & inmask);
 	const unsigned not2 = ~is2 & inmask;
-	const unsigned cmask = FORWARD ? ~(0xFFFFu >> (2 * cnt)) & 0xFFFFu : (1u << (2 * cnt)) - 1u;
-	code16 &= cmask;
-	// 16 codes per u32.  Forward reads are packed big-endian inside the word so that a k-mer
-	// extracted from them has its OLDEST base in the top bits like FOREACH_KMER's rolling value;
-	// reverse reads are packed little-endian, which gives FOREACH_KMER_REVERSE's value directly.
-	reinterpret_cast<uint16_t *>(codes)[FORWARD ? (lane ^ 1) : lane] = (uint16_t) code16;
+	code16 &= (1u << (2 * cnt)) - 1u;
+	// 16 codes per u32, base b at bits 2b..2b+1 of the stream.  A forward k-mer is the 16 bits
+	// ending at its position (oldest base in the low bits).  A reverse k-mer must pair its base t
+	// with the forward k-mer's base 7-t, so the reverse stream stores each code with its two bits
+	// swapped (C=2, G=1) and the probe bit-reverses the 16-bit window: the pair order flips and the
+	// bits inside each pair swap back.  Only equality of k-mers matters (the reference's table index
+	// is just a key), so any consistent encoding gives the same candidate set.
+	reinterpret_cast<uint16_t *>(codes)[lane] = (uint16_t) code16;
 	reinterpret_cast<uint8_t *>(nmap)[lane] = (uint8_t) nbits;
 	const int mine = not2 ? lane * 8 + (31 - __builtin_clz(not2)) + 1 : 0;
 	const u64 has = __ballot(not2 != 0);
@@ -267,8 +269,12 @@ __device__ __forceinline__ double score_sb_planes(const PamdKernelParams &P, con
 	packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x121, 0xF, 0xF, false);	// row_ror:1
 	const unsigned unknowns = packed & 1023u, matches = (packed >> 10) & 1023u, mismatches = packed >> 20;
 	// size_t arithmetic inside the parenthesis (algo_simple_bayes.c:61-65), wrap included
-	const u64 free_bases = (ov >= flen && ov >= rlen) ? (u64) unknowns : (u64) flen + (u64) rlen - 2ull * (u64) ov + (u64) unknowns;
-	return P.qual_nn * (double) free_bases + (double) matches * P.sb_pmatch + (double) mismatches * P.sb_pmismatch;
+	// flen + rlen - 2*ov + unknowns in size_t arithmetic: when it is negative the reference's unsigned
+	// value is 2^64 - |x|, whose conversion to double we reproduce through the 64-bit path; otherwise a
+	// single 32-bit conversion is exact
+	const int fb = (ov >= flen && ov >= rlen) ? (int) unknowns : flen + rlen - 2 * ov + (int) unknowns;
+	const double free_bases = fb >= 0 ? (double) (unsigned) fb : (double) (u64) (long long) fb;
+	return P.qual_nn * free_bases + (double) matches * P.sb_pmatch + (double) mismatches * P.sb_pmismatch;
 }
 
 // ---- overlap_probability, one candidate ------------------------------------------------------
@@ -374,47 +380,180 @@ struct WaveArena {
 	u64 end;
 };
 
-// ---- one pair ---------------------------------------------------------------------------------
-struct PairOut {
-	pamd_pair_result rec;
-	int status;
-	int reject;
-	int seqlen;
+// ---- deferred finish ---------------------------------------------------------------------------
+// The three quality sums of a pair (assembler.c:171,226,236) are ordered f64 chains: one lane can
+// advance one chain, so doing them per pair keeps 3 of 64 lanes busy for ~200 dependent adds.
+// Instead every wave parks each merged pair in a small LDS record, and once GROUP pairs are parked
+// (or its work runs out) finishes them together: lane 3*slot + chain walks one chain of one pair,
+// reading the log-probabilities back from the pair's output row (just written, L2/MALL resident),
+// so 48 lanes advance 48 chains with the same instructions.  Then lane `slot` finishes pair `slot`:
+// quality, LOWQ, check modules, the 48-byte record and the counters.
+constexpr int GROUP = 16;
+
+struct PendRec {	// 80 bytes
+	u64 pair;
+	u64 off;	// row offset in seq_nt / seq_p, ~0 = no row (failed before the merge, or arena full)
+	double best;	// estimated_overlap_probability
+	int st;		// status so far: BADR / NOFP / NORP / NOALGN, or OK = merged, sums pending
+	int seqlen, A, novl, len;
+	int bo, examined, mism, degen, fo, ro, slow;
+	int phmin;	// smallest panda_result_phred over the merged bases (only when a min_phred module is loaded)
+	int pad;
 };
 
-// Everything up to (not including) the HBM stores of one pair.
+static_assert(sizeof(PendRec) == 80, "PendRec is sized by pamd_api.cpp");
+
+__device__ __forceinline__ double load_p_l2(const double *p) {
+	// bypass this CU's vector L1: the row was written by this wave moments ago (write-through to L2)
+	union {
+		unsigned long long u;
+		double d;
+	} x;
+	x.u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return x.d;
+}
+
+__device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsigned *lctr, const PendRec *pend, int npend, int lane) {
+	// all of this wave's row stores must have reached L2 before they are read back
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	wave_sync();
+	// ---- ordered sums, one chain per lane ----
+	const int slot = lane / 3, chain = lane - 3 * slot;
+	double acc = 0.0;
+	{
+		int lo = 0, cnt = 0;
+		const double *row = P.seq_p;
+		if (slot < npend) {
+			const PendRec &r = pend[slot];
+			if (r.st == PAMD_ST_OK && r.off != ~0ull) {
+				// chain 0: forward-only [0,A)   chain 1: reverse-only [A+novl, seqlen)   chain 2: overlap [A, A+novl)
+				lo = chain == 0 ? 0 : (chain == 1 ? r.A + r.novl : r.A);
+				const int hi = chain == 0 ? r.A : (chain == 1 ? r.seqlen : r.A + r.novl);
+				cnt = hi - lo;
+				row = P.seq_p + r.off + lo;
+			}
+		}
+		int k = 0;
+		for (; k + 8 <= cnt; k += 8) {	// same left-to-right order as the reference, 8 loads in flight
+			const double v0 = load_p_l2(row + k), v1 = load_p_l2(row + k + 1), v2 = load_p_l2(row + k + 2), v3 = load_p_l2(row + k + 3);
+			const double v4 = load_p_l2(row + k + 4), v5 = load_p_l2(row + k + 5), v6 = load_p_l2(row + k + 6), v7 = load_p_l2(row + k + 7);
+			acc += v0;
+			acc += v1;
+			acc += v2;
+			acc += v3;
+			acc += v4;
+			acc += v5;
+			acc += v6;
+			acc += v7;
+		}
+		for (; k < cnt; k++)
+			acc += load_p_l2(row + k);
+	}
+	// ---- one lane per pair ----
+	const int src = lane < GROUP ? 3 * lane : 0;
+	const double fquality = __shfl(acc, src);
+	const double rquality = __shfl(acc, src + 1);
+	const double oquality = __shfl(acc, src + 2);
+	int status = -1, reject = -1, overlap = 0;
+	if (lane < npend) {
+		const PendRec r = pend[lane];
+		status = r.st;
+		double quality = 0.0;
+		u64 off = ~0ull;
+		if (status == PAMD_ST_OK) {
+			if (r.off == ~0ull) {
+				atomicAdd(P.error_flag, 1ull);	// the output arena was too small for this row
+			}
+			quality = (fquality + rquality + oquality) / (double) r.len;	// assembler.c:244
+			if (quality < P.threshold) {	// assembler.c:334-338
+				status = PAMD_ST_LOWQ;
+			} else {
+				for (int mi = 0; mi < P.n_modules && reject < 0; mi++) {	// module.c:124-136
+					const PamdModule md = P.modules[mi];
+					if (md.kind == 1) {	// plugin_min_phred.c:8-22
+						if (r.phmin < md.phred)
+							reject = mi;
+					} else if (md.kind == 2) {	// plugin_min_overlapbits.c:17-23
+						if (!(md.nats <= r.best))
+							reject = mi;
+					}
+				}
+				if (reject >= 0)
+					status = PAMD_ST_REJECT;
+				else
+					off = r.off;
+			}
+		}
+		overlap = r.bo;
+		// pamd_pair_result, 48 bytes, as three 16-byte stores
+		union {
+			double d;
+			unsigned u[2];
+		} q, e;
+		q.d = quality;
+		e.d = r.best;
+		uint4 *dst = reinterpret_cast<uint4 *>(&P.results[r.pair]);
+		dst[0] = make_uint4(q.u[0], q.u[1], e.u[0], e.u[1]);
+		dst[1] = make_uint4((unsigned) off, (unsigned) (off >> 32), (unsigned) r.seqlen | ((unsigned) r.bo << 16), (unsigned) r.examined | ((unsigned) r.mism << 16));
+		dst[2] = make_uint4((unsigned) r.degen | ((unsigned) r.fo << 16), (unsigned) r.ro | ((unsigned) status << 16) | (((unsigned) reject & 0xFFu) << 24), (unsigned) r.slow, 0u);
+		if (r.slow)
+			atomicAdd(&lctr[PAMD_CTR_SLOW], 1u);
+		if (status == PAMD_ST_OK)
+			atomicAdd(&lctr[PAMD_CTR_OVERLAP0 + overlap], 1u);
+		else if (status == PAMD_ST_REJECT)
+			atomicAdd(&lctr[PAMD_CTR_REJECTED0 + reject], 1u);
+	}
+	// workgroup-local counters (assembler.h:59-67,75): one LDS atomic per status per group
+	const int ctr_of[6] = { PAMD_CTR_OK, PAMD_CTR_BADR, PAMD_CTR_NOFP, PAMD_CTR_NORP, PAMD_CTR_NOALGN, PAMD_CTR_LOWQ };
+#pragma unroll
+	for (int st = 0; st < 6; st++) {
+		const int c = __popcll(__ballot(status == st));
+		if (c != 0 && lane == 0)
+			atomicAdd(&lctr[ctr_of[st]], (unsigned) c);
+	}
+	if (lane == 0)
+		atomicAdd(&lctr[PAMD_CTR_COUNT], (unsigned) npend);
+	wave_sync();
+}
+
+// the registers a wave carries from one pair to the next (software prefetch)
+struct Carry {
+	int flen_v, rlen_v;
+	uint4 f, r;
+};
+
+// ---- one pair: everything up to its parked record ----------------------------------------------
 template <int ALGO>
-__device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, const WaveLds &L, int lane, const int flen, const int rlen, const uint4 fregs, const uint4 rregs, PairOut &po
+__device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, const WaveLds &L, WaveArena &arena, PendRec *slot_rec, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt
 #ifdef PAMD_PHASE_TIMING
 	, u64 *ph_acc
 #endif
 ) {
+	const uint4 fregs = cur.f, rregs = cur.r;
 	PH_DECL;
+	bool rotated = false;
 	const int minov = P.minoverlap;
 	const unsigned hmask = P.hash_slots - 1u;
 	const unsigned hshift = P.hash_shift;
 
-	pamd_pair_result &out = po.rec;
-	out.quality = 0.0;
-	out.est_overlap_prob = 0.0;
-	out.seq_offset = ~0ull;
-	out.seq_len = 0;
-	out.overlap = 0;
-	out.examined = 0;
-	out.mismatches = 0;
-	out.degenerates = 0;
-	out.fwd_offset = 0;
-	out.rev_offset = 0;
-	out.status = PAMD_ST_OK;
-	out.reject_module = -1;
-	out.slow = 0;
-#pragma unroll
-	for (int k = 0; k < 7; k++)
-		out.reserved[k] = 0;
-
+	PendRec rec;
+	rec.pair = pair;
+	rec.off = ~0ull;
+	rec.best = 0.0;
+	rec.st = PAMD_ST_OK;
+	rec.seqlen = 0;
+	rec.A = 0;
+	rec.novl = 0;
+	rec.len = 1;
+	rec.bo = 0;
+	rec.examined = 0;
+	rec.mism = 0;
+	rec.degen = 0;
+	rec.fo = 0;
+	rec.ro = 0;
+	rec.slow = 0;
+	rec.phmin = 127;
 	int status = PAMD_ST_OK;
-	int reject = -1;
-	int seqlen = 0;
 
 	do {
 		if (flen < 2 || rlen < 2) {	// assembler.c:255-258
@@ -445,7 +584,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		} else {
 			fo = P.ftrim;
 		}
-		out.fwd_offset = (uint16_t) fo;
+		rec.fo = fo;
 		if (P.rprimer_len > 0) {
 			const int r = primer_offset(P, ltab, L.R, rlen, lprimers + 456, P.rprimer_len, lane);
 			if (r == 0) {
@@ -456,7 +595,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		} else {
 			ro = P.rtrim;
 		}
-		out.rev_offset = (uint16_t) ro;
+		rec.ro = ro;
 		if ((flen < rlen ? flen : rlen) < minov) {	// assembler.c:289-292
 			status = PAMD_ST_BADR;
 			break;
@@ -485,14 +624,12 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			const int p = base + lane;
 			bool ok = p >= 8 && p < flen;
 			if (ok) {	// no N among the 9 positions ending at p (misc.h:41)
-				const int s = p - 8;
-				const u64 win = ((u64) L.fn[(s >> 5) + 1] << 32) | (u64) L.fn[s >> 5];
-				ok = ((win >> (s & 31)) & 0x1FFull) == 0;
+				const int sn = p - 8;
+				ok = (__builtin_amdgcn_alignbit(L.fn[(sn >> 5) + 1], L.fn[sn >> 5], (unsigned) sn & 31u) & 0x1FFu) == 0;
 			}
 			if (ok) {
-				const int s = p - 7;
-				const u64 win = ((u64) L.fc[s >> 4] << 32) | (u64) L.fc[(s >> 4) + 1];
-				const unsigned kmer = (unsigned) (win >> (48 - 2 * (s & 15))) & 0xFFFFu;
+				const int sc = p - 7;
+				const unsigned kmer = __builtin_amdgcn_alignbit(L.fc[(sc >> 4) + 1], L.fc[sc >> 4], 2u * ((unsigned) sc & 15u)) & 0xFFFFu;
 				const unsigned word = (kmer << 16) | (unsigned) p;
 				unsigned slot = kmer_hash(kmer, hshift);
 				while (atomicCAS(&L.hash[slot], HASH_EMPTY, word) != HASH_EMPTY)
@@ -505,37 +642,32 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		for (int base = 0; base < rlen; base += 64) {
 			const int p = base + lane;
 			bool ok = p + 8 < rlen;	// p <= rlen - 9
-			if (ok) {	// no N among positions p .. p+8
-				const u64 win = ((u64) L.rn[(p >> 5) + 1] << 32) | (u64) L.rn[p >> 5];
-				ok = ((win >> (p & 31)) & 0x1FFull) == 0;
-			}
+			if (ok)	// no N among positions p .. p+8
+				ok = (__builtin_amdgcn_alignbit(L.rn[(p >> 5) + 1], L.rn[p >> 5], (unsigned) p & 31u) & 0x1FFu) == 0;
 			if (ok) {
-				const u64 win = ((u64) L.rc[(p >> 4) + 1] << 32) | (u64) L.rc[p >> 4];
-				const unsigned kmer = (unsigned) (win >> (2 * (p & 15))) & 0xFFFFu;
+				const unsigned x = __builtin_amdgcn_alignbit(L.rc[(p >> 4) + 1], L.rc[p >> 4], 2u * ((unsigned) p & 15u)) & 0xFFFFu;
+				const unsigned kmer = __builtin_bitreverse32(x) >> 16;
 				unsigned slot = kmer_hash(kmer, hshift);
 				unsigned m1 = 0xFFFFu, m2 = 0xFFFFu;
 				unsigned wd;
 				while ((wd = L.hash[slot]) != HASH_EMPTY) {
-					if ((wd >> 16) == kmer) {
-						const unsigned pos = wd & 0xFFFFu;
-						if (pos < m1) {
-							m2 = m1;
-							m1 = pos;
-						} else if (pos < m2) {
-							m2 = pos;
-						}
-					}
+					// keep the two smallest forward positions of this k-mer (the reference's first two)
+					const unsigned pos = (wd >> 16) == kmer ? (wd & 0xFFFFu) : 0xFFFFu;
+					const unsigned lo = pos < m1 ? pos : m1;
+					const unsigned mid = pos < m1 ? m1 : pos;
+					m1 = lo;
+					m2 = mid < m2 ? mid : m2;
 					slot = (slot + 1) & hmask;
 				}
 				if (m1 != 0xFFFFu) {
 					const int idx = flen + rlen - p - (int) m1 - minov - 1;	// assembler.c:107
 					if (idx >= 0 && idx < size)
 						atomicOr(&L.bits[idx >> 5], 1u << (idx & 31));
-				}
-				if (m2 != 0xFFFFu) {
-					const int idx = flen + rlen - p - (int) m2 - minov - 1;
-					if (idx >= 0 && idx < size)
-						atomicOr(&L.bits[idx >> 5], 1u << (idx & 31));
+					if (m2 != 0xFFFFu) {
+						const int idx2 = flen + rlen - p - (int) m2 - minov - 1;
+						if (idx2 >= 0 && idx2 < size)
+							atomicOr(&L.bits[idx2 >> 5], 1u << (idx2 & 31));
+					}
 				}
 			}
 		}
@@ -560,25 +692,26 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			const int row = lane >> 4;
 			int myov = 0;	// this row's candidate
 			int pending = 0;
-			for (int w = 0; w <= lastw + 1; w++) {
-				unsigned m = w <= lastw ? (unsigned) __builtin_amdgcn_readlane((int) mybits, w) : 0u;
-				const bool flush = w > lastw;
-				while (m != 0 || (flush && pending > 0)) {
-					if (m != 0) {
-						const int b = __builtin_ctz(m);
-						m &= m - 1;
-						const int ov = w * 32 + b + minov;
-						myov = row == pending ? ov : myov;
-						pending++;
-					}
-					if (pending == 4 || (flush && m == 0)) {
+			u64 words = __ballot(mybits != 0);	// non-empty 32-candidate words, ascending
+			while (words != 0) {
+				const int w = __builtin_ctzll(words);
+				words &= words - 1;
+				unsigned m = (unsigned) __builtin_amdgcn_readlane((int) mybits, w);
+				const bool lastword = words == 0;
+				while (m != 0) {
+					const int b = __builtin_ctz(m);
+					m &= m - 1;
+					const int ov = w * 32 + b + minov;
+					myov = row == pending ? ov : myov;
+					pending++;
+					if (pending == 4 || (lastword && m == 0)) {
 						const double sc = score_sb_planes(P, L, flen, rlen, myov, row < pending, lane);
 						for (int r = 0; r < pending; r++) {
 							const double pr = lane_f64(sc, 16 * r);
-							const int ov = __builtin_amdgcn_readlane(myov, 16 * r);
+							const int ovr = __builtin_amdgcn_readlane(myov, 16 * r);
 							if (pr > best) {	// strict: ascending scan keeps the smallest overlap on ties
 								best = pr;
-								bo = ov;
+								bo = ovr;
 							}
 						}
 						examined += pending;
@@ -602,173 +735,47 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				}
 			}
 		}
-		out.examined = (uint16_t) examined;
+		rec.examined = examined;
 		if ((u64) examined == maxov64 - (u64) minov + 1ull)	// assembler.c:135, unsigned wrap included
-			out.slow = 1;
+			rec.slow = 1;
 		if (bo < 0) {
 			status = PAMD_ST_NOALGN;
 			break;
 		}
 
 		PH_MARK(4);
-		// ---- merge (assembler.c:146-247) ----
+		// ---- merge (assembler.c:146-247), written straight to the pair's output row ----
 		const int len = flen - fo - bo + rlen - ro + 1;
 		if (len <= 0 || len > 2 * PAMD_MAX_LEN) {
 			status = PAMD_ST_NOALGN;
 			break;
 		}
-		seqlen = len - 1;
+		const int seqlen = len - 1;
 		const int df = flen - fo - bo;
 		const int dr = rlen - ro - bo;
 		const int A = df > 0 ? df : 0;		// VEEZ(df): forward-only bases
 		const int wdf = df < 0 ? df : 0;	// WEDGEZ(df)
 		const int wdr = dr < 0 ? dr : 0;
 		const int novl = bo + wdf + wdr;	// overlap bases
-		const int Bn = dr > 0 ? dr : 0;		// reverse-only bases
-		const int rbase = df + bo;		// first reverse-only index (assembler.c:232)
-		int mism = 0, degen = 0;
-		for (int j0 = 0; j0 < seqlen; j0 += 64) {
-			const int j = j0 + lane;
-			unsigned nt = 0;
-			double q = 0.0;
-			bool ismm = false;
-			const bool in = j < seqlen;
-			if (in) {
-				if (j < A) {	// assembler.c:162-173
-					const unsigned e = L.F[j + fo];
-					nt = e & 0xFFu;
-					q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
-				} else if (j < A + novl) {	// assembler.c:181-228
-					const int i = j - A;
-					const int fi = fo + A + i;
-					const int ri = rlen - i - 1 + wdf;
-					const unsigned ef = L.F[fi];
-					const unsigned er = L.R[ri];
-					const unsigned a = ef & 0xFFu, b = er & 0xFFu;
-					const int fq = qual_of(ef), rq = qual_of(er);
-					const bool match = (a & b) != 0;
-					ismm = !match;
-					const bool fmask = fi >= uf, rmask = ri >= ur;	// B-cliff
-					if (fmask && rmask) {
-						q = P.qual_nn;
-					} else if (fmask) {
-						q = ltab[PAMD_LT_SCORE + clampq(rq)];
-					} else if (rmask) {
-						q = ltab[PAMD_LT_SCORE + clampq(fq)];
-					} else if (ALGO == PAMD_ALGO_RDP_MLE) {	// algo_rdp_mle.c:29-41
-						if (match) {
-							const int mx = fq >= rq ? fq : rq;
-							q = ltab[PAMD_LT_SCORE + clampq(mx)];
-						} else {
-							q = ltab[PAMD_LT_C + clampq(fq) * PAMD_NQ + clampq(rq)];
-						}
-					} else {	// algo_simple_bayes.c:68-75, algo_pear.c:61-68
-						q = ltab[(match ? PAMD_LT_A : PAMD_LT_B) + clampq(fq) * PAMD_NQ + clampq(rq)];
-					}
-					nt = match ? (a & b) : (fq < rq ? b : a);	// assembler.c:212-220
-				} else {	// assembler.c:231-243
-					const int i = j - rbase;
-					const int ri = rlen - bo - i - 1;
-					const unsigned e = L.R[ri];
-					nt = e & 0xFFu;
-					q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
-				}
-				L.nts[j] = (uint8_t) nt;
-				L.ps[j] = q;
-			}
-			mism += __popcll(__ballot(in && ismm));
-			degen += __popcll(__ballot(in && __popc(nt) != 1));	// PANDA_NT_IS_DEGN
-		}
-		(void) Bn;
-		wave_sync();
-		PH_MARK(5);
-		// ordered sums: lane 0 forward-only, lane 1 reverse-only, lane 2 overlap
-		double acc = 0.0;
-		{
-			int lo = 0, hi = 0;
-			if (lane == 0) {
-				lo = 0;
-				hi = A;
-			} else if (lane == 1) {
-				lo = A + novl;
-				hi = seqlen;
-			} else if (lane == 2) {
-				lo = A;
-				hi = A + novl;
-			}
-			// same left-to-right order as the reference; the loads of a block are issued together so
-			// the chain pays one LDS round trip per 8 adds instead of one per add
-			int j = lo;
-			for (; j + 8 <= hi; j += 8) {
-				const double v0 = L.ps[j], v1 = L.ps[j + 1], v2 = L.ps[j + 2], v3 = L.ps[j + 3];
-				const double v4 = L.ps[j + 4], v5 = L.ps[j + 5], v6 = L.ps[j + 6], v7 = L.ps[j + 7];
-				acc += v0;
-				acc += v1;
-				acc += v2;
-				acc += v3;
-				acc += v4;
-				acc += v5;
-				acc += v6;
-				acc += v7;
-			}
-			for (; j < hi; j++)
-				acc += L.ps[j];
-		}
-		PH_MARK(6);
-		const double fquality = lane_f64(acc, 0);
-		const double rquality = lane_f64(acc, 1);
-		const double oquality = lane_f64(acc, 2);
-		const double quality = (fquality + rquality + oquality) / (double) len;	// assembler.c:244
-		out.quality = quality;
-		out.overlap = (uint16_t) bo;
-		out.est_overlap_prob = best;
-		out.mismatches = (uint16_t) mism;
-		out.degenerates = (uint16_t) degen;
-		out.seq_len = (uint16_t) seqlen;
+		const int Bn = dr > 0 ? dr : 0;		// reverse-only bases; they start at index df + bo = A + novl
+		rec.seqlen = seqlen;
+		rec.A = A;
+		rec.novl = novl;
+		rec.len = len;
+		rec.bo = bo;
+		rec.best = best;
 
-		if (quality < P.threshold) {	// assembler.c:334-338
-			status = PAMD_ST_LOWQ;
-			break;
-		}
-		// ---- check modules in order (module.c:124-136) ----
-		for (int mi = 0; mi < P.n_modules && reject < 0; mi++) {
-			const PamdModule md = P.modules[mi];
-			if (md.kind == 1) {	// plugin_min_phred.c:8-22
-				bool bad = false;
-				for (int j0 = 0; j0 < seqlen; j0 += 64) {
-					const int j = j0 + lane;
-					if (j < seqlen && result_phred(ltab + PAMD_LT_SCORE, L.ps[j]) < md.phred)
-						bad = true;
-				}
-				if (__ballot(bad) != 0)
-					reject = mi;
-			} else if (md.kind == 2) {	// plugin_min_overlapbits.c:17-23
-				if (!(md.nats <= best))
-					reject = mi;
-			}
-		}
-		if (reject >= 0) {
-			status = PAMD_ST_REJECT;
-			break;
-		}
-	} while (0);
+		// Rotate the prefetched registers in BEFORE this pair's stores are issued: vmcnt counts loads
+		// and stores in one in-order queue, so waiting for the (long finished) loads here is free,
+		// while waiting for them at the top of the next iteration would also wait for the stores.
+		cur = nxt;
+		asm volatile("" : "+v"(cur.flen_v), "+v"(cur.rlen_v), "+v"(cur.f.x), "+v"(cur.f.y), "+v"(cur.f.z), "+v"(cur.f.w), "+v"(cur.r.x), "+v"(cur.r.y), "+v"(cur.r.z), "+v"(cur.r.w));
+		rotated = true;
 
-	po.status = status;
-	po.reject = reject;
-	po.seqlen = seqlen;
-	out.status = (uint8_t) status;
-	out.reject_module = (int8_t) reject;
-	PH_MARK(7);
-}
-
-// The HBM stores of one pair: merged row (accepted pairs only), 48-byte record, workgroup counters.
-__device__ void emit_pair(const PamdKernelParams &P, unsigned *lctr, const WaveLds &L, WaveArena &arena, u64 pair, int lane, PairOut &po) {
-	pamd_pair_result &out = po.rec;
-	const int status = po.status, reject = po.reject, seqlen = po.seqlen;
-	if (status == PAMD_ST_OK) {
+		// the row: fixed stride, or the next piece of this wave's arena chunk (rows of pairs that are
+		// rejected later simply stay behind as holes)
 		const u64 need = ((u64) seqlen + 15ull) & ~15ull;
 		u64 off;
-		bool fits = true;
 		if (P.seq_stride != 0) {
 			off = pair * P.seq_stride;
 		} else {
@@ -788,53 +795,123 @@ __device__ void emit_pair(const PamdKernelParams &P, unsigned *lctr, const WaveL
 			}
 			off = arena.cur;
 			arena.cur += need;
-			fits = off + need <= P.seq_capacity;
+			if (off + need > P.seq_capacity)
+				off = ~0ull;
 		}
-		if (fits) {
-			out.seq_offset = off;
-			// 16 nt bytes per lane, 2 log-p per lane: full 16-byte stores, rows are 16-base aligned
-			if (lane * 16 < seqlen)
-				reinterpret_cast<uint4 *>(P.seq_nt + off)[lane] = reinterpret_cast<const uint4 *>(L.nts)[lane];
-			for (int j0 = 0; j0 < seqlen; j0 += 128) {
-				const int j = j0 + lane * 2;
-				if (j < seqlen)
-					reinterpret_cast<double2 *>(P.seq_p + off)[j >> 1] = reinterpret_cast<const double2 *>(L.ps)[j >> 1];
+		rec.off = off;
+		const bool store = off != ~0ull;
+		uint8_t *row_nt = P.seq_nt + (store ? off : 0);
+		double *row_p = P.seq_p + (store ? off : 0);
+		const bool want_phred = P.has_min_phred != 0;
+		// a register copy: selecting between "load from the kernel arguments" and "load from LDS"
+		// makes the compiler emit one FLAT load, whose wait also waits for every store in flight
+		double qual_nn = P.qual_nn;
+		asm volatile("" : "+v"(qual_nn));
+		int mism = 0, degen = 0, phmin = 127;
+		// forward-only bases (assembler.c:162-173)
+		for (int j0 = 0; j0 < A; j0 += 64) {
+			const int j = j0 + lane;
+			const bool in = j < A;
+			unsigned nt = 1;
+			if (in) {
+				const unsigned e = L.F[j + fo];
+				nt = e & 0xFFu;
+				const double q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
+				if (store) {
+					row_nt[j] = (uint8_t) nt;
+					row_p[j] = q;
+				}
+				if (want_phred) {
+					const int ph = result_phred(ltab + PAMD_LT_SCORE, q);
+					phmin = ph < phmin ? ph : phmin;
+				}
 			}
-		} else if (lane == 0) {
-			atomicAdd(P.error_flag, 1ull);
+			degen += __popcll(__ballot(in && __popc(nt) != 1));	// PANDA_NT_IS_DEGN
 		}
-	}
-	if (lane == 0) {
-		P.results[pair] = out;
-		// workgroup-local counters (assembler.h:59-67,75); flushed once per workgroup
-		atomicAdd(&lctr[PAMD_CTR_COUNT], 1u);
-		if (out.slow)
-			atomicAdd(&lctr[PAMD_CTR_SLOW], 1u);
-		switch (status) {
-		case PAMD_ST_OK:
-			atomicAdd(&lctr[PAMD_CTR_OK], 1u);
-			atomicAdd(&lctr[PAMD_CTR_OVERLAP0 + out.overlap], 1u);
-			break;
-		case PAMD_ST_BADR:
-			atomicAdd(&lctr[PAMD_CTR_BADR], 1u);
-			break;
-		case PAMD_ST_NOFP:
-			atomicAdd(&lctr[PAMD_CTR_NOFP], 1u);
-			break;
-		case PAMD_ST_NORP:
-			atomicAdd(&lctr[PAMD_CTR_NORP], 1u);
-			break;
-		case PAMD_ST_NOALGN:
-			atomicAdd(&lctr[PAMD_CTR_NOALGN], 1u);
-			break;
-		case PAMD_ST_LOWQ:
-			atomicAdd(&lctr[PAMD_CTR_LOWQ], 1u);
-			break;
-		default:
-			atomicAdd(&lctr[PAMD_CTR_REJECTED0 + reject], 1u);
-			break;
+		// overlapping bases (assembler.c:181-228)
+		for (int i0 = 0; i0 < novl; i0 += 64) {
+			const int i = i0 + lane;
+			const bool in = i < novl;
+			unsigned nt = 1;
+			bool ismm = false;
+			if (in) {
+				const int fi = fo + A + i;
+				const int ri = rlen - i - 1 + wdf;
+				const unsigned ef = L.F[fi];
+				const unsigned er = L.R[ri];
+				const unsigned a = ef & 0xFFu, b = er & 0xFFu;
+				const int fq = qual_of(ef), rq = qual_of(er);
+				const bool match = (a & b) != 0;
+				ismm = !match;
+				const bool fmask = fi >= uf, rmask = ri >= ur;	// B-cliff
+				double q;
+				if (fmask && rmask) {
+					q = qual_nn;
+				} else if (fmask) {
+					q = ltab[PAMD_LT_SCORE + clampq(rq)];
+				} else if (rmask) {
+					q = ltab[PAMD_LT_SCORE + clampq(fq)];
+				} else if (ALGO == PAMD_ALGO_RDP_MLE) {	// algo_rdp_mle.c:29-41
+					if (match) {
+						const int mx = fq >= rq ? fq : rq;
+						q = ltab[PAMD_LT_SCORE + clampq(mx)];
+					} else {
+						q = ltab[PAMD_LT_C + clampq(fq) * PAMD_NQ + clampq(rq)];
+					}
+				} else {	// algo_simple_bayes.c:68-75, algo_pear.c:61-68
+					q = ltab[(match ? PAMD_LT_A : PAMD_LT_B) + clampq(fq) * PAMD_NQ + clampq(rq)];
+				}
+				nt = match ? (a & b) : (fq < rq ? b : a);	// assembler.c:212-220
+				if (store) {
+					row_nt[A + i] = (uint8_t) nt;
+					row_p[A + i] = q;
+				}
+				if (want_phred) {
+					const int ph = result_phred(ltab + PAMD_LT_SCORE, q);
+					phmin = ph < phmin ? ph : phmin;
+				}
+			}
+			mism += __popcll(__ballot(in && ismm));
+			degen += __popcll(__ballot(in && __popc(nt) != 1));
 		}
+		// reverse-only bases (assembler.c:231-243)
+		for (int i0 = 0; i0 < Bn; i0 += 64) {
+			const int i = i0 + lane;
+			const bool in = i < Bn;
+			unsigned nt = 1;
+			if (in) {
+				const unsigned e = L.R[rlen - bo - i - 1];
+				nt = e & 0xFFu;
+				const double q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
+				if (store) {
+					row_nt[A + novl + i] = (uint8_t) nt;
+					row_p[A + novl + i] = q;
+				}
+				if (want_phred) {
+					const int ph = result_phred(ltab + PAMD_LT_SCORE, q);
+					phmin = ph < phmin ? ph : phmin;
+				}
+			}
+			degen += __popcll(__ballot(in && __popc(nt) != 1));
+		}
+		if (want_phred) {
+			for (int o = 32; o > 0; o >>= 1) {
+				const int other = __shfl_xor(phmin, o);
+				phmin = other < phmin ? other : phmin;
+			}
+			rec.phmin = uni(phmin);
+		}
+		rec.mism = mism;
+		rec.degen = degen;
+	} while (0);
+	if (!rotated) {
+		cur = nxt;
+		asm volatile("" : "+v"(cur.flen_v), "+v"(cur.rlen_v), "+v"(cur.f.x), "+v"(cur.f.y), "+v"(cur.f.z), "+v"(cur.f.w), "+v"(cur.r.x), "+v"(cur.r.y), "+v"(cur.r.z), "+v"(cur.r.w));
 	}
+	rec.st = status;
+	PH_MARK(7);
+	if (lane == 0)
+		*slot_rec = rec;	// park it; finish_group() does the rest
 }
 
 template <int ALGO>
@@ -870,9 +947,9 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	for (unsigned i = lane; i < 2 * PLANE_BYTES / 4; i += 64)
 		reinterpret_cast<uint32_t *>(wb + P.w_fpl)[i] = 0;	// plane pads stay zero for the whole kernel
 	L.bits = reinterpret_cast<uint32_t *>(wb + P.w_bits);
-	L.nts = reinterpret_cast<uint8_t *>(wb + P.w_nt);
 	L.ps = reinterpret_cast<double *>(wb + P.w_p);
 	L.hash = reinterpret_cast<uint32_t *>(wb + P.w_p);
+	PendRec *pend = reinterpret_cast<PendRec *>(wb + P.w_pend);
 
 	WaveArena arena;
 	arena.cur = 0;
@@ -888,39 +965,44 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	u64 pair = (u64) blockIdx.x * (u64) nwaves + (u64) wave;
 	const u64 last = P.n_pairs - 1;
 	u64 q = pair < P.n_pairs ? pair : last;
-	int flen_v = P.flen[q];
-	int rlen_v = P.rlen[q];
-	uint4 fregs = load_read(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
-	uint4 rregs = load_read(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
+	Carry cur;
+	cur.flen_v = P.flen[q];
+	cur.rlen_v = P.rlen[q];
+	cur.f = load_read(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+	cur.r = load_read(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
 	// settle the prologue loads before the loop so that, at the loop header, the carried registers
-	// are known-ready on both incoming edges (otherwise every use inside the loop gets a vmcnt wait
-	// that also waits for the previous pair's stores)
-	asm volatile("" : "+v"(flen_v), "+v"(rlen_v), "+v"(fregs.x), "+v"(fregs.y), "+v"(fregs.z), "+v"(fregs.w), "+v"(rregs.x), "+v"(rregs.y), "+v"(rregs.z), "+v"(rregs.w));
+	// are known-ready on both incoming edges
+	asm volatile("" : "+v"(cur.flen_v), "+v"(cur.rlen_v), "+v"(cur.f.x), "+v"(cur.f.y), "+v"(cur.f.z), "+v"(cur.f.w), "+v"(cur.r.x), "+v"(cur.r.y), "+v"(cur.r.z), "+v"(cur.r.w));
+	int npend = 0;
 	while (pair < P.n_pairs) {
 		const u64 next = pair + total_waves;
 		q = next < P.n_pairs ? next : last;
-		const int nflen_v = P.flen[q];
-		const int nrlen_v = P.rlen[q];
-		const uint4 nf = load_read(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
-		const uint4 nr = load_read(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
-		const int flen = uni(flen_v), rlen = uni(rlen_v);
-		PairOut po;
+		Carry nxt;
+		nxt.flen_v = P.flen[q];
+		nxt.rlen_v = P.rlen[q];
+		nxt.f = load_read(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+		nxt.r = load_read(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
+		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
 #ifdef PAMD_PHASE_TIMING
-		assemble_pair<ALGO>(P, ltab, lprimers, L, lane, flen, rlen, fregs, rregs, po, ph_acc);
+		assemble_pair<ALGO>(P, ltab, lprimers, L, arena, &pend[npend], pair, lane, flen, rlen, cur, nxt, ph_acc);
 #else
-		assemble_pair<ALGO>(P, ltab, lprimers, L, lane, flen, rlen, fregs, rregs, po);
+		assemble_pair<ALGO>(P, ltab, lprimers, L, arena, &pend[npend], pair, lane, flen, rlen, cur, nxt);
 #endif
-		// Rotate the prefetched registers in BEFORE this pair's stores are issued: vmcnt counts loads
-		// and stores in one in-order queue, so waiting for the (long finished) loads here is free,
-		// while waiting for them at the top of the next iteration would also wait for the stores.
-		flen_v = nflen_v;
-		rlen_v = nrlen_v;
-		fregs = nf;
-		rregs = nr;
-		asm volatile("" : "+v"(flen_v), "+v"(rlen_v), "+v"(fregs.x), "+v"(fregs.y), "+v"(fregs.z), "+v"(fregs.w), "+v"(rregs.x), "+v"(rregs.y), "+v"(rregs.z), "+v"(rregs.w));
-		emit_pair(P, lctr, L, arena, pair, lane, po);
+		npend++;
+		if (npend == GROUP) {
+#ifdef PAMD_PHASE_TIMING
+			const u64 t0 = __builtin_amdgcn_s_memtime();
+#endif
+			finish_group(P, ltab, lctr, pend, npend, lane);
+#ifdef PAMD_PHASE_TIMING
+			ph_acc[8] += __builtin_amdgcn_s_memtime() - t0;
+#endif
+			npend = 0;
+		}
 		pair = next;
 	}
+	if (npend > 0)
+		finish_group(P, ltab, lctr, pend, npend, lane);
 #ifdef PAMD_PHASE_TIMING
 	ph_acc[9] = __builtin_amdgcn_s_memtime() - ph_begin;
 	if (lane == 0 && P.phase_cycles != nullptr)

@@ -41,8 +41,8 @@ asm.assemble_device(b)
 torch.cuda.synchronize()
 ms = asm.last_kernel_ms()
 _lib.check(_lib.lib().pamd_debug_phase_cycles(asm._h, buf.ctypes.data, 1))
-names = ["stage", "offsets", "seed-fwd", "seed-rev", "scan", "merge", "sums", "filters+write", "-", "whole-wave"]
-tot = float(buf[:8].sum())
+names = ["stage", "offsets", "seed-fwd", "seed-rev", "scan", "merge+row stores", "-", "-", "group finish", "whole-wave"]
+tot = float(buf[:9].sum())
 print(f"config {args.config}, {n} pairs, kernel {ms:.2f} ms ({n / ms / 1e3:.1f} M pairs/s with timing overhead)")
 for k, nm in enumerate(names):
-    print(f"  {nm:14s} {buf[k] / n:10.0f} cycles/pair  {100.0 * buf[k] / tot if k < 8 else 0:5.1f}%")
+    print(f"  {nm:14s} {buf[k] / n:10.0f} cycles/pair  {100.0 * buf[k] / tot if k < 9 else 0:5.1f}%")
