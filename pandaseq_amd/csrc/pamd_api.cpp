@@ -414,7 +414,9 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.w_bits = o;
 	o += 128;
 	p.w_pend = o;
-	o += 16 * 80;	// GROUP parked records of 80 bytes
+	o += 8 * 80;	// GROUP parked records of 80 bytes
+	p.w_nt = o;
+	o += mmax;
 	p.w_p = o;
 	o += (mmax * 8u > 2048u ? mmax * 8u : 2048u);
 	p.lds_wave_bytes = up16(o);

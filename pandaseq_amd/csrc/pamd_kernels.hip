@@ -108,6 +108,7 @@ struct WaveLds {
 	uint8_t *fpl;	// forward one-hot bit planes A,C,G,T: 4 x PLANE_STRIDE bytes, bit p = base p has that bit
 	uint8_t *rpl;	// reverse one-hot bit planes (natural read order)
 	uint32_t *bits;	// candidate overlaps (BITS_INIT, assembler.c:41,84)
+	uint8_t *nts;	// merged nt staging
 	double *ps;	// merged log-p staging; the k-mer table lives here while seeding
 	uint32_t *hash;
 };
@@ -122,8 +123,30 @@ __device__ __forceinline__ uint4 load_read(const uint8_t *row, unsigned row_byte
 	return *reinterpret_cast<const uint4 *>(row + off);
 }
 
+// The one-hot bit planes of a read (only needed when many candidates must be scored, see the scan).
+__device__ __forceinline__ void build_planes(const uint16_t *src, int len, int lane, uint8_t *planes) {
+	const uint4 v = lane * 8 < len ? reinterpret_cast<const uint4 *>(src)[lane] : make_uint4(0, 0, 0, 0);
+	const unsigned w[4] = { v.x, v.y, v.z, v.w };
+	unsigned pa = 0, pc = 0, pg = 0, pt = 0;
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		const unsigned nt = (w[k >> 1] >> (16 * (k & 1))) & 0xFFu;
+		pa |= (nt & 1u) << k;
+		pc |= ((nt >> 1) & 1u) << k;
+		pg |= ((nt >> 2) & 1u) << k;
+		pt |= ((nt >> 3) & 1u) << k;
+	}
+	int cnt = len - lane * 8;
+	cnt = cnt < 0 ? 0 : (cnt > 8 ? 8 : cnt);
+	const unsigned inmask = (1u << cnt) - 1u;
+	planes[4 + lane] = (uint8_t) (pa & inmask);
+	planes[4 + PLANE_STRIDE + lane] = (uint8_t) (pc & inmask);
+	planes[4 + 2 * PLANE_STRIDE + lane] = (uint8_t) (pg & inmask);
+	planes[4 + 3 * PLANE_STRIDE + lane] = (uint8_t) (pt & inmask);
+}
+
 template <bool FORWARD>
-__device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint16_t *dst, uint32_t *codes, uint32_t *nmap, uint8_t *planes) {
+__device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint16_t *dst, uint32_t *codes, uint32_t *nmap) {
 	if (lane * 8 < len)
 		reinterpret_cast<uint4 *>(dst)[lane] = v;
 	const unsigned w[4] = { v.x, v.y, v.z, v.w };
@@ -133,30 +156,21 @@ __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint
 	//              (the reverse read stores C=2 G=1, see below)
 	//   N          = (nt + 1) >> 4
 	//   qual == 2  = bit 8 of ((qual ^ 2) - 1) taken as an unsigned byte
-	//   one-hot planes: bit b of nt, gathered over the lane's 8 bases into one byte per plane
-	unsigned code16 = 0, is2 = 0, pa = 0, pc = 0, pg = 0, pt = 0;
+	unsigned code16 = 0, is2 = 0, nbits = 0;
 #pragma unroll
 	for (int k = 0; k < 8; k++) {
 		const unsigned e = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
 		const unsigned nt = e & 0xFFu;
 		const unsigned c = ((FORWARD ? 0x00030210u : 0x00030120u) >> ((nt & 15u) * 2u)) & 3u;
 		code16 |= c << (2 * k);
-		pa |= (nt & 1u) << k;
-		pc |= ((nt >> 1) & 1u) << k;
-		pg |= ((nt >> 2) & 1u) << k;
-		pt |= ((nt >> 3) & 1u) << k;
+		nbits |= (((nt + 1u) >> 4) & 1u) << k;
 		is2 |= (((((e >> 8) ^ 2u) & 0xFFu) - 1u) >> 8 & 1u) << k;
 	}
-	unsigned nbits = pa & pc & pg & pt;	// nt == 15
 	// bases at or beyond the read length contribute nothing
 	int cnt = len - lane * 8;
 	cnt = cnt < 0 ? 0 : (cnt > 8 ? 8 : cnt);
 	const unsigned inmask = (1u << cnt) - 1u;	// bit k set <=> base k of this lane exists
 	nbits &= inmask;
-	planes[4 + lane] = (uint8_t) (pa & inmask);
-	planes[4 + PLANE_STRIDE + lane] = (uint8_t) (pc & inmask);
-	planes[4 + 2 * PLANE_STRIDE + lane] = (uint8_t) (pg & inmask);
-	planes[4 + 3 * PLANE_STRIDE + lane] = (uint8_t) (pt & inmask);
 	const unsigned not2 = ~is2 & inmask;
 	code16 &= (1u << (2 * cnt)) - 1u;
 	// 16 codes per u32, base b at bits 2b..2b+1 of the stream.  A forward k-mer is the 16 bits
@@ -388,7 +402,10 @@ struct WaveArena {
 // reading the log-probabilities back from the pair's output row (just written, L2/MALL resident),
 // so 48 lanes advance 48 chains with the same instructions.  Then lane `slot` finishes pair `slot`:
 // quality, LOWQ, check modules, the 48-byte record and the counters.
-constexpr int GROUP = 16;
+constexpr int GROUP = 8;
+#ifndef FINISH_DEPTH
+#define FINISH_DEPTH 8
+#endif
 
 struct PendRec {	// 80 bytes
 	u64 pair;
@@ -434,20 +451,32 @@ __device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsi
 			}
 		}
 		int k = 0;
-		for (; k + 8 <= cnt; k += 8) {	// same left-to-right order as the reference, 8 loads in flight
-			const double v0 = load_p_l2(row + k), v1 = load_p_l2(row + k + 1), v2 = load_p_l2(row + k + 2), v3 = load_p_l2(row + k + 3);
-			const double v4 = load_p_l2(row + k + 4), v5 = load_p_l2(row + k + 5), v6 = load_p_l2(row + k + 6), v7 = load_p_l2(row + k + 7);
-			acc += v0;
-			acc += v1;
-			acc += v2;
-			acc += v3;
-			acc += v4;
-			acc += v5;
-			acc += v6;
-			acc += v7;
+		// Same left-to-right order as the reference.  The loads do not depend on the adds, so a deep
+		// batch is issued first: the rows come back from L2/HBM (microseconds), and only the number
+		// of loads in flight hides that.
+		for (; k + FINISH_DEPTH <= cnt; k += FINISH_DEPTH) {
+			double v[FINISH_DEPTH];
+#pragma unroll
+			for (int t = 0; t < FINISH_DEPTH; t++)
+				v[t] = load_p_l2(row + k + t);
+#pragma unroll
+			for (int t = 0; t < FINISH_DEPTH; t++)
+				acc += v[t];
 		}
-		for (; k < cnt; k++)
-			acc += load_p_l2(row + k);
+		if (k < cnt) {
+			// the last, partial batch: same depth (a one-at-a-time tail would pay one memory round
+			// trip per add); slots past the end re-read the last element and are added as +0.0,
+			// which leaves a sum that is negative or +0.0 unchanged
+			double v[FINISH_DEPTH];
+#pragma unroll
+			for (int t = 0; t < FINISH_DEPTH; t++) {
+				const int kk = k + t < cnt ? k + t : cnt - 1;
+				v[t] = load_p_l2(row + kk);
+			}
+#pragma unroll
+			for (int t = 0; t < FINISH_DEPTH; t++)
+				acc += (k + t < cnt) ? v[t] : 0.0;
+		}
 	}
 	// ---- one lane per pair ----
 	const int src = lane < GROUP ? 3 * lane : 0;
@@ -562,8 +591,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		}
 		// previous pair's readers are done with this wave's LDS
 		wave_sync();
-		const int uf = stage_read<true>(fregs, flen, lane, L.F, L.fc, L.fn, L.fpl);
-		const int ur = stage_read<false>(rregs, rlen, lane, L.R, L.rc, L.rn, L.rpl);
+		const int uf = stage_read<true>(fregs, flen, lane, L.F, L.fc, L.fn);
+		const int ur = stage_read<false>(rregs, rlen, lane, L.R, L.rc, L.rn);
 		// clear the k-mer table (aliases the log-p staging area) and the candidate bitmap
 		for (unsigned s4 = lane; s4 < P.hash_slots / 4; s4 += 64)
 			reinterpret_cast<uint4 *>(L.hash)[s4] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
@@ -622,14 +651,13 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		// smallest positions of its k-mer, which is the same set.
 		for (int base = 0; base < flen; base += 64) {
 			const int p = base + lane;
-			bool ok = p >= 8 && p < flen;
-			if (ok) {	// no N among the 9 positions ending at p (misc.h:41)
-				const int sn = p - 8;
-				ok = (__builtin_amdgcn_alignbit(L.fn[(sn >> 5) + 1], L.fn[sn >> 5], (unsigned) sn & 31u) & 0x1FFu) == 0;
-			}
-			if (ok) {
-				const int sc = p - 7;
-				const unsigned kmer = __builtin_amdgcn_alignbit(L.fc[(sc >> 4) + 1], L.fc[sc >> 4], 2u * ((unsigned) sc & 15u)) & 0xFFFFu;
+			const bool inr = p >= 8 && p < flen;
+			// both windows are read unconditionally (clamped) so the two LDS round trips overlap
+			const int sn = inr ? p - 8 : 0;	// no N among the 9 positions ending at p (misc.h:41)
+			const int sc = inr ? p - 7 : 0;
+			const unsigned nwin = __builtin_amdgcn_alignbit(L.fn[(sn >> 5) + 1], L.fn[sn >> 5], (unsigned) sn & 31u) & 0x1FFu;
+			const unsigned kmer = __builtin_amdgcn_alignbit(L.fc[(sc >> 4) + 1], L.fc[sc >> 4], 2u * ((unsigned) sc & 15u)) & 0xFFFFu;
+			if (inr && nwin == 0) {
 				const unsigned word = (kmer << 16) | (unsigned) p;
 				unsigned slot = kmer_hash(kmer, hshift);
 				while (atomicCAS(&L.hash[slot], HASH_EMPTY, word) != HASH_EMPTY)
@@ -641,11 +669,11 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		// ---- seed: reverse k-mers flag candidate overlaps (assembler.c:104-110) ----
 		for (int base = 0; base < rlen; base += 64) {
 			const int p = base + lane;
-			bool ok = p + 8 < rlen;	// p <= rlen - 9
-			if (ok)	// no N among positions p .. p+8
-				ok = (__builtin_amdgcn_alignbit(L.rn[(p >> 5) + 1], L.rn[p >> 5], (unsigned) p & 31u) & 0x1FFu) == 0;
-			if (ok) {
-				const unsigned x = __builtin_amdgcn_alignbit(L.rc[(p >> 4) + 1], L.rc[p >> 4], 2u * ((unsigned) p & 15u)) & 0xFFFFu;
+			const bool inr = p + 8 < rlen;	// p <= rlen - 9
+			const int sp = inr ? p : 0;	// no N among positions p .. p+8
+			const unsigned nwin = __builtin_amdgcn_alignbit(L.rn[(sp >> 5) + 1], L.rn[sp >> 5], (unsigned) sp & 31u) & 0x1FFu;
+			const unsigned x = __builtin_amdgcn_alignbit(L.rc[(sp >> 4) + 1], L.rc[sp >> 4], 2u * ((unsigned) sp & 15u)) & 0xFFFFu;
+			if (inr && nwin == 0) {
 				const unsigned kmer = __builtin_bitreverse32(x) >> 16;
 				unsigned slot = kmer_hash(kmer, hshift);
 				unsigned m1 = 0xFFFFu, m2 = 0xFFFFu;
@@ -687,8 +715,21 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		double best = P.qual_nn * (double) (flen + rlen);	// assembler.c:60
 		int bo = -1;
 		int examined = 0;
+		int ncand = 0;
 		if (ALGO == PAMD_ALGO_SIMPLE_BAYES) {
-			// four candidates per step, one per 16-lane row, still judged in ascending overlap order
+			u64 nz = __ballot(mybits != 0);
+			while (nz != 0 && ncand <= 4) {	// only "more than four?" matters
+				const int w = __builtin_ctzll(nz);
+				nz &= nz - 1;
+				ncand += __popc((unsigned) __builtin_amdgcn_readlane((int) mybits, w));
+			}
+		}
+		if (ALGO == PAMD_ALGO_SIMPLE_BAYES && ncand > 4) {
+			// Many candidates (tandem repeats, or no seed at all): score them four per step from
+			// one-hot bit planes, one candidate per 16-lane row, still judged in ascending order.
+			build_planes(L.F, flen, lane, L.fpl);
+			build_planes(L.R, rlen, lane, L.rpl);
+			wave_sync();
 			const int row = lane >> 4;
 			int myov = 0;	// this row's candidate
 			int pending = 0;
@@ -720,7 +761,10 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				}
 			}
 		} else {
-			for (int w = 0; w <= lastw; w++) {
+			u64 words = __ballot(mybits != 0);	// non-empty 32-candidate words, ascending
+			while (words != 0) {
+				const int w = __builtin_ctzll(words);
+				words &= words - 1;
 				unsigned m = (unsigned) __builtin_amdgcn_readlane((int) mybits, w);
 				while (m) {
 					const int b = __builtin_ctz(m);
@@ -817,10 +861,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const unsigned e = L.F[j + fo];
 				nt = e & 0xFFu;
 				const double q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
-				if (store) {
-					row_nt[j] = (uint8_t) nt;
-					row_p[j] = q;
-				}
+				L.nts[j] = (uint8_t) nt;
+				L.ps[j] = q;
 				if (want_phred) {
 					const int ph = result_phred(ltab + PAMD_LT_SCORE, q);
 					phmin = ph < phmin ? ph : phmin;
@@ -862,10 +904,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 					q = ltab[(match ? PAMD_LT_A : PAMD_LT_B) + clampq(fq) * PAMD_NQ + clampq(rq)];
 				}
 				nt = match ? (a & b) : (fq < rq ? b : a);	// assembler.c:212-220
-				if (store) {
-					row_nt[A + i] = (uint8_t) nt;
-					row_p[A + i] = q;
-				}
+				L.nts[A + i] = (uint8_t) nt;
+				L.ps[A + i] = q;
 				if (want_phred) {
 					const int ph = result_phred(ltab + PAMD_LT_SCORE, q);
 					phmin = ph < phmin ? ph : phmin;
@@ -883,16 +923,25 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const unsigned e = L.R[rlen - bo - i - 1];
 				nt = e & 0xFFu;
 				const double q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
-				if (store) {
-					row_nt[A + novl + i] = (uint8_t) nt;
-					row_p[A + novl + i] = q;
-				}
+				L.nts[A + novl + i] = (uint8_t) nt;
+				L.ps[A + novl + i] = q;
 				if (want_phred) {
 					const int ph = result_phred(ltab + PAMD_LT_SCORE, q);
 					phmin = ph < phmin ? ph : phmin;
 				}
 			}
 			degen += __popcll(__ballot(in && __popc(nt) != 1));
+		}
+		// the row leaves LDS in full 16-byte stores (16 nt or 2 log-p per lane); rows are 16-base aligned
+		wave_sync();
+		if (store) {
+			if (lane * 16 < seqlen)
+				reinterpret_cast<uint4 *>(row_nt)[lane] = reinterpret_cast<const uint4 *>(L.nts)[lane];
+			for (int j0 = 0; j0 < seqlen; j0 += 128) {
+				const int j = j0 + lane * 2;
+				if (j < seqlen)
+					reinterpret_cast<double2 *>(row_p)[j >> 1] = reinterpret_cast<const double2 *>(L.ps)[j >> 1];
+			}
 		}
 		if (want_phred) {
 			for (int o = 32; o > 0; o >>= 1) {
@@ -947,6 +996,7 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	for (unsigned i = lane; i < 2 * PLANE_BYTES / 4; i += 64)
 		reinterpret_cast<uint32_t *>(wb + P.w_fpl)[i] = 0;	// plane pads stay zero for the whole kernel
 	L.bits = reinterpret_cast<uint32_t *>(wb + P.w_bits);
+	L.nts = wb + P.w_nt;
 	L.ps = reinterpret_cast<double *>(wb + P.w_p);
 	L.hash = reinterpret_cast<uint32_t *>(wb + P.w_p);
 	PendRec *pend = reinterpret_cast<PendRec *>(wb + P.w_pend);
