@@ -404,7 +404,7 @@ struct WaveArena {
 // quality, LOWQ, check modules, the 48-byte record and the counters.
 constexpr int GROUP = 8;
 #ifndef FINISH_DEPTH
-#define FINISH_DEPTH 8
+#define FINISH_DEPTH 6	/* 16-byte loads in flight per chain */
 #endif
 
 struct PendRec {	// 80 bytes
@@ -420,16 +420,6 @@ struct PendRec {	// 80 bytes
 
 static_assert(sizeof(PendRec) == 80, "PendRec is sized by pamd_api.cpp");
 
-__device__ __forceinline__ double load_p_l2(const double *p) {
-	// bypass this CU's vector L1: the row was written by this wave moments ago (write-through to L2)
-	union {
-		unsigned long long u;
-		double d;
-	} x;
-	x.u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	return x.d;
-}
-
 __device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsigned *lctr, const PendRec *pend, int npend, int lane) {
 	// all of this wave's row stores must have reached L2 before they are read back
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -438,44 +428,52 @@ __device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsi
 	const int slot = lane / 3, chain = lane - 3 * slot;
 	double acc = 0.0;
 	{
-		int lo = 0, cnt = 0;
-		const double *row = P.seq_p;
+		// chain 0: forward-only [0,A)   chain 1: reverse-only [A+novl, seqlen)   chain 2: overlap [A, A+novl)
+		// Plain cached loads are correct here: the rows were written by this very wave, the wait above
+		// retired those stores, and a CU's vector L1 is coherent for its own stores.  Two values per
+		// load: one memory request serves two adds, and the eight loads of a 128-byte line hit in L1.
+		int j = 0, end = 0;
+		const double *rowp = P.seq_p;
 		if (slot < npend) {
 			const PendRec &r = pend[slot];
 			if (r.st == PAMD_ST_OK && r.off != ~0ull) {
-				// chain 0: forward-only [0,A)   chain 1: reverse-only [A+novl, seqlen)   chain 2: overlap [A, A+novl)
-				lo = chain == 0 ? 0 : (chain == 1 ? r.A + r.novl : r.A);
-				const int hi = chain == 0 ? r.A : (chain == 1 ? r.seqlen : r.A + r.novl);
-				cnt = hi - lo;
-				row = P.seq_p + r.off + lo;
+				j = chain == 0 ? 0 : (chain == 1 ? r.A + r.novl : r.A);
+				end = chain == 0 ? r.A : (chain == 1 ? r.seqlen : r.A + r.novl);
+				rowp = P.seq_p + r.off;	// 128-byte aligned
 			}
 		}
-		int k = 0;
-		// Same left-to-right order as the reference.  The loads do not depend on the adds, so a deep
-		// batch is issued first: the rows come back from L2/HBM (microseconds), and only the number
-		// of loads in flight hides that.
-		for (; k + FINISH_DEPTH <= cnt; k += FINISH_DEPTH) {
-			double v[FINISH_DEPTH];
-#pragma unroll
-			for (int t = 0; t < FINISH_DEPTH; t++)
-				v[t] = load_p_l2(row + k + t);
-#pragma unroll
-			for (int t = 0; t < FINISH_DEPTH; t++)
-				acc += v[t];
+		if (j < end && (j & 1)) {	// reach an even index
+			acc += rowp[j];
+			j++;
 		}
-		if (k < cnt) {
-			// the last, partial batch: same depth (a one-at-a-time tail would pay one memory round
-			// trip per add); slots past the end re-read the last element and are added as +0.0,
-			// which leaves a sum that is negative or +0.0 unchanged
-			double v[FINISH_DEPTH];
+		// same left-to-right order as the reference
+		for (; j + 2 * FINISH_DEPTH <= end; j += 2 * FINISH_DEPTH) {
+			double2 v[FINISH_DEPTH];
+#pragma unroll
+			for (int t = 0; t < FINISH_DEPTH; t++)
+				v[t] = *reinterpret_cast<const double2 *>(rowp + j + 2 * t);
 #pragma unroll
 			for (int t = 0; t < FINISH_DEPTH; t++) {
-				const int kk = k + t < cnt ? k + t : cnt - 1;
-				v[t] = load_p_l2(row + kk);
+				acc += v[t].x;
+				acc += v[t].y;
+			}
+		}
+		if (j < end) {
+			// the last, partial batch at the same depth (a one-at-a-time tail would pay one memory
+			// round trip per add); slots past the end re-read the last pair and are added as +0.0,
+			// which leaves a sum that is negative or +0.0 unchanged
+			const int lastpair = (end - 1) & ~1;
+			double2 v[FINISH_DEPTH];
+#pragma unroll
+			for (int t = 0; t < FINISH_DEPTH; t++) {
+				const int jj = j + 2 * t < end ? j + 2 * t : lastpair;
+				v[t] = *reinterpret_cast<const double2 *>(rowp + jj);
 			}
 #pragma unroll
-			for (int t = 0; t < FINISH_DEPTH; t++)
-				acc += (k + t < cnt) ? v[t] : 0.0;
+			for (int t = 0; t < FINISH_DEPTH; t++) {
+				acc += (j + 2 * t < end) ? v[t].x : 0.0;
+				acc += (j + 2 * t + 1 < end) ? v[t].y : 0.0;
+			}
 		}
 	}
 	// ---- one lane per pair ----
