@@ -297,18 +297,19 @@ __device__ __forceinline__ double score_overlap(const PamdKernelParams &P, const
 	if (ALGO == PAMD_ALGO_SIMPLE_BAYES) {
 		// algo_simple_bayes.c:33-66: three integer counts, then a closed form
 		int unknowns = 0, matches = 0, mismatches = 0;
-		for (int i0 = 0; i0 < ov; i0 += 64) {
-			const int i = i0 + lane;
-			const int fi = flen + i - ov;
-			const int ri = rlen - i - 1;
-			const bool in = i < ov && fi >= 0 && ri >= 0;
-			const unsigned a = in ? (L.F[fi] & 0xFFu) : 0u;
-			const unsigned b = in ? (L.R[ri] & 0xFFu) : 0u;
-			const bool isn = a == NT_N || b == NT_N;
-			const bool m = (a & b) != 0;
-			unknowns += __popcll(__ballot(in && isn));
-			matches += __popcll(__ballot(in && !isn && m));
-			mismatches += __popcll(__ballot(in && !isn && !m));
+		for (int i0 = 0; i0 < ov; i0 += 128) {	// two overlap positions per lane: four LDS reads in flight
+			const int ia = i0 + lane, ib = i0 + 64 + lane;
+			const int fa = flen + ia - ov, ra = rlen - ia - 1;
+			const int fb = flen + ib - ov, rb = rlen - ib - 1;
+			const bool ina = ia < ov && fa >= 0 && ra >= 0;
+			const bool inb = ib < ov && fb >= 0 && rb >= 0;
+			const unsigned a0 = L.F[ina ? fa : 0] & 0xFFu, b0 = L.R[ina ? ra : 0] & 0xFFu;
+			const unsigned a1 = L.F[inb ? fb : 0] & 0xFFu, b1 = L.R[inb ? rb : 0] & 0xFFu;
+			const bool n0 = a0 == NT_N || b0 == NT_N, n1 = a1 == NT_N || b1 == NT_N;
+			const bool m0 = (a0 & b0) != 0, m1 = (a1 & b1) != 0;
+			unknowns += __popcll(__ballot(ina && n0)) + __popcll(__ballot(inb && n1));
+			matches += __popcll(__ballot(ina && !n0 && m0)) + __popcll(__ballot(inb && !n1 && m1));
+			mismatches += __popcll(__ballot(ina && !n0 && !m0)) + __popcll(__ballot(inb && !n1 && !m1));
 		}
 		// size_t arithmetic inside the parenthesis (algo_simple_bayes.c:61-65), wrap included
 		const u64 free_bases = (ov >= flen && ov >= rlen) ? (u64) unknowns : (u64) flen + (u64) rlen - 2ull * (u64) ov + (u64) unknowns;
@@ -675,15 +676,26 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const unsigned kmer = __builtin_bitreverse32(x) >> 16;
 				unsigned slot = kmer_hash(kmer, hshift);
 				unsigned m1 = 0xFFFFu, m2 = 0xFFFFu;
-				unsigned wd;
-				while ((wd = L.hash[slot]) != HASH_EMPTY) {
-					// keep the two smallest forward positions of this k-mer (the reference's first two)
-					const unsigned pos = (wd >> 16) == kmer ? (wd & 0xFFFFu) : 0xFFFFu;
-					const unsigned lo = pos < m1 ? pos : m1;
-					const unsigned mid = pos < m1 ? m1 : pos;
+				// walk the probe chain two slots per step (both reads are issued together); keep the two
+				// smallest forward positions of this k-mer, which are the reference's first two
+				bool more = true;
+				while (more) {
+					const unsigned w0 = L.hash[slot];
+					const unsigned w1 = L.hash[(slot + 1) & hmask];
+					const bool live0 = w0 != HASH_EMPTY;
+					const bool live1 = live0 && w1 != HASH_EMPTY;
+					const unsigned pos0 = (live0 && (w0 >> 16) == kmer) ? (w0 & 0xFFFFu) : 0xFFFFu;
+					const unsigned pos1 = (live1 && (w1 >> 16) == kmer) ? (w1 & 0xFFFFu) : 0xFFFFu;
+					unsigned lo = pos0 < m1 ? pos0 : m1;
+					unsigned mid = pos0 < m1 ? m1 : pos0;
 					m1 = lo;
 					m2 = mid < m2 ? mid : m2;
-					slot = (slot + 1) & hmask;
+					lo = pos1 < m1 ? pos1 : m1;
+					mid = pos1 < m1 ? m1 : pos1;
+					m1 = lo;
+					m2 = mid < m2 ? mid : m2;
+					slot = (slot + 2) & hmask;
+					more = live1;
 				}
 				if (m1 != 0xFFFFu) {
 					const int idx = flen + rlen - p - (int) m1 - minov - 1;	// assembler.c:107
