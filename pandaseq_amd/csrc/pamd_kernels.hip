@@ -370,6 +370,36 @@ __device__ __forceinline__ double score_overlap(const PamdKernelParams &P, const
 	}
 }
 
+// ---- pear / rdp_mle with many candidates: one candidate per lane ---------------------------------
+// Each lane walks ITS candidate's overlap in index order and adds the terms as the reference does
+// (algo_pear.c:42-56, algo_rdp_mle.c:55-72), so 64 ordered sums advance together instead of one.
+template <int ALGO>
+__device__ __forceinline__ double score_overlap_serial(const PamdKernelParams &P, const double *ltab, const WaveLds &L, int flen, int rlen, int ov, double neg_random_base, double qual_nn) {
+	double acc = 0.0;
+	for (int i = 0; i < ov; i++) {
+		const int fi = flen + i - ov;
+		const int ri = rlen - i - 1;
+		if (fi >= 0 && ri >= 0) {
+			const unsigned ef = L.F[fi];
+			const unsigned er = L.R[ri];
+			const unsigned a = ef & 0xFFu, b = er & 0xFFu;
+			const int qa = clampq(qual_of(ef));
+			if (ALGO == PAMD_ALGO_PEAR) {
+				if (a == NT_N || b == NT_N) {
+					acc += neg_random_base;
+				} else {
+					const int qb = ri < flen ? clampq(qual_of(L.F[ri])) : 0;	// sic: forward quality at rindex
+					acc += ltab[((a & b) != 0 ? PAMD_LT_A : PAMD_LT_B) + qa * PAMD_NQ + qb];
+				}
+			} else {
+				const int qb = clampq(qual_of(er));
+				acc += ltab[((a & b) != 0 ? PAMD_LT_A : PAMD_LT_B) + qa * PAMD_NQ + qb] - qual_nn;
+			}
+		}
+	}
+	return acc;
+}
+
 // panda_result_phred (nt.c:126-150) on the staged score table
 __device__ __forceinline__ int result_phred(const double *score, double p) {
 	int lower = 0, upper = 46;
@@ -726,7 +756,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		int bo = -1;
 		int examined = 0;
 		int ncand = 0;
-		if (ALGO == PAMD_ALGO_SIMPLE_BAYES) {
+		{
 			u64 nz = __ballot(mybits != 0);
 			while (nz != 0 && ncand <= 4) {	// only "more than four?" matters
 				const int w = __builtin_ctzll(nz);
@@ -770,6 +800,48 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 					}
 				}
 			}
+		} else if (ALGO != PAMD_ALGO_SIMPLE_BAYES && ncand > 4) {
+			// Many candidates: list them in ascending order (u16 overlaps in the staging area), then
+			// 64 at a time, one per lane, each lane summing its own candidate in reference order.
+			uint16_t *cand = reinterpret_cast<uint16_t *>(L.ps);
+			int total = 0;
+			u64 words = __ballot(mybits != 0);
+			while (words != 0) {
+				const int w = __builtin_ctzll(words);
+				words &= words - 1;
+				const unsigned m = (unsigned) __builtin_amdgcn_readlane((int) mybits, w);
+				if (lane < 32 && ((m >> lane) & 1u))
+					cand[total + __popc(m & ((1u << lane) - 1u))] = (uint16_t) (w * 32 + lane + minov);
+				total += __popc(m);
+			}
+			wave_sync();
+			double nrb = -P.pear_random_base, nn = P.qual_nn;
+			asm volatile("" : "+v"(nrb), "+v"(nn));	// register copies: keep the table reads pure LDS loads
+			for (int c0 = 0; c0 < total; c0 += 64) {
+				const bool have = c0 + lane < total;
+				const int ov = have ? (int) cand[c0 + lane] : 0;
+				double pr = score_overlap_serial<ALGO>(P, ltab, L, flen, rlen, ov, nrb, nn);
+				// first maximum of this batch: larger score wins, equal scores -> smaller overlap
+				int bov = have ? ov : 0x7FFFFFFF;
+				if (!have)
+					pr = -__builtin_inf();
+				for (int o = 32; o > 0; o >>= 1) {
+					const double opr = __shfl_xor(pr, o);
+					const int oov = __shfl_xor(bov, o);
+					if (opr > pr || (opr == pr && oov < bov)) {
+						pr = opr;
+						bov = oov;
+					}
+				}
+				pr = uni_f64(pr);
+				bov = uni(bov);
+				if (pr > best) {	// batches are in ascending overlap order, strict > keeps the earlier one
+					best = pr;
+					bo = bov;
+				}
+			}
+			examined = total;
+			wave_sync();
 		} else {
 			u64 words = __ballot(mybits != 0);	// non-empty 32-candidate words, ascending
 			while (words != 0) {
