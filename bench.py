@@ -174,6 +174,19 @@ def main():
     algo_bytes = 2 * lens + 9 * merged_bases + 64 * n
     achieved = algo_bytes / avg_kernel_s / 1e9
 
+    # HBM bytes per launch from the PMC passes (tools/traffic_probe.py -> profiles/r01_traffic_config*.json):
+    # FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, units calibrated on a 1 GiB copy in the same
+    # process (gfx950: FETCH_SIZE counts 2 KiB per unit for wide reads).  Measured per pair on the same
+    # workload; scaled to this launch's pair count.
+    traffic = args.traffic_bytes
+    traffic_src = "--traffic-bytes" if traffic is not None else None
+    tpath = os.path.join(ROOT, "profiles", f"r01_traffic_config{cfg_index}.json")
+    if traffic is None and os.path.exists(tpath):
+        with open(tpath) as fh:
+            tj = json.load(fh)
+        traffic = tj["hbm_bytes_per_pair"] * n
+        traffic_src = f"profiles/r01_traffic_config{cfg_index}.json ({tj['pairs']} pairs per launch)"
+
     value = n * world * args.steps / elapsed
     out = {
         "metric": "merged read-pairs/sec",
@@ -206,7 +219,8 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": args.traffic_bytes,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": algo_bytes,
             "bytes_per_pair": algo_bytes / n,
             "kernel_ms_avg": avg_kernel_s * 1e3,

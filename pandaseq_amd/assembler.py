@@ -191,7 +191,7 @@ class Assembler:
         check(lib().pamd_last_launch_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"workgroups": a.value, "waves_per_workgroup": b.value, "lds_bytes": c.value}
 
-    def assemble_host(self, fwd, rev, flen, rlen, seq_stride=None):
+    def assemble_host(self, fwd, rev, flen, rlen, seq_stride=None, capacity=None):
         """numpy in, numpy out, through pamd_assemble_host (upload, kernel, download)."""
         fwd = np.ascontiguousarray(fwd, dtype=np.uint8)
         rev = np.ascontiguousarray(rev, dtype=np.uint8)
@@ -200,7 +200,7 @@ class Assembler:
         n = fwd.shape[0]
         if seq_stride is None:
             seq_stride = ((min(900, fwd.shape[1] + rev.shape[1]) + 15) // 16) * 16
-        cap = n * seq_stride if seq_stride else n * 912 + 16384 * 4096
+        cap = n * seq_stride if seq_stride else (capacity or n * 912 + 16384 * 4096)
         res = np.zeros(n, dtype=RESULT_DTYPE)
         seq_nt = np.zeros(cap, dtype=np.uint8)
         seq_p = np.zeros(cap, dtype=np.float64)

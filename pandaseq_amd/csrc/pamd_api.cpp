@@ -551,8 +551,15 @@ int pamd_assemble_host(pamd_assembler *a, const pamd_batch *hb) {
 	unsigned long long overflow = 0;
 	HIP_TRY2(hipMemcpy(&overflow, a->d_error, 8, hipMemcpyDeviceToHost));
 	HIP_TRY2(hipMemcpy(hb->results, dres, n * sizeof(pamd_pair_result), hipMemcpyDeviceToHost));
-	HIP_TRY2(hipMemcpy(hb->seq_nt, dnt, cap, hipMemcpyDeviceToHost));
-	HIP_TRY2(hipMemcpy(hb->seq_p, dp, cap * sizeof(double), hipMemcpyDeviceToHost));
+	// compact arena: only the part the launch used comes back
+	size_t used = cap;
+	if (hb->seq_stride == 0) {
+		unsigned long long cur = 0;
+		HIP_TRY2(hipMemcpy(&cur, dcur, 8, hipMemcpyDeviceToHost));
+		used = cur < cap ? (size_t) cur : cap;
+	}
+	HIP_TRY2(hipMemcpy(hb->seq_nt, dnt, used, hipMemcpyDeviceToHost));
+	HIP_TRY2(hipMemcpy(hb->seq_p, dp, used * sizeof(double), hipMemcpyDeviceToHost));
 	if (hb->seq_cursor)
 		HIP_TRY2(hipMemcpy(hb->seq_cursor, dcur, 8, hipMemcpyDeviceToHost));
 	if (hb->counters) {

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""usage: summarize_traffic.py <fetch_results.db> <write_results.db> <pairs>
+Prints calibrated HBM bytes of the last assemble dispatch (see tools/traffic_probe.py)."""
+import json
+import sqlite3
+import sys
+
+GIB = float(1 << 30)
+
+
+def per_kernel(db, counter):
+    con = sqlite3.connect(db)
+    rows = list(con.execute("select kernel_name, value, start from counters_collection where counter_name = ? order by start", (counter,)))
+    asm = [v for k, v, _ in rows if "pamd_assemble_kernel" in k]
+    # the calibration copy is the 1 GiB device-to-device copy: by far the largest copy dispatch
+    cp = [v for k, v, _ in rows if "copybuffer" in k.lower()]
+    return asm[-1], max(cp)
+
+
+fetch_db, write_db, pairs = sys.argv[1], sys.argv[2], int(sys.argv[3])
+a_rd, c_rd = per_kernel(fetch_db, "FETCH_SIZE")
+a_wr, c_wr = per_kernel(write_db, "WRITE_SIZE")
+rd_unit = GIB / c_rd   # bytes per FETCH_SIZE count, from the 1 GiB copy
+wr_unit = GIB / c_wr
+out = {
+    "pairs": pairs,
+    "raw": {"FETCH_SIZE_assemble": a_rd, "FETCH_SIZE_copy_1GiB": c_rd, "WRITE_SIZE_assemble": a_wr, "WRITE_SIZE_copy_1GiB": c_wr},
+    "bytes_per_count": {"FETCH_SIZE": rd_unit, "WRITE_SIZE": wr_unit},
+    "hbm_read_bytes": a_rd * rd_unit,
+    "hbm_write_bytes": a_wr * wr_unit,
+}
+out["hbm_bytes_per_launch"] = out["hbm_read_bytes"] + out["hbm_write_bytes"]
+out["hbm_bytes_per_pair"] = out["hbm_bytes_per_launch"] / pairs
+print(json.dumps(out, indent=1))
