@@ -84,11 +84,19 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with that many ranks (WORLD_SIZE={world})")
     dist = None
+    # test hook (tests/test_bench_gpu.py): run a 2-rank job on a 1-GPU box -- every rank on cuda:0,
+    # counters reduced over gloo instead of RCCL.  Never set by the driver.
+    single_device = os.environ.get("PAMD_BENCH_SINGLE_DEVICE") == "1"
+    if single_device:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if single_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
 

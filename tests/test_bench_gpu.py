@@ -1,0 +1,58 @@
+"""bench.py's contract: one JSON line with the required keys, single- and multi-rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _check(line, n_gpus, steps, warmup):
+    d = json.loads(line)
+    assert REQUIRED <= set(d), REQUIRED - set(d)
+    assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
+    assert d["unit"] == "pairs/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # value is whole-job pairs over the timed region
+    assert abs(d["value"] - d["config"]["pairs_per_gpu"] * n_gpus / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
+    assert d["stat"]["count"] == d["config"]["pairs_per_gpu"] * n_gpus
+    return d
+
+
+def test_bench_single_gpu(built):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "300000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _check(out.stdout.strip().splitlines()[-1], 1, 2, 1)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["cores"] >= 1 and c["matches_gpu_on_sample"] is True
+
+
+def test_bench_two_ranks_sharded(built):
+    """The N>1 path (contiguous shards + counter all-reduce + max-over-ranks timing) on one GPU:
+    both ranks share cuda:0 and reduce over gloo (PAMD_BENCH_SINGLE_DEVICE test hook)."""
+    env = dict(os.environ, PAMD_BENCH_SINGLE_DEVICE="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--pairs", "200000", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    d = _check(lines[0], 2, 2, 1)
+    assert "cpu_baseline" not in d
+    # the two shards are pairs [0, n) and [n, 2n): their summed counters equal one 2n-pair run
+    single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "400000", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                            capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert single.returncode == 0, single.stderr[-2000:]
+    s = json.loads(single.stdout.strip().splitlines()[-1])
+    assert d["stat"] == s["stat"]
