@@ -66,7 +66,9 @@ struct pamd_assembler {
 	uint8_t *d_primers = nullptr;
 	bool primers_dirty = true;
 	unsigned long long *d_error = nullptr;
-	unsigned long long *d_phase = nullptr;	// 10 words, only written by -DPAMD_PHASE_TIMING builds
+	unsigned long long *d_phase = nullptr;
+	double *d_scratch = nullptr;	// parked score terms (pear / rdp_mle), sized for the largest launch so far
+	size_t scratch_rows = 0;	// 10 words, only written by -DPAMD_PHASE_TIMING builds
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 	bool timed = false;
 	int last_wgs = 0, last_waves = 0, last_lds = 0;
@@ -164,6 +166,8 @@ void pamd_assembler_destroy(pamd_assembler *a) {
 		(void) hipFree(a->d_error);
 	if (a->d_phase)
 		(void) hipFree(a->d_phase);
+	if (a->d_scratch)
+		(void) hipFree(a->d_scratch);
 	if (a->ev_start)
 		(void) hipEventDestroy(a->ev_start);
 	if (a->ev_stop)
@@ -447,6 +451,18 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	a->last_waves = waves;
 	a->last_lds = (int) lds_bytes;
 
+	if (a->algo != PAMD_ALGO_SIMPLE_BAYES) {
+		const size_t rows = (size_t) wgs * (size_t) waves * 8u;	// GROUP parked rows per wave
+		if (rows > a->scratch_rows) {
+			if (a->d_scratch)
+				HIP_TRY(hipFree(a->d_scratch));
+			a->d_scratch = nullptr;
+			a->scratch_rows = 0;
+			HIP_TRY(hipMalloc(&a->d_scratch, rows * 456u * sizeof(double)));
+			a->scratch_rows = rows;
+		}
+		p.score_scratch = a->d_scratch;
+	}
 	HIP_TRY(hipEventRecord(a->ev_start, st));
 	rc = pamd_launch_assemble(p, wgs, waves, lds_bytes, stream);
 	if (rc != PAMD_OK)

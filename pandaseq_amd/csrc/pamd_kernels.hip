@@ -207,7 +207,27 @@ __device__ int primer_offset(const PamdKernelParams &P, const double *ltab, cons
 		const int index = s + plen;
 		if (index <= len - 1) {
 			double acc = 0.0;
-			for (int x = 0; x < plen; x++) {
+			// same order as offset.c:79-87 (x ascending); the loads of eight steps are issued together
+			int x = 0;
+			for (; x + 8 <= plen; x += 8) {
+				unsigned e[8], pn[8];
+				double t[8];
+#pragma unroll
+				for (int u = 0; u < 8; u++) {
+					e[u] = S[s + x + u];
+					pn[u] = primer[x + u];
+				}
+#pragma unroll
+				for (int u = 0; u < 8; u++) {
+					const int q = clampq(qual_of(e[u]));
+					t[u] = ltab[(((nt_of(e[u]) & pn[u]) != 0) ? PAMD_LT_SCORE : PAMD_LT_ERR) + q];
+				}
+#pragma unroll
+				for (int u = 0; u < 8; u++)
+					if (pn[u] != NT_N)
+						acc += t[u];
+			}
+			for (; x < plen; x++) {
 				const unsigned pn = primer[x];
 				if (pn != NT_N) {
 					const unsigned e = S[s + x];
@@ -291,6 +311,79 @@ __device__ __forceinline__ double score_sb_planes(const PamdKernelParams &P, con
 	return P.qual_nn * free_bases + (double) matches * P.sb_pmatch + (double) mismatches * P.sb_pmismatch;
 }
 
+// ---- pear / rdp_mle: the per-base terms of one candidate, in L.ps[0..ov) ---------------------------
+// (skipped positions get +0.0, which leaves an f64 sum that started at +0.0 unchanged)
+template <int ALGO>
+__device__ __forceinline__ void score_terms(const PamdKernelParams &P, const double *ltab, const WaveLds &L, int flen, int rlen, int ov, int lane) {
+	double nrb = -P.pear_random_base, nn = P.qual_nn;
+	asm volatile("" : "+v"(nrb), "+v"(nn));	// register copies: keep the table reads pure LDS loads
+	for (int i0 = 0; i0 < ov; i0 += 64) {
+		const int i = i0 + lane;
+		if (i < ov) {
+			const int fi = flen + i - ov;
+			const int ri = rlen - i - 1;
+			double term = 0.0;
+			if (fi >= 0 && ri >= 0) {
+				const unsigned ef = L.F[fi];
+				const unsigned er = L.R[ri];
+				const unsigned a = ef & 0xFFu, b = er & 0xFFu;
+				const int qa = clampq(qual_of(ef));
+				if (ALGO == PAMD_ALGO_PEAR) {
+					if (a == NT_N || b == NT_N) {
+						term = nrb;	// "probability -= random_base"
+					} else {
+						// second index: the FORWARD read's quality at rindex (algo_pear.c:52,54);
+						// past the forward read the reference is undefined, we define quality 0
+						const int qb = ri < flen ? clampq(qual_of(L.F[ri])) : 0;
+						term = ltab[((a & b) != 0 ? PAMD_LT_A : PAMD_LT_B) + qa * PAMD_NQ + qb];
+					}
+				} else {
+					const int qb = clampq(qual_of(er));
+					term = ltab[((a & b) != 0 ? PAMD_LT_A : PAMD_LT_B) + qa * PAMD_NQ + qb] - nn;
+				}
+			}
+			L.ps[i] = term;
+		}
+	}
+	wave_sync();
+}
+
+// the reference's own summation order, by one lane
+__device__ __forceinline__ double sum_terms_exact(const WaveLds &L, int ov, int lane) {
+	double acc = 0.0;
+	if (lane == 0) {
+		int i = 0;
+		for (; i + 8 <= ov; i += 8) {
+			const double v0 = L.ps[i], v1 = L.ps[i + 1], v2 = L.ps[i + 2], v3 = L.ps[i + 3];
+			const double v4 = L.ps[i + 4], v5 = L.ps[i + 5], v6 = L.ps[i + 6], v7 = L.ps[i + 7];
+			acc += v0;
+			acc += v1;
+			acc += v2;
+			acc += v3;
+			acc += v4;
+			acc += v5;
+			acc += v6;
+			acc += v7;
+		}
+		for (; i < ov; i++)
+			acc += L.ps[i];
+	}
+	wave_sync();
+	return uni_f64(acc);
+}
+
+// any-order sum of the same terms: only used to DECIDE between candidates whose scores differ by far
+// more than its rounding error (|error| < 1e-9 for 450 terms of magnitude < 1e3)
+__device__ __forceinline__ double sum_terms_fast(const WaveLds &L, int ov, int lane) {
+	double acc = 0.0;
+	for (int i = lane; i < ov; i += 64)
+		acc += L.ps[i];
+	for (int o = 32; o > 0; o >>= 1)
+		acc += __shfl_xor(acc, o);
+	wave_sync();
+	return uni_f64(acc);
+}
+
 // ---- overlap_probability, one candidate ------------------------------------------------------
 template <int ALGO>
 __device__ __forceinline__ double score_overlap(const PamdKernelParams &P, const double *ltab, const WaveLds &L, int flen, int rlen, int ov, int lane) {
@@ -312,61 +405,14 @@ __device__ __forceinline__ double score_overlap(const PamdKernelParams &P, const
 			mismatches += __popcll(__ballot(ina && !n0 && !m0)) + __popcll(__ballot(inb && !n1 && !m1));
 		}
 		// size_t arithmetic inside the parenthesis (algo_simple_bayes.c:61-65), wrap included
-		const u64 free_bases = (ov >= flen && ov >= rlen) ? (u64) unknowns : (u64) flen + (u64) rlen - 2ull * (u64) ov + (u64) unknowns;
-		return P.qual_nn * (double) free_bases + (double) matches * P.sb_pmatch + (double) mismatches * P.sb_pmismatch;
+		const int fb = (ov >= flen && ov >= rlen) ? unknowns : flen + rlen - 2 * ov + unknowns;
+		const double free_bases = fb >= 0 ? (double) (unsigned) fb : (double) (u64) (long long) fb;
+		return P.qual_nn * free_bases + (double) matches * P.sb_pmatch + (double) mismatches * P.sb_pmismatch;
 	} else {
 		// algo_pear.c:32-59 / algo_rdp_mle.c:43-74: a sequential f64 sum over i = 0..ov-1.
-		// Lanes produce the terms, lane 0 adds them in order (skipped positions add +0.0, which
-		// leaves an f64 sum that started at +0.0 unchanged).
-		for (int i0 = 0; i0 < ov; i0 += 64) {
-			const int i = i0 + lane;
-			if (i < ov) {
-				const int fi = flen + i - ov;
-				const int ri = rlen - i - 1;
-				double term = 0.0;
-				if (fi >= 0 && ri >= 0) {
-					const unsigned ef = L.F[fi];
-					const unsigned er = L.R[ri];
-					const unsigned a = ef & 0xFFu, b = er & 0xFFu;
-					const int qa = clampq(qual_of(ef));
-					if (ALGO == PAMD_ALGO_PEAR) {
-						if (a == NT_N || b == NT_N) {
-							term = -P.pear_random_base;	// "probability -= random_base"
-						} else {
-							// second index: the FORWARD read's quality at rindex (algo_pear.c:52,54);
-							// past the forward read the reference is undefined, we define quality 0
-							const int qb = ri < flen ? clampq(qual_of(L.F[ri])) : 0;
-							term = ltab[((a & b) != 0 ? PAMD_LT_A : PAMD_LT_B) + qa * PAMD_NQ + qb];
-						}
-					} else {
-						const int qb = clampq(qual_of(er));
-						term = ltab[((a & b) != 0 ? PAMD_LT_A : PAMD_LT_B) + qa * PAMD_NQ + qb] - P.qual_nn;
-					}
-				}
-				L.ps[i] = term;
-			}
-		}
-		wave_sync();
-		double acc = 0.0;
-		if (lane == 0) {
-			int i = 0;
-			for (; i + 8 <= ov; i += 8) {
-				const double v0 = L.ps[i], v1 = L.ps[i + 1], v2 = L.ps[i + 2], v3 = L.ps[i + 3];
-				const double v4 = L.ps[i + 4], v5 = L.ps[i + 5], v6 = L.ps[i + 6], v7 = L.ps[i + 7];
-				acc += v0;
-				acc += v1;
-				acc += v2;
-				acc += v3;
-				acc += v4;
-				acc += v5;
-				acc += v6;
-				acc += v7;
-			}
-			for (; i < ov; i++)
-				acc += L.ps[i];
-		}
-		wave_sync();
-		return uni_f64(acc);
+		// Lanes produce the terms, lane 0 adds them in order.
+		score_terms<ALGO>(P, ltab, L, flen, rlen, ov, lane);
+		return sum_terms_exact(L, ov, lane);
 	}
 }
 
@@ -434,6 +480,7 @@ struct WaveArena {
 // so 48 lanes advance 48 chains with the same instructions.  Then lane `slot` finishes pair `slot`:
 // quality, LOWQ, check modules, the 48-byte record and the counters.
 constexpr int GROUP = 8;
+constexpr int SCORE_STRIDE = 456;	// doubles per parked score-term row
 #ifndef FINISH_DEPTH
 #define FINISH_DEPTH 6	/* 16-byte loads in flight per chain */
 #endif
@@ -446,17 +493,19 @@ struct PendRec {	// 80 bytes
 	int seqlen, A, novl, len;
 	int bo, examined, mism, degen, fo, ro, slow;
 	int phmin;	// smallest panda_result_phred over the merged bases (only when a min_phred module is loaded)
-	int pad;
+	int score_n;	// pear / rdp_mle: > 0 = `best` is still to be summed from this many parked terms
 };
 
 static_assert(sizeof(PendRec) == 80, "PendRec is sized by pamd_api.cpp");
 
-__device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsigned *lctr, const PendRec *pend, int npend, int lane) {
+template <int ALGO>
+__device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsigned *lctr, const PendRec *pend, int npend, unsigned wave_gid, int lane) {
+	constexpr int NCH = ALGO == PAMD_ALGO_SIMPLE_BAYES ? 3 : 4;	// chains per pair
 	// all of this wave's row stores must have reached L2 before they are read back
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	wave_sync();
 	// ---- ordered sums, one chain per lane ----
-	const int slot = lane / 3, chain = lane - 3 * slot;
+	const int slot = lane / NCH, chain = lane - NCH * slot;
 	double acc = 0.0;
 	{
 		// chain 0: forward-only [0,A)   chain 1: reverse-only [A+novl, seqlen)   chain 2: overlap [A, A+novl)
@@ -467,7 +516,11 @@ __device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsi
 		const double *rowp = P.seq_p;
 		if (slot < npend) {
 			const PendRec &r = pend[slot];
-			if (r.st == PAMD_ST_OK && r.off != ~0ull) {
+			if (chain == 3) {
+				// pear / rdp_mle: the winning candidate's terms, parked by assemble_pair()
+				end = r.score_n;
+				rowp = P.score_scratch + ((size_t) wave_gid * GROUP + (size_t) slot) * SCORE_STRIDE;
+			} else if (r.st == PAMD_ST_OK && r.off != ~0ull) {
 				j = chain == 0 ? 0 : (chain == 1 ? r.A + r.novl : r.A);
 				end = chain == 0 ? r.A : (chain == 1 ? r.seqlen : r.A + r.novl);
 				rowp = P.seq_p + r.off;	// 128-byte aligned
@@ -508,13 +561,16 @@ __device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsi
 		}
 	}
 	// ---- one lane per pair ----
-	const int src = lane < GROUP ? 3 * lane : 0;
+	const int src = lane < GROUP ? NCH * lane : 0;
 	const double fquality = __shfl(acc, src);
 	const double rquality = __shfl(acc, src + 1);
 	const double oquality = __shfl(acc, src + 2);
+	const double parked_score = NCH == 4 ? __shfl(acc, src + 3) : 0.0;
 	int status = -1, reject = -1, overlap = 0;
 	if (lane < npend) {
-		const PendRec r = pend[lane];
+		PendRec r = pend[lane];
+		if (NCH == 4 && r.score_n > 0)
+			r.best = parked_score;	// the ordered sum of the parked terms = estimated_overlap_probability
 		status = r.st;
 		double quality = 0.0;
 		u64 off = ~0ull;
@@ -582,7 +638,7 @@ struct Carry {
 
 // ---- one pair: everything up to its parked record ----------------------------------------------
 template <int ALGO>
-__device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, const WaveLds &L, WaveArena &arena, PendRec *slot_rec, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt
+__device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, const WaveLds &L, WaveArena &arena, PendRec *slot_rec, int slot_idx, unsigned wave_gid, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt
 #ifdef PAMD_PHASE_TIMING
 	, u64 *ph_acc
 #endif
@@ -611,6 +667,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 	rec.ro = 0;
 	rec.slow = 0;
 	rec.phmin = 127;
+	rec.score_n = 0;
 	int status = PAMD_ST_OK;
 
 	do {
@@ -755,6 +812,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		double best = P.qual_nn * (double) (flen + rlen);	// assembler.c:60
 		int bo = -1;
 		int examined = 0;
+		int score_parked = 0;	// pear / rdp_mle: the winner's terms sit in L.ps and must be parked
 		int ncand = 0;
 		{
 			u64 nz = __ballot(mybits != 0);
@@ -843,21 +901,61 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			examined = total;
 			wave_sync();
 		} else {
-			u64 words = __ballot(mybits != 0);	// non-empty 32-candidate words, ascending
-			while (words != 0) {
-				const int w = __builtin_ctzll(words);
-				words &= words - 1;
-				unsigned m = (unsigned) __builtin_amdgcn_readlane((int) mybits, w);
-				while (m) {
-					const int b = __builtin_ctz(m);
-					m &= m - 1;
-					const int ov = w * 32 + b + minov;
-					const double pr = score_overlap<ALGO>(P, ltab, L, flen, rlen, ov, lane);
-					if (pr > best) {	// strict: ascending scan keeps the smallest overlap on ties
-						best = pr;
-						bo = ov;
+			// Few candidates.  simple_bayesian scores are exact integers-in-a-formula.  pear / rdp_mle
+			// scores are ordered f64 chains, ~150 dependent adds each: the winner is DECIDED from
+			// any-order sums (error < 1e-9) whenever every comparison is clearer than 1e-6, and its exact
+			// ordered sum is left to the group finish as a fourth chain over the parked terms.  Any
+			// comparison closer than that falls back to summing every candidate in reference order here.
+			bool ambiguous = ALGO == PAMD_ALGO_SIMPLE_BAYES || P.score_scratch == nullptr;
+			if (ALGO != PAMD_ALGO_SIMPLE_BAYES && !ambiguous) {
+				int last_ov = -1;
+				u64 words = __ballot(mybits != 0);
+				while (words != 0) {
+					const int w = __builtin_ctzll(words);
+					words &= words - 1;
+					unsigned m = (unsigned) __builtin_amdgcn_readlane((int) mybits, w);
+					while (m) {
+						const int b = __builtin_ctz(m);
+						m &= m - 1;
+						const int ov = w * 32 + b + minov;
+						score_terms<ALGO>(P, ltab, L, flen, rlen, ov, lane);
+						const double pr = sum_terms_fast(L, ov, lane);
+						if (pr > best + 1e-6) {
+							best = pr;
+							bo = ov;
+						} else if (!(pr < best - 1e-6)) {
+							ambiguous = true;
+						}
+						last_ov = ov;
+						examined++;
 					}
-					examined++;
+				}
+				if (!ambiguous && bo >= 0) {
+					if (last_ov != bo)
+						score_terms<ALGO>(P, ltab, L, flen, rlen, bo, lane);
+					score_parked = bo;	// stored to the scratch row once the prefetch registers are rotated in
+				}
+			}
+			if (ambiguous) {
+				best = P.qual_nn * (double) (flen + rlen);
+				bo = -1;
+				examined = 0;
+				u64 words = __ballot(mybits != 0);	// non-empty 32-candidate words, ascending
+				while (words != 0) {
+					const int w = __builtin_ctzll(words);
+					words &= words - 1;
+					unsigned m = (unsigned) __builtin_amdgcn_readlane((int) mybits, w);
+					while (m) {
+						const int b = __builtin_ctz(m);
+						m &= m - 1;
+						const int ov = w * 32 + b + minov;
+						const double pr = score_overlap<ALGO>(P, ltab, L, flen, rlen, ov, lane);
+						if (pr > best) {	// strict: ascending scan keeps the smallest overlap on ties
+							best = pr;
+							bo = ov;
+						}
+						examined++;
+					}
 				}
 			}
 		}
@@ -869,6 +967,24 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			break;
 		}
 
+		// Rotate the prefetched registers in BEFORE this pair's stores are issued: vmcnt counts loads
+		// and stores in one in-order queue, so waiting for the (long finished) loads here is free,
+		// while waiting for them at the top of the next iteration would also wait for the stores.
+		cur = nxt;
+		asm volatile("" : "+v"(cur.flen_v), "+v"(cur.rlen_v), "+v"(cur.f.x), "+v"(cur.f.y), "+v"(cur.f.z), "+v"(cur.f.w), "+v"(cur.r.x), "+v"(cur.r.y), "+v"(cur.r.z), "+v"(cur.r.w));
+		rotated = true;
+
+		if (score_parked > 0) {
+			// park the winner's terms for the finish: 16-byte stores into this wave's scratch row
+			double *dst = P.score_scratch + ((size_t) wave_gid * GROUP + (size_t) slot_idx) * SCORE_STRIDE;
+			for (int j0 = 0; j0 < score_parked; j0 += 128) {
+				const int j = j0 + lane * 2;
+				if (j < score_parked)
+					reinterpret_cast<double2 *>(dst)[j >> 1] = reinterpret_cast<const double2 *>(L.ps)[j >> 1];
+			}
+			rec.score_n = score_parked;
+			wave_sync();
+		}
 		PH_MARK(4);
 		// ---- merge (assembler.c:146-247), written straight to the pair's output row ----
 		const int len = flen - fo - bo + rlen - ro + 1;
@@ -890,13 +1006,6 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		rec.len = len;
 		rec.bo = bo;
 		rec.best = best;
-
-		// Rotate the prefetched registers in BEFORE this pair's stores are issued: vmcnt counts loads
-		// and stores in one in-order queue, so waiting for the (long finished) loads here is free,
-		// while waiting for them at the top of the next iteration would also wait for the stores.
-		cur = nxt;
-		asm volatile("" : "+v"(cur.flen_v), "+v"(cur.rlen_v), "+v"(cur.f.x), "+v"(cur.f.y), "+v"(cur.f.z), "+v"(cur.f.w), "+v"(cur.r.x), "+v"(cur.r.y), "+v"(cur.r.z), "+v"(cur.r.w));
-		rotated = true;
 
 		// the row: fixed stride, or the next piece of this wave's arena chunk (rows of pairs that are
 		// rejected later simply stay behind as holes)
@@ -934,6 +1043,9 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		double qual_nn = P.qual_nn;
 		asm volatile("" : "+v"(qual_nn));
 		int mism = 0, degen = 0, phmin = 127;
+		bool low_p = false;
+		double pmin = 0.0;	// every log-p is <= 0
+		const double qs0 = want_phred ? ltab[PAMD_LT_SCORE] : 0.0;
 		// forward-only bases (assembler.c:162-173)
 		for (int j0 = 0; j0 < A; j0 += 64) {
 			const int j = j0 + lane;
@@ -945,10 +1057,11 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const double q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
 				L.nts[j] = (uint8_t) nt;
 				L.ps[j] = q;
-				if (want_phred) {
-					const int ph = result_phred(ltab + PAMD_LT_SCORE, q);
-					phmin = ph < phmin ? ph : phmin;
-				}
+				// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
+				// it (checked over every breakpoint in tests/test_oracle_cpu.py), so the smallest phred of
+				// the row follows from "any p at or below qual_score[0]" and the smallest p above it
+				low_p |= q <= qs0;
+				pmin = (q > qs0 && q < pmin) ? q : pmin;
 			}
 			degen += __popcll(__ballot(in && __popc(nt) != 1));	// PANDA_NT_IS_DEGN
 		}
@@ -988,10 +1101,11 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				nt = match ? (a & b) : (fq < rq ? b : a);	// assembler.c:212-220
 				L.nts[A + i] = (uint8_t) nt;
 				L.ps[A + i] = q;
-				if (want_phred) {
-					const int ph = result_phred(ltab + PAMD_LT_SCORE, q);
-					phmin = ph < phmin ? ph : phmin;
-				}
+				// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
+				// it (checked over every breakpoint in tests/test_oracle_cpu.py), so the smallest phred of
+				// the row follows from "any p at or below qual_score[0]" and the smallest p above it
+				low_p |= q <= qs0;
+				pmin = (q > qs0 && q < pmin) ? q : pmin;
 			}
 			mism += __popcll(__ballot(in && ismm));
 			degen += __popcll(__ballot(in && __popc(nt) != 1));
@@ -1007,10 +1121,11 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const double q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
 				L.nts[A + novl + i] = (uint8_t) nt;
 				L.ps[A + novl + i] = q;
-				if (want_phred) {
-					const int ph = result_phred(ltab + PAMD_LT_SCORE, q);
-					phmin = ph < phmin ? ph : phmin;
-				}
+				// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
+				// it (checked over every breakpoint in tests/test_oracle_cpu.py), so the smallest phred of
+				// the row follows from "any p at or below qual_score[0]" and the smallest p above it
+				low_p |= q <= qs0;
+				pmin = (q > qs0 && q < pmin) ? q : pmin;
 			}
 			degen += __popcll(__ballot(in && __popc(nt) != 1));
 		}
@@ -1027,10 +1142,13 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		}
 		if (want_phred) {
 			for (int o = 32; o > 0; o >>= 1) {
-				const int other = __shfl_xor(phmin, o);
-				phmin = other < phmin ? other : phmin;
+				const double other = __shfl_xor(pmin, o);
+				pmin = other < pmin ? other : pmin;
 			}
-			rec.phmin = uni(phmin);
+			phmin = result_phred(ltab + PAMD_LT_SCORE, uni_f64(pmin));
+			if (__ballot(low_p) != 0 && phmin > 1)
+				phmin = 1;
+			rec.phmin = seqlen > 0 ? phmin : 127;	// an empty row passes any threshold
 		}
 		rec.mism = mism;
 		rec.degen = degen;
@@ -1087,6 +1205,7 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	arena.cur = 0;
 	arena.end = 0;
 	const u64 total_waves = (u64) gridDim.x * (u64) nwaves;
+	const unsigned wave_gid = blockIdx.x * (unsigned) nwaves + (unsigned) wave;
 #ifdef PAMD_PHASE_TIMING
 	u64 ph_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	const u64 ph_begin = __builtin_amdgcn_s_memtime();
@@ -1116,16 +1235,16 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		nxt.r = load_read(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
 #ifdef PAMD_PHASE_TIMING
-		assemble_pair<ALGO>(P, ltab, lprimers, L, arena, &pend[npend], pair, lane, flen, rlen, cur, nxt, ph_acc);
+		assemble_pair<ALGO>(P, ltab, lprimers, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt, ph_acc);
 #else
-		assemble_pair<ALGO>(P, ltab, lprimers, L, arena, &pend[npend], pair, lane, flen, rlen, cur, nxt);
+		assemble_pair<ALGO>(P, ltab, lprimers, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt);
 #endif
 		npend++;
 		if (npend == GROUP) {
 #ifdef PAMD_PHASE_TIMING
 			const u64 t0 = __builtin_amdgcn_s_memtime();
 #endif
-			finish_group(P, ltab, lctr, pend, npend, lane);
+			finish_group<ALGO>(P, ltab, lctr, pend, npend, wave_gid, lane);
 #ifdef PAMD_PHASE_TIMING
 			ph_acc[8] += __builtin_amdgcn_s_memtime() - t0;
 #endif
@@ -1134,7 +1253,7 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		pair = next;
 	}
 	if (npend > 0)
-		finish_group(P, ltab, lctr, pend, npend, lane);
+		finish_group<ALGO>(P, ltab, lctr, pend, npend, wave_gid, lane);
 #ifdef PAMD_PHASE_TIMING
 	ph_acc[9] = __builtin_amdgcn_s_memtime() - ph_begin;
 	if (lane == 0 && P.phase_cycles != nullptr)

@@ -94,6 +94,25 @@ def test_phred_quirks(po):
     assert L.po_result_phred(C.byref(t), -1.38629) == 2
 
 
+def test_phred_is_one_below_qs0_and_monotone_above(po):
+    """The device derives min_phred's verdict from the smallest log-p of a row.  That needs
+    panda_result_phred (nt.c:126-150) to be 1 for p <= qual_score[0] and non-decreasing for larger p.
+    The function is piecewise constant with breakpoints at the 47 table values: check each value and
+    its two neighbouring doubles, plus a dense grid."""
+    t = po.tables()
+    L = po.lib()
+    qs = po.tables_np()["score"]
+    assert L.po_result_phred(C.byref(t), float(qs[0])) == 1 and L.po_result_phred(C.byref(t), -700.0) == 1
+    pts = set()
+    for v in qs:
+        for w in (np.nextafter(v, -np.inf), v, np.nextafter(v, np.inf)):
+            if w > qs[0]:
+                pts.add(float(w))
+    pts |= {float(v) for v in np.linspace(qs[0], 0.0, 20001)[1:]}
+    ph = np.array([L.po_result_phred(C.byref(t), v) for v in sorted(pts)])
+    assert (np.diff(ph) >= 0).all() and ph.min() == 0 and ph.max() == 45
+
+
 def test_kmer_iterator_rules(po):
     """misc.h:41-45: first forward k-mer at position 8; a 9-wide N exclusion window; A and ambiguity codes hash as 0."""
     L = po.lib()
