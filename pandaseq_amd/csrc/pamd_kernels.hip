@@ -637,7 +637,7 @@ struct Carry {
 };
 
 // ---- one pair: everything up to its parked record ----------------------------------------------
-template <int ALGO>
+template <int ALGO, bool PHRED>
 __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, const WaveLds &L, WaveArena &arena, PendRec *slot_rec, int slot_idx, unsigned wave_gid, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt
 #ifdef PAMD_PHASE_TIMING
 	, u64 *ph_acc
@@ -1037,7 +1037,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		const bool store = off != ~0ull;
 		uint8_t *row_nt = P.seq_nt + (store ? off : 0);
 		double *row_p = P.seq_p + (store ? off : 0);
-		const bool want_phred = P.has_min_phred != 0;
+		constexpr bool want_phred = PHRED;	// a min_phred module is loaded (separate kernel instantiation)
 		// a register copy: selecting between "load from the kernel arguments" and "load from LDS"
 		// makes the compiler emit one FLAT load, whose wait also waits for every store in flight
 		double qual_nn = P.qual_nn;
@@ -1163,7 +1163,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		*slot_rec = rec;	// park it; finish_group() does the rest
 }
 
-template <int ALGO>
+template <int ALGO, bool PHRED>
 __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	double *ltab = reinterpret_cast<double *>(lds);
@@ -1235,9 +1235,9 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		nxt.r = load_read(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
 #ifdef PAMD_PHASE_TIMING
-		assemble_pair<ALGO>(P, ltab, lprimers, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt, ph_acc);
+		assemble_pair<ALGO, PHRED>(P, ltab, lprimers, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt, ph_acc);
 #else
-		assemble_pair<ALGO>(P, ltab, lprimers, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt);
+		assemble_pair<ALGO, PHRED>(P, ltab, lprimers, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt);
 #endif
 		npend++;
 		if (npend == GROUP) {
@@ -1364,15 +1364,16 @@ int pamd_launch_assemble(const PamdKernelParams &p, int workgroups, int waves_pe
 	const dim3 grid((unsigned) workgroups), block((unsigned) waves_per_wg * 64u);
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	void (*kern)(const PamdKernelParams) = nullptr;
+	const bool ph = p.has_min_phred != 0;
 	switch (p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
-		kern = pamd_assemble_kernel<PAMD_ALGO_SIMPLE_BAYES>;
+		kern = ph ? pamd_assemble_kernel<PAMD_ALGO_SIMPLE_BAYES, true> : pamd_assemble_kernel<PAMD_ALGO_SIMPLE_BAYES, false>;
 		break;
 	case PAMD_ALGO_PEAR:
-		kern = pamd_assemble_kernel<PAMD_ALGO_PEAR>;
+		kern = ph ? pamd_assemble_kernel<PAMD_ALGO_PEAR, true> : pamd_assemble_kernel<PAMD_ALGO_PEAR, false>;
 		break;
 	case PAMD_ALGO_RDP_MLE:
-		kern = pamd_assemble_kernel<PAMD_ALGO_RDP_MLE>;
+		kern = ph ? pamd_assemble_kernel<PAMD_ALGO_RDP_MLE, true> : pamd_assemble_kernel<PAMD_ALGO_RDP_MLE, false>;
 		break;
 	default:
 		pamd_set_error("unknown algorithm %d", p.algo);
