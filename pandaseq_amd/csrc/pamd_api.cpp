@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -438,6 +439,11 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	int waves = (int) ((LDS_LIMIT - p.lds_wave_off) / p.lds_wave_bytes);
 	if (waves > MAX_WAVES_PER_WG)
 		waves = MAX_WAVES_PER_WG;
+	if (const char *cap = getenv("PAMD_MAX_WAVES")) {	// occupancy experiments only
+		const int c = atoi(cap);
+		if (c >= 1 && c < waves)
+			waves = c;
+	}
 	if (waves < 1) {
 		pamd_set_error("batch does not fit in LDS");
 		return PAMD_EINVAL;

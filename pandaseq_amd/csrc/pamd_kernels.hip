@@ -115,12 +115,17 @@ struct WaveLds {
 
 // ---- load one read, stage it, derive its packed k-mer inputs --------------------------------
 // Returns the B-cliff length: read length minus the trailing run of raw quality 2 (assembler.c:176-177).
-// Branch-free so the compiler can count it in s_waitcnt vmcnt(N): every lane loads 16 B of the row,
-// lanes past the row end re-read its last 16 bytes (rows are whole multiples of 16 B).
+// Branch-free so the compiler can count it in s_waitcnt vmcnt(N): every lane loads BPL bases (2*BPL
+// bytes) of the row, lanes past the row end re-read its last bytes (rows are whole multiples of 16 B).
+// BPL = 4 when a row fits 64 lanes x 4 bases (reads <= 256): all 64 lanes then share the packing work.
+template <int BPL>
 __device__ __forceinline__ uint4 load_read(const uint8_t *row, unsigned row_bytes, int lane) {
-	unsigned off = (unsigned) lane * 16u;
-	off = off < row_bytes ? off : row_bytes - 16u;
-	return *reinterpret_cast<const uint4 *>(row + off);
+	unsigned off = (unsigned) lane * (2u * BPL);
+	off = off < row_bytes ? off : row_bytes - 2u * BPL;
+	if (BPL == 8)
+		return *reinterpret_cast<const uint4 *>(row + off);
+	const uint2 v = *reinterpret_cast<const uint2 *>(row + off);
+	return make_uint4(v.x, v.y, 0u, 0u);
 }
 
 // The one-hot bit planes of a read (only needed when many candidates must be scored, see the scan).
@@ -145,10 +150,14 @@ __device__ __forceinline__ void build_planes(const uint16_t *src, int len, int l
 	planes[4 + 3 * PLANE_STRIDE + lane] = (uint8_t) (pt & inmask);
 }
 
-template <bool FORWARD>
+template <bool FORWARD, int BPL>
 __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint16_t *dst, uint32_t *codes, uint32_t *nmap) {
-	if (lane * 8 < len)
-		reinterpret_cast<uint4 *>(dst)[lane] = v;
+	if (lane * BPL < len) {
+		if (BPL == 8)
+			reinterpret_cast<uint4 *>(dst)[lane] = v;
+		else
+			reinterpret_cast<uint2 *>(dst)[lane] = make_uint2(v.x, v.y);
+	}
 	const unsigned w[4] = { v.x, v.y, v.z, v.w };
 	// Branch-free on purpose (straight-line bit arithmetic; ?: chains here compile to exec-mask
 	// branches per base).  nt is 0..15 in the device domain.
@@ -156,32 +165,40 @@ __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint
 	//              (the reverse read stores C=2 G=1, see below)
 	//   N          = (nt + 1) >> 4
 	//   qual == 2  = bit 8 of ((qual ^ 2) - 1) taken as an unsigned byte
-	unsigned code16 = 0, is2 = 0, nbits = 0;
+	unsigned codes_k = 0, is2 = 0, nbits = 0;
 #pragma unroll
-	for (int k = 0; k < 8; k++) {
+	for (int k = 0; k < BPL; k++) {
 		const unsigned e = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
 		const unsigned nt = e & 0xFFu;
 		const unsigned c = ((FORWARD ? 0x00030210u : 0x00030120u) >> ((nt & 15u) * 2u)) & 3u;
-		code16 |= c << (2 * k);
+		codes_k |= c << (2 * k);
 		nbits |= (((nt + 1u) >> 4) & 1u) << k;
 		is2 |= (((((e >> 8) ^ 2u) & 0xFFu) - 1u) >> 8 & 1u) << k;
 	}
 	// bases at or beyond the read length contribute nothing
-	int cnt = len - lane * 8;
-	cnt = cnt < 0 ? 0 : (cnt > 8 ? 8 : cnt);
+	int cnt = len - lane * BPL;
+	cnt = cnt < 0 ? 0 : (cnt > BPL ? BPL : cnt);
 	const unsigned inmask = (1u << cnt) - 1u;	// bit k set <=> base k of this lane exists
 	nbits &= inmask;
 	const unsigned not2 = ~is2 & inmask;
-	code16 &= (1u << (2 * cnt)) - 1u;
+	codes_k &= (1u << (2 * cnt)) - 1u;
 	// 16 codes per u32, base b at bits 2b..2b+1 of the stream.  A forward k-mer is the 16 bits
 	// ending at its position (oldest base in the low bits).  A reverse k-mer must pair its base t
 	// with the forward k-mer's base 7-t, so the reverse stream stores each code with its two bits
 	// swapped (C=2, G=1) and the probe bit-reverses the 16-bit window: the pair order flips and the
 	// bits inside each pair swap back.  Only equality of k-mers matters (the reference's table index
 	// is just a key), so any consistent encoding gives the same candidate set.
-	reinterpret_cast<uint16_t *>(codes)[lane] = (uint16_t) code16;
-	reinterpret_cast<uint8_t *>(nmap)[lane] = (uint8_t) nbits;
-	const int mine = not2 ? lane * 8 + (31 - __builtin_clz(not2)) + 1 : 0;
+	if (BPL == 8) {
+		reinterpret_cast<uint16_t *>(codes)[lane] = (uint16_t) codes_k;
+		reinterpret_cast<uint8_t *>(nmap)[lane] = (uint8_t) nbits;
+	} else {
+		reinterpret_cast<uint8_t *>(codes)[lane] = (uint8_t) codes_k;
+		// the N bitmap holds 8 positions per byte: even lanes write their nibble plus the next lane's
+		const unsigned hi = (unsigned) __builtin_amdgcn_mov_dpp((int) nbits, 0xF5, 0xF, 0xF, true);	// quad_perm [1,1,3,3]
+		if ((lane & 1) == 0)
+			reinterpret_cast<uint8_t *>(nmap)[lane >> 1] = (uint8_t) (nbits | (hi << 4));
+	}
+	const int mine = not2 ? lane * BPL + (31 - __builtin_clz(not2)) + 1 : 0;
 	const u64 has = __ballot(not2 != 0);
 	if (has == 0)
 		return 0;
@@ -637,7 +654,7 @@ struct Carry {
 };
 
 // ---- one pair: everything up to its parked record ----------------------------------------------
-template <int ALGO, bool PHRED>
+template <int ALGO, bool PHRED, int BPL>
 __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, const WaveLds &L, WaveArena &arena, PendRec *slot_rec, int slot_idx, unsigned wave_gid, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt
 #ifdef PAMD_PHASE_TIMING
 	, u64 *ph_acc
@@ -677,8 +694,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		}
 		// previous pair's readers are done with this wave's LDS
 		wave_sync();
-		const int uf = stage_read<true>(fregs, flen, lane, L.F, L.fc, L.fn);
-		const int ur = stage_read<false>(rregs, rlen, lane, L.R, L.rc, L.rn);
+		const int uf = stage_read<true, BPL>(fregs, flen, lane, L.F, L.fc, L.fn);
+		const int ur = stage_read<false, BPL>(rregs, rlen, lane, L.R, L.rc, L.rn);
 		// clear the k-mer table (aliases the log-p staging area) and the candidate bitmap
 		for (unsigned s4 = lane; s4 < P.hash_slots / 4; s4 += 64)
 			reinterpret_cast<uint4 *>(L.hash)[s4] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
@@ -1163,7 +1180,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		*slot_rec = rec;	// park it; finish_group() does the rest
 }
 
-template <int ALGO, bool PHRED>
+template <int ALGO, bool PHRED, int BPL>
 __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	double *ltab = reinterpret_cast<double *>(lds);
@@ -1219,8 +1236,8 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	Carry cur;
 	cur.flen_v = P.flen[q];
 	cur.rlen_v = P.rlen[q];
-	cur.f = load_read(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
-	cur.r = load_read(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
+	cur.f = load_read<BPL>(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+	cur.r = load_read<BPL>(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
 	// settle the prologue loads before the loop so that, at the loop header, the carried registers
 	// are known-ready on both incoming edges
 	asm volatile("" : "+v"(cur.flen_v), "+v"(cur.rlen_v), "+v"(cur.f.x), "+v"(cur.f.y), "+v"(cur.f.z), "+v"(cur.f.w), "+v"(cur.r.x), "+v"(cur.r.y), "+v"(cur.r.z), "+v"(cur.r.w));
@@ -1231,13 +1248,13 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		Carry nxt;
 		nxt.flen_v = P.flen[q];
 		nxt.rlen_v = P.rlen[q];
-		nxt.f = load_read(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
-		nxt.r = load_read(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
+		nxt.f = load_read<BPL>(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+		nxt.r = load_read<BPL>(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
 #ifdef PAMD_PHASE_TIMING
-		assemble_pair<ALGO, PHRED>(P, ltab, lprimers, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt, ph_acc);
+		assemble_pair<ALGO, PHRED, BPL>(P, ltab, lprimers, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt, ph_acc);
 #else
-		assemble_pair<ALGO, PHRED>(P, ltab, lprimers, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt);
+		assemble_pair<ALGO, PHRED, BPL>(P, ltab, lprimers, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt);
 #endif
 		npend++;
 		if (npend == GROUP) {
@@ -1365,20 +1382,23 @@ int pamd_launch_assemble(const PamdKernelParams &p, int workgroups, int waves_pe
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	void (*kern)(const PamdKernelParams) = nullptr;
 	const bool ph = p.has_min_phred != 0;
+	const bool narrow = p.smax <= 256;	// 4 bases per lane while staging
+#define PAMD_PICK(A) (ph ? (narrow ? pamd_assemble_kernel<A, true, 4> : pamd_assemble_kernel<A, true, 8>) : (narrow ? pamd_assemble_kernel<A, false, 4> : pamd_assemble_kernel<A, false, 8>))
 	switch (p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
-		kern = ph ? pamd_assemble_kernel<PAMD_ALGO_SIMPLE_BAYES, true> : pamd_assemble_kernel<PAMD_ALGO_SIMPLE_BAYES, false>;
+		kern = PAMD_PICK(PAMD_ALGO_SIMPLE_BAYES);
 		break;
 	case PAMD_ALGO_PEAR:
-		kern = ph ? pamd_assemble_kernel<PAMD_ALGO_PEAR, true> : pamd_assemble_kernel<PAMD_ALGO_PEAR, false>;
+		kern = PAMD_PICK(PAMD_ALGO_PEAR);
 		break;
 	case PAMD_ALGO_RDP_MLE:
-		kern = ph ? pamd_assemble_kernel<PAMD_ALGO_RDP_MLE, true> : pamd_assemble_kernel<PAMD_ALGO_RDP_MLE, false>;
+		kern = PAMD_PICK(PAMD_ALGO_RDP_MLE);
 		break;
 	default:
 		pamd_set_error("unknown algorithm %d", p.algo);
 		return PAMD_EINVAL;
 	}
+#undef PAMD_PICK
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 	if (e != hipSuccess) {
 		pamd_set_error("hipFuncSetAttribute(%zu bytes LDS): %s", lds_bytes, hipGetErrorString(e));
