@@ -68,6 +68,8 @@ struct pamd_assembler {
 	bool primers_dirty = true;
 	unsigned long long *d_error = nullptr;
 	unsigned long long *d_phase = nullptr;
+	void *hb_ptr[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };	// pamd_assemble_host staging
+	size_t hb_cap[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	double *d_scratch = nullptr;	// parked score terms (pear / rdp_mle), sized for the largest launch so far
 	size_t scratch_rows = 0;	// 10 words, only written by -DPAMD_PHASE_TIMING builds
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -169,6 +171,9 @@ void pamd_assembler_destroy(pamd_assembler *a) {
 		(void) hipFree(a->d_phase);
 	if (a->d_scratch)
 		(void) hipFree(a->d_scratch);
+	for (void *q : a->hb_ptr)
+		if (q)
+			(void) hipFree(q);
 	if (a->ev_start)
 		(void) hipEventDestroy(a->ev_start);
 	if (a->ev_stop)
@@ -512,6 +517,22 @@ int pamd_last_launch_info(pamd_assembler *a, int *workgroups, int *waves_per_wor
 	return PAMD_OK;
 }
 
+// Device-side staging buffers of the host entry point: grow-only, kept across calls (a hipMalloc /
+// hipFree pair per call cost more than the kernel for small batches).
+static int host_buf(pamd_assembler *a, int which, size_t bytes, void **out) {
+	if (a->hb_cap[which] < bytes) {
+		if (a->hb_ptr[which])
+			HIP_TRY(hipFree(a->hb_ptr[which]));
+		a->hb_ptr[which] = nullptr;
+		a->hb_cap[which] = 0;
+		const size_t want = bytes + bytes / 4 + 256;
+		HIP_TRY(hipMalloc(&a->hb_ptr[which], want));
+		a->hb_cap[which] = want;
+	}
+	*out = a->hb_ptr[which];
+	return PAMD_OK;
+}
+
 int pamd_assemble_host(pamd_assembler *a, const pamd_batch *hb) {
 	if (a == nullptr || hb == nullptr) {
 		pamd_set_error("pamd_assemble_host: null argument");
@@ -523,39 +544,17 @@ int pamd_assemble_host(pamd_assembler *a, const pamd_batch *hb) {
 		return PAMD_OK;
 	const size_t cap = hb->seq_stride ? hb->seq_stride * n : hb->seq_capacity;
 	pamd_batch d = *hb;
-	void *dfwd = nullptr, *drev = nullptr, *dfl = nullptr, *drl = nullptr, *dres = nullptr, *dnt = nullptr, *dp = nullptr, *dcur = nullptr, *dctr = nullptr;
-	int rc = PAMD_OK;
-	auto fail = [&](int code) {
-		void *all[] = { dfwd, drev, dfl, drl, dres, dnt, dp, dcur, dctr };
-		for (void *q : all)
-			if (q)
-				(void) hipFree(q);
-		return code;
-	};
-#define HIP_TRY2(call)                                                          \
-	do {                                                                    \
-		hipError_t e_ = (call);                                         \
-		if (e_ != hipSuccess) {                                         \
-			pamd_set_error("%s: %s", #call, hipGetErrorString(e_)); \
-			return fail(PAMD_ENODEVICE);                            \
-		}                                                               \
-	} while (0)
-	HIP_TRY2(hipMalloc(&dfwd, n * hb->fwd_stride * 2));
-	HIP_TRY2(hipMalloc(&drev, n * hb->rev_stride * 2));
-	HIP_TRY2(hipMalloc(&dfl, n * 2));
-	HIP_TRY2(hipMalloc(&drl, n * 2));
-	HIP_TRY2(hipMalloc(&dres, n * sizeof(pamd_pair_result)));
-	HIP_TRY2(hipMalloc(&dnt, cap + 16));
-	HIP_TRY2(hipMalloc(&dp, (cap + 16) * sizeof(double)));
-	HIP_TRY2(hipMalloc(&dcur, 8));
-	HIP_TRY2(hipMalloc(&dctr, PAMD_NUM_COUNTERS * 8));
-	HIP_TRY2(hipMemcpy(dfwd, hb->fwd, n * hb->fwd_stride * 2, hipMemcpyHostToDevice));
-	HIP_TRY2(hipMemcpy(drev, hb->rev, n * hb->rev_stride * 2, hipMemcpyHostToDevice));
-	HIP_TRY2(hipMemcpy(dfl, hb->flen, n * 2, hipMemcpyHostToDevice));
-	HIP_TRY2(hipMemcpy(drl, hb->rlen, n * 2, hipMemcpyHostToDevice));
-	HIP_TRY2(hipMemset(dcur, 0, 8));
-	HIP_TRY2(hipMemset(dctr, 0, PAMD_NUM_COUNTERS * 8));
-	HIP_TRY2(hipMemset(a->d_error, 0, 8));
+	void *dfwd, *drev, *dfl, *drl, *dres, *dnt, *dp, *dcur, *dctr;
+	int rc;
+	if ((rc = host_buf(a, 0, n * hb->fwd_stride * 2, &dfwd)) || (rc = host_buf(a, 1, n * hb->rev_stride * 2, &drev)) || (rc = host_buf(a, 2, n * 2, &dfl)) || (rc = host_buf(a, 3, n * 2, &drl)) || (rc = host_buf(a, 4, n * sizeof(pamd_pair_result), &dres)) || (rc = host_buf(a, 5, cap + 16, &dnt)) || (rc = host_buf(a, 6, (cap + 16) * sizeof(double), &dp)) || (rc = host_buf(a, 7, 8, &dcur)) || (rc = host_buf(a, 8, PAMD_NUM_COUNTERS * 8, &dctr)))
+		return rc;
+	HIP_TRY(hipMemcpy(dfwd, hb->fwd, n * hb->fwd_stride * 2, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(drev, hb->rev, n * hb->rev_stride * 2, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(dfl, hb->flen, n * 2, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(drl, hb->rlen, n * 2, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemset(dcur, 0, 8));
+	HIP_TRY(hipMemset(dctr, 0, PAMD_NUM_COUNTERS * 8));
+	HIP_TRY(hipMemset(a->d_error, 0, 8));
 	d.fwd = static_cast<const pamd_qual *>(dfwd);
 	d.rev = static_cast<const pamd_qual *>(drev);
 	d.flen = static_cast<const uint16_t *>(dfl);
@@ -568,29 +567,28 @@ int pamd_assemble_host(pamd_assembler *a, const pamd_batch *hb) {
 	d.seq_capacity = cap;
 	rc = pamd_assemble_device(a, &d, nullptr);
 	if (rc != PAMD_OK)
-		return fail(rc);
-	HIP_TRY2(hipDeviceSynchronize());
+		return rc;
+	HIP_TRY(hipDeviceSynchronize());
 	unsigned long long overflow = 0;
-	HIP_TRY2(hipMemcpy(&overflow, a->d_error, 8, hipMemcpyDeviceToHost));
-	HIP_TRY2(hipMemcpy(hb->results, dres, n * sizeof(pamd_pair_result), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(&overflow, a->d_error, 8, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(hb->results, dres, n * sizeof(pamd_pair_result), hipMemcpyDeviceToHost));
 	// compact arena: only the part the launch used comes back
 	size_t used = cap;
 	if (hb->seq_stride == 0) {
 		unsigned long long cur = 0;
-		HIP_TRY2(hipMemcpy(&cur, dcur, 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(&cur, dcur, 8, hipMemcpyDeviceToHost));
 		used = cur < cap ? (size_t) cur : cap;
 	}
-	HIP_TRY2(hipMemcpy(hb->seq_nt, dnt, used, hipMemcpyDeviceToHost));
-	HIP_TRY2(hipMemcpy(hb->seq_p, dp, used * sizeof(double), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(hb->seq_nt, dnt, used, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(hb->seq_p, dp, used * sizeof(double), hipMemcpyDeviceToHost));
 	if (hb->seq_cursor)
-		HIP_TRY2(hipMemcpy(hb->seq_cursor, dcur, 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(hb->seq_cursor, dcur, 8, hipMemcpyDeviceToHost));
 	if (hb->counters) {
 		std::vector<int64_t> tmp(PAMD_NUM_COUNTERS);
-		HIP_TRY2(hipMemcpy(tmp.data(), dctr, PAMD_NUM_COUNTERS * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(tmp.data(), dctr, PAMD_NUM_COUNTERS * 8, hipMemcpyDeviceToHost));
 		for (int i = 0; i < PAMD_NUM_COUNTERS; i++)
 			hb->counters[i] += tmp[i];
 	}
-	fail(0);
 	if (overflow) {
 		pamd_set_error("output arena too small: %llu accepted pairs did not fit in seq_capacity=%zu bases", overflow, cap);
 		return PAMD_EINVAL;
