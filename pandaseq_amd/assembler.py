@@ -162,6 +162,11 @@ class Assembler:
         else:
             raise _lib.PamdError(f"module {name!r} is not fused on the device path")
 
+    def set_exact_sums(self, exact: bool):
+        """True (default): ordered sums, every output bit-identical to the reference.  False: any-order
+        sums with exactness guards on every decision (see include/pandaseq_amd.h)."""
+        check(lib().pamd_set_exact_sums(self._h, 1 if exact else 0))
+
     def clear_modules(self):
         check(lib().pamd_clear_modules(self._h))
 

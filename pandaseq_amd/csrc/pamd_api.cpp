@@ -60,6 +60,7 @@ struct pamd_assembler {
 	double primer_penalty = 0;
 	int n_modules = 0;
 	PamdModule modules[PAMD_MAX_MODULES];
+	int exact_sums = 1;
 	// tables
 	PamdTables tabs;
 	double *d_tables = nullptr;	// image for the current algorithm
@@ -278,6 +279,11 @@ int pamd_add_module_min_overlapbits(pamd_assembler *a, double bits) {	// plugin_
 	return PAMD_OK;
 }
 
+int pamd_set_exact_sums(pamd_assembler *a, int exact) {
+	a->exact_sums = exact ? 1 : 0;
+	return PAMD_OK;
+}
+
 int pamd_clear_modules(pamd_assembler *a) {
 	a->n_modules = 0;
 	return PAMD_OK;
@@ -387,6 +393,7 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.sb_pmatch = a->sb_pmatch;
 	p.sb_pmismatch = a->sb_pmismatch;
 	p.pear_random_base = a->pear_random_base;
+	p.exact_sums = a->exact_sums;
 	memcpy(p.modules, a->modules, sizeof p.modules);
 	for (int m = 0; m < a->n_modules; m++)
 		if (a->modules[m].kind == 1)
@@ -462,7 +469,7 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	a->last_waves = waves;
 	a->last_lds = (int) lds_bytes;
 
-	if (a->algo != PAMD_ALGO_SIMPLE_BAYES) {
+	if (a->algo != PAMD_ALGO_SIMPLE_BAYES && a->exact_sums) {
 		const size_t rows = (size_t) wgs * (size_t) waves * 8u;	// GROUP parked rows per wave
 		if (rows > a->scratch_rows) {
 			if (a->d_scratch)

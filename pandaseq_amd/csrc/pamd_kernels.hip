@@ -654,8 +654,8 @@ struct Carry {
 };
 
 // ---- one pair: everything up to its parked record ----------------------------------------------
-template <int ALGO, bool PHRED, int BPL>
-__device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, const WaveLds &L, WaveArena &arena, PendRec *slot_rec, int slot_idx, unsigned wave_gid, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt
+template <int ALGO, bool PHRED, int BPL, bool EXACT>
+__device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, unsigned *lctr, const WaveLds &L, WaveArena &arena, PendRec *slot_rec, int slot_idx, unsigned wave_gid, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt
 #ifdef PAMD_PHASE_TIMING
 	, u64 *ph_acc
 #endif
@@ -663,6 +663,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 	const uint4 fregs = cur.f, rregs = cur.r;
 	PH_DECL;
 	bool rotated = false;
+	double quality_fast = 0.0;
+	u64 row_need = 0;	// arena bases taken by this pair's row (compact mode), given back if it is rejected
 	const int minov = P.minoverlap;
 	const unsigned hmask = P.hash_slots - 1u;
 	const unsigned hshift = P.hash_shift;
@@ -923,7 +925,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			// any-order sums (error < 1e-9) whenever every comparison is clearer than 1e-6, and its exact
 			// ordered sum is left to the group finish as a fourth chain over the parked terms.  Any
 			// comparison closer than that falls back to summing every candidate in reference order here.
-			bool ambiguous = ALGO == PAMD_ALGO_SIMPLE_BAYES || P.score_scratch == nullptr;
+			bool ambiguous = ALGO == PAMD_ALGO_SIMPLE_BAYES || (EXACT && P.score_scratch == nullptr);
 			if (ALGO != PAMD_ALGO_SIMPLE_BAYES && !ambiguous) {
 				int last_ov = -1;
 				u64 words = __ballot(mybits != 0);
@@ -948,9 +950,22 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 					}
 				}
 				if (!ambiguous && bo >= 0) {
-					if (last_ov != bo)
-						score_terms<ALGO>(P, ltab, L, flen, rlen, bo, lane);
-					score_parked = bo;	// stored to the scratch row once the prefetch registers are rotated in
+					if (EXACT) {
+						if (last_ov != bo)
+							score_terms<ALGO>(P, ltab, L, flen, rlen, bo, lane);
+						score_parked = bo;	// stored to the scratch row once the prefetch registers are rotated in
+					} else {
+						// fast sums: `best` (any-order, |error| < 1e-9) is what gets reported; the one
+						// decision that still depends on it is min_overlapbits, re-done exactly if close
+						for (int mi = 0; mi < P.n_modules; mi++) {
+							const PamdModule md = P.modules[mi];
+							if (md.kind == 2 && fabs(md.nats - best) <= 1e-6) {
+								score_terms<ALGO>(P, ltab, L, flen, rlen, bo, lane);
+								best = sum_terms_exact(L, bo, lane);
+								break;
+							}
+						}
+					}
 				}
 			}
 			if (ambiguous) {
@@ -1060,6 +1075,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		double qual_nn = P.qual_nn;
 		asm volatile("" : "+v"(qual_nn));
 		int mism = 0, degen = 0, phmin = 127;
+		double qacc = 0.0;	// fast sums: this lane's share of the quality sum, any order
 		bool low_p = false;
 		double pmin = 0.0;	// every log-p is <= 0
 		const double qs0 = want_phred ? ltab[PAMD_LT_SCORE] : 0.0;
@@ -1074,6 +1090,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const double q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
 				L.nts[j] = (uint8_t) nt;
 				L.ps[j] = q;
+				if (!EXACT)
+					qacc += q;
 				// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
 				// it (checked over every breakpoint in tests/test_oracle_cpu.py), so the smallest phred of
 				// the row follows from "any p at or below qual_score[0]" and the smallest p above it
@@ -1118,6 +1136,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				nt = match ? (a & b) : (fq < rq ? b : a);	// assembler.c:212-220
 				L.nts[A + i] = (uint8_t) nt;
 				L.ps[A + i] = q;
+				if (!EXACT)
+					qacc += q;
 				// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
 				// it (checked over every breakpoint in tests/test_oracle_cpu.py), so the smallest phred of
 				// the row follows from "any p at or below qual_score[0]" and the smallest p above it
@@ -1138,6 +1158,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const double q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
 				L.nts[A + novl + i] = (uint8_t) nt;
 				L.ps[A + novl + i] = q;
+				if (!EXACT)
+					qacc += q;
 				// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
 				// it (checked over every breakpoint in tests/test_oracle_cpu.py), so the smallest phred of
 				// the row follows from "any p at or below qual_score[0]" and the smallest p above it
@@ -1169,6 +1191,32 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		}
 		rec.mism = mism;
 		rec.degen = degen;
+		row_need = P.seq_stride == 0 && store ? need : 0;
+		if (!EXACT) {
+			// quality from the any-order sum (|error| ~1e-12); the LOWQ verdict is the only consumer that
+			// could notice, so within 1e-9 of the threshold the three sums are redone in reference order
+			for (int o = 32; o > 0; o >>= 1)
+				qacc += __shfl_xor(qacc, o);
+			quality_fast = uni_f64(qacc) / (double) len;
+			if (fabs(quality_fast - P.threshold) <= 1e-9) {
+				wave_sync();
+				double acc = 0.0;
+				int lo = 0, hi = 0;
+				if (lane == 0) {
+					hi = A;
+				} else if (lane == 1) {
+					lo = A + novl;
+					hi = seqlen;
+				} else if (lane == 2) {
+					lo = A;
+					hi = A + novl;
+				}
+				for (int j = lo; j < hi; j++)
+					acc += L.ps[j];
+				const double fq = lane_f64(acc, 0), rq = lane_f64(acc, 1), oq = lane_f64(acc, 2);
+				quality_fast = (fq + rq + oq) / (double) len;	// assembler.c:244
+			}
+		}
 	} while (0);
 	if (!rotated) {
 		cur = nxt;
@@ -1176,11 +1224,64 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 	}
 	rec.st = status;
 	PH_MARK(7);
-	if (lane == 0)
-		*slot_rec = rec;	// park it; finish_group() does the rest
+	if (EXACT) {
+		if (lane == 0)
+			*slot_rec = rec;	// park it; finish_group() does the rest
+		return;
+	}
+	// fast sums: nothing is pending, finish the pair here (same steps as finish_group's tail)
+	int reject = -1;
+	u64 off = ~0ull;
+	if (status == PAMD_ST_OK) {
+		if (rec.off == ~0ull && lane == 0)
+			atomicAdd(P.error_flag, 1ull);
+		if (quality_fast < P.threshold) {	// assembler.c:334-338
+			status = PAMD_ST_LOWQ;
+		} else {
+			for (int mi = 0; mi < P.n_modules && reject < 0; mi++) {	// module.c:124-136
+				const PamdModule md = P.modules[mi];
+				if (md.kind == 1) {
+					if (rec.phmin < md.phred)
+						reject = mi;
+				} else if (md.kind == 2) {
+					if (!(md.nats <= rec.best))
+						reject = mi;
+				}
+			}
+			if (reject >= 0)
+				status = PAMD_ST_REJECT;
+			else
+				off = rec.off;
+		}
+		if (status != PAMD_ST_OK)
+			arena.cur -= row_need;	// the row of a rejected pair is the arena's newest piece: hand it back
+	}
+	if (lane == 0) {
+		union {
+			double d;
+			unsigned u[2];
+		} q, e;
+		q.d = quality_fast;
+		e.d = rec.best;
+		uint4 *dst = reinterpret_cast<uint4 *>(&P.results[pair]);
+		dst[0] = make_uint4(q.u[0], q.u[1], e.u[0], e.u[1]);
+		dst[1] = make_uint4((unsigned) off, (unsigned) (off >> 32), (unsigned) rec.seqlen | ((unsigned) rec.bo << 16), (unsigned) rec.examined | ((unsigned) rec.mism << 16));
+		dst[2] = make_uint4((unsigned) rec.degen | ((unsigned) rec.fo << 16), (unsigned) rec.ro | ((unsigned) status << 16) | (((unsigned) reject & 0xFFu) << 24), (unsigned) rec.slow, 0u);
+		atomicAdd(&lctr[PAMD_CTR_COUNT], 1u);
+		if (rec.slow)
+			atomicAdd(&lctr[PAMD_CTR_SLOW], 1u);
+		const int ctr_of[6] = { PAMD_CTR_OK, PAMD_CTR_BADR, PAMD_CTR_NOFP, PAMD_CTR_NORP, PAMD_CTR_NOALGN, PAMD_CTR_LOWQ };
+		if (status == PAMD_ST_REJECT) {
+			atomicAdd(&lctr[PAMD_CTR_REJECTED0 + reject], 1u);
+		} else {
+			atomicAdd(&lctr[ctr_of[status]], 1u);
+			if (status == PAMD_ST_OK)
+				atomicAdd(&lctr[PAMD_CTR_OVERLAP0 + rec.bo], 1u);
+		}
+	}
 }
 
-template <int ALGO, bool PHRED, int BPL>
+template <int ALGO, bool PHRED, int BPL, bool EXACT>
 __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	double *ltab = reinterpret_cast<double *>(lds);
@@ -1252,12 +1353,13 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		nxt.r = load_read<BPL>(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
 #ifdef PAMD_PHASE_TIMING
-		assemble_pair<ALGO, PHRED, BPL>(P, ltab, lprimers, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt, ph_acc);
+		assemble_pair<ALGO, PHRED, BPL, EXACT>(P, ltab, lprimers, lctr, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt, ph_acc);
 #else
-		assemble_pair<ALGO, PHRED, BPL>(P, ltab, lprimers, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt);
+		assemble_pair<ALGO, PHRED, BPL, EXACT>(P, ltab, lprimers, lctr, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt);
 #endif
-		npend++;
-		if (npend == GROUP) {
+		if (EXACT)
+			npend++;
+		if (EXACT && npend == GROUP) {
 #ifdef PAMD_PHASE_TIMING
 			const u64 t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1383,7 +1485,8 @@ int pamd_launch_assemble(const PamdKernelParams &p, int workgroups, int waves_pe
 	void (*kern)(const PamdKernelParams) = nullptr;
 	const bool ph = p.has_min_phred != 0;
 	const bool narrow = p.smax <= 256;	// 4 bases per lane while staging
-#define PAMD_PICK(A) (ph ? (narrow ? pamd_assemble_kernel<A, true, 4> : pamd_assemble_kernel<A, true, 8>) : (narrow ? pamd_assemble_kernel<A, false, 4> : pamd_assemble_kernel<A, false, 8>))
+#define PAMD_PICK3(A, PH, B) (p.exact_sums ? pamd_assemble_kernel<A, PH, B, true> : pamd_assemble_kernel<A, PH, B, false>)
+#define PAMD_PICK(A) (ph ? (narrow ? PAMD_PICK3(A, true, 4) : PAMD_PICK3(A, true, 8)) : (narrow ? PAMD_PICK3(A, false, 4) : PAMD_PICK3(A, false, 8)))
 	switch (p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
 		kern = PAMD_PICK(PAMD_ALGO_SIMPLE_BAYES);
@@ -1399,6 +1502,7 @@ int pamd_launch_assemble(const PamdKernelParams &p, int workgroups, int waves_pe
 		return PAMD_EINVAL;
 	}
 #undef PAMD_PICK
+#undef PAMD_PICK3
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 	if (e != hipSuccess) {
 		pamd_set_error("hipFuncSetAttribute(%zu bytes LDS): %s", lds_bytes, hipGetErrorString(e));

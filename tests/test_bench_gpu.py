@@ -18,7 +18,7 @@ def _check(line, n_gpus, steps, warmup):
     assert REQUIRED <= set(d), REQUIRED - set(d)
     assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
     assert d["unit"] == "pairs/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert "workload" in d["config"] and "model" not in d["config"]
+    assert "workload" in d["config"] and "model" not in d["config"] and "sums" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12

@@ -22,9 +22,15 @@ def _oracle(algo, fwd, rev, flen, rlen, **kw):
     return po.assemble_batch(po.make_config(algo, **kw), fwd, rev, flen, rlen)
 
 
+@pytest.fixture(params=["exact", "fast"])
+def sums(request):
+    """Both summation modes of the library (include/pandaseq_amd.h, pamd_set_exact_sums)."""
+    return request.param
+
+
 @pytest.mark.parametrize("algo", ["simple_bayesian", "pear", "rdp_mle"])
 @pytest.mark.parametrize("cfg", [0, 1, 4])
-def test_synthetic_configs(built, algo, cfg):
+def test_synthetic_configs(built, algo, cfg, sums):
     import pandaseq_amd as pa
     from pandaseq_amd import synth
     spec = synth.config_spec(cfg)
@@ -32,14 +38,15 @@ def test_synthetic_configs(built, algo, cfg):
     fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
     asm = pa.Assembler(0)
     asm.set_algorithm(algo)
+    asm.set_exact_sums(sums == "exact")
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
     o_res, o_nt, o_p, o_ctr = _oracle(algo, fwd, rev, flen, rlen)
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), o_res, o_nt, o_p)
+    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), o_res, o_nt, o_p, exact_sums=sums == "exact")
     compare_counters(b.counters_dict(), o_ctr)
 
 
 @pytest.mark.parametrize("algo", ["simple_bayesian", "pear", "rdp_mle"])
-def test_adversarial_strided(built, algo):
+def test_adversarial_strided(built, algo, sums):
     import pandaseq_amd as pa
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
@@ -49,9 +56,10 @@ def test_adversarial_strided(built, algo):
         rlen = np.minimum(rlen, flen)
     asm = pa.Assembler(0)
     asm.set_algorithm(algo)
+    asm.set_exact_sums(sums == "exact")
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=512)
     o_res, o_nt, o_p, o_ctr = _oracle(algo, fwd, rev, flen, rlen)
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), o_res, o_nt, o_p, seq_stride=512)
+    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), o_res, o_nt, o_p, seq_stride=512, exact_sums=sums == "exact")
     compare_counters(b.counters_dict(), o_ctr)
 
 
@@ -71,11 +79,12 @@ def test_synth_device_matches_numpy(built):
         assert np.array_equal(drl.cpu().numpy().view(np.uint16), rl)
 
 
-def _asm_for(algo, spec=None, primers=False, modules=(), **settings):
+def _asm_for(algo, spec=None, primers=False, modules=(), exact=True, **settings):
     import pandaseq_amd as pa
     from pandaseq_amd import synth
     asm = pa.Assembler(0)
     asm.set_algorithm(algo)
+    asm.set_exact_sums(exact)
     if primers:
         asm.set_forward_primer(synth.nt_codes(spec.fprimer))
         asm.set_reverse_primer(synth.nt_codes(spec.rprimer, complement=True))
@@ -86,7 +95,7 @@ def _asm_for(algo, spec=None, primers=False, modules=(), **settings):
     return asm
 
 
-def test_config2_primers_pear(built):
+def test_config2_primers_pear(built, sums):
     """BASELINE configs[2]: 2x300 with embedded primers, -p/-q, pear."""
     from pandaseq_amd import synth
     spec = synth.config_spec(2)
@@ -98,10 +107,10 @@ def test_config2_primers_pear(built):
         rev[i + 1, :17, 0] = rng.choice(np.array([1, 2, 4, 8], np.uint8), 17)
     flen[300] = 10
     rlen[301] = 16
-    asm = _asm_for("pear", spec, primers=True)
+    asm = _asm_for("pear", spec, primers=True, exact=sums == "exact")
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
     o = _oracle("pear", fwd, rev, flen, rlen, fprimer=synth.nt_codes(spec.fprimer), rprimer=synth.nt_codes(spec.rprimer, complement=True))
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
     compare_counters(b.counters_dict(), o[3])
     assert o[3]["ok"] > 4000 and (o[0]["fwd_offset"][o[0]["status"] == 0] >= 17).all()
 
@@ -120,16 +129,16 @@ def test_primers_all_algorithms_with_penalty(built, penalty):
         compare_counters(b.counters_dict(), o[3])
 
 
-def test_config3_rdp_with_modules(built):
+def test_config3_rdp_with_modules(built, sums):
     """BASELINE configs[3]: rdp_mle + min_phred + min_overlapbits, modules applied in order."""
     from pandaseq_amd import synth
     spec = synth.config_spec(3)
     fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 6000)
     for mods in ([("min_phred", 2), ("min_overlapbits", 15)], [("min_overlapbits", 40), ("min_phred", 1)], [("min_phred", 10)]):
-        asm = _asm_for("rdp_mle", modules=[f"{k}:{v}" for k, v in mods])
+        asm = _asm_for("rdp_mle", modules=[f"{k}:{v}" for k, v in mods], exact=sums == "exact")
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
         o = _oracle("rdp_mle", fwd, rev, flen, rlen, modules=mods)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
         compare_counters(b.counters_dict(), o[3])
         assert sum(o[3]["rejected"]) > 0
 
@@ -138,7 +147,7 @@ def test_config3_rdp_with_modules(built):
     dict(minimum_overlap=10), dict(minimum_overlap=60, maximum_overlap=100), dict(maximum_overlap=400),
     dict(threshold=0.9), dict(threshold=0.3), dict(forward_trim=5, reverse_trim=11), dict(maximum_overlap=120, forward_trim=30),
 ])
-def test_assembler_settings(built, settings):
+def test_assembler_settings(built, settings, sums):
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
     fwd, rev, flen, rlen = adversarial_pairs(spec, 3000, seed=5)
@@ -146,10 +155,10 @@ def test_assembler_settings(built, settings):
     for k, v in settings.items():
         okw[{"minimum_overlap": "minoverlap", "maximum_overlap": "maxoverlap", "forward_trim": "ftrim", "reverse_trim": "rtrim"}.get(k, k)] = v
     for algo in ("simple_bayesian", "rdp_mle"):
-        asm = _asm_for(algo, **settings)
+        asm = _asm_for(algo, exact=sums == "exact", **settings)
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
         o = _oracle(algo, fwd, rev, flen, rlen, **okw)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
         compare_counters(b.counters_dict(), o[3])
 
 
@@ -171,16 +180,16 @@ def test_algorithm_parameters(built):
     compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
 
 
-def test_max_length_reads(built):
+def test_max_length_reads(built, sums):
     """PANDA_MAX_LEN = 450 reads: the widest rows, the longest merges (899) and the smallest launch geometry."""
     from pandaseq_amd import synth
     spec = synth.SynthSpec(seed=77, read_len=450, tmin=450, tmax=899, qhi=40)
     fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 1500)
     for algo in ("simple_bayesian", "pear", "rdp_mle"):
-        asm = _asm_for(algo)
+        asm = _asm_for(algo, exact=sums == "exact")
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
         o = _oracle(algo, fwd, rev, flen, rlen)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
         compare_counters(b.counters_dict(), o[3])
         assert o[0]["seq_len"].max() > 850
 

@@ -50,9 +50,12 @@ def adversarial_pairs(spec, n, seed=1, ragged=True, weird_quals=True, iupac=True
     return fwd, rev, flen, rlen
 
 
-def compare_results(dev_res, dev_nt, dev_p, ora_res, ora_nt, ora_p, seq_stride=None, check_seq=True):
-    """Bit-exact on every integer/index field and on the two f64 scalars; per-base p within P_TOL
-    (and reported if not exactly equal)."""
+SUM_TOL = 1e-9  # fast-sums mode: |quality - ref| and |est_overlap_prob - ref| (north_star allows 1e-6)
+
+
+def compare_results(dev_res, dev_nt, dev_p, ora_res, ora_nt, ora_p, seq_stride=None, check_seq=True, exact_sums=True):
+    """Bit-exact on every integer/index field; the two f64 scalars bit-exact in the default (exact-sums)
+    mode and within SUM_TOL in fast-sums mode; per-base p within P_TOL (and required to be exactly equal)."""
     n = len(ora_res)
     assert len(dev_res) == n
     st_d = dev_res["status"].astype(np.int64)
@@ -75,15 +78,21 @@ def compare_results(dev_res, dev_nt, dev_p, ora_res, ora_nt, ora_p, seq_stride=N
     offs = st_o >= 4
     assert np.array_equal(dev_res["fwd_offset"].astype(np.int64)[offs | (st_o == 0)], ora_res["fwd_offset"].astype(np.int64)[offs | (st_o == 0)])
     assert np.array_equal(dev_res["rev_offset"].astype(np.int64)[offs | (st_o == 0)], ora_res["rev_offset"].astype(np.int64)[offs | (st_o == 0)])
-    # f64 scalars: bit-exact
-    q_d = dev_res["quality"][merged].view(np.uint64)
-    q_o = ora_res["quality"][merged].view(np.uint64)
-    w = np.nonzero(q_d != q_o)[0]
-    assert w.size == 0, f"quality bits differ at {np.nonzero(merged)[0][w[:10]]}"
-    e_d = dev_res["est_overlap_prob"][merged].view(np.uint64)
-    e_o = ora_res["est_prob"][merged].view(np.uint64)
-    w = np.nonzero(e_d != e_o)[0]
-    assert w.size == 0, f"estimated_overlap_probability bits differ at {np.nonzero(merged)[0][w[:10]]}"
+    # f64 scalars
+    if exact_sums:
+        q_d = dev_res["quality"][merged].view(np.uint64)
+        q_o = ora_res["quality"][merged].view(np.uint64)
+        w = np.nonzero(q_d != q_o)[0]
+        assert w.size == 0, f"quality bits differ at {np.nonzero(merged)[0][w[:10]]}"
+        e_d = dev_res["est_overlap_prob"][merged].view(np.uint64)
+        e_o = ora_res["est_prob"][merged].view(np.uint64)
+        w = np.nonzero(e_d != e_o)[0]
+        assert w.size == 0, f"estimated_overlap_probability bits differ at {np.nonzero(merged)[0][w[:10]]}"
+    else:
+        dq = np.abs(dev_res["quality"][merged] - ora_res["quality"][merged])
+        de = np.abs(dev_res["est_overlap_prob"][merged] - ora_res["est_prob"][merged])
+        assert dq.size == 0 or dq.max() <= SUM_TOL, f"quality differs by {dq.max()}"
+        assert de.size == 0 or de.max() <= SUM_TOL, f"estimated_overlap_probability differs by {de.max()}"
     if not check_seq:
         return
     ok = np.nonzero(st_o == 0)[0]

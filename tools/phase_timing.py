@@ -27,7 +27,7 @@ import pandaseq_amd as pa
 from pandaseq_amd import _lib, synth
 import bench
 
-asm, spec = bench.setup_assembler(pa, synth, args.config, 0)
+asm, spec = bench.setup_assembler(pa, synth, args.config, 0, exact_sums=os.environ.get("PAMD_SUMS", "exact") == "exact")
 n = args.pairs
 f, r, fl, rl = synth.generate_device(spec, 0, n)
 outs = pa.alloc_outputs(n, n * 420 + (1 << 27), "cuda:0")

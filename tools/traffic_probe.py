@@ -23,7 +23,7 @@ import bench
 
 cfg = int(os.environ.get("PAMD_CONFIG", "1"))
 n = int(os.environ.get("PAMD_PAIRS", "8000000"))
-asm, spec = bench.setup_assembler(pa, synth, cfg, 0)
+asm, spec = bench.setup_assembler(pa, synth, cfg, 0, exact_sums=os.environ.get("PAMD_SUMS", "exact") == "exact")
 f, r, fl, rl = synth.generate_device(spec, 0, n)
 outs = pa.alloc_outputs(n, n * 440 + (1 << 27), "cuda:0")
 b = pa.DeviceBatch(n=n, fwd=f, rev=r, flen=fl, rlen=rl, **outs)
