@@ -307,3 +307,45 @@ def _row_checksums(b, res, ok, sample=4000):
         out[k, 0] = float(nt[off:off + m].double().sum().item())
         out[k, 1] = float(p[off:off + m].sum().item())
     return out
+
+
+def test_unequal_strides_and_api_validation(built):
+    """Forward and reverse rows may have different strides; bad strides / alignment / a missing cursor are
+    refused with an error (never silently computed)."""
+    import ctypes as C
+
+    import torch
+
+    import pandaseq_amd as pa
+    from pandaseq_amd import _lib, synth
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 1500)
+    # reverse reads truncated to 180 bases in a narrower row
+    rev2 = np.ascontiguousarray(rev[:, :184])
+    rlen2 = np.minimum(rlen, 180).astype(np.uint16)
+    asm = pa.Assembler(0)
+    b = _run(asm, fwd, rev2, flen, rlen2, seq_stride=0)
+    o = _oracle("simple_bayesian", fwd, rev2, flen, rlen2)
+    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+    compare_counters(b.counters_dict(), o[3])
+    # validation: stride not a multiple of 8
+    bad = pa.upload_batch(np.ascontiguousarray(fwd[:, :252]), rev, np.minimum(flen, 250), rlen, device="cuda:0", seq_stride=0)
+    with pytest.raises(pa.PamdError, match="multiples of 8"):
+        asm.assemble_device(bad)
+    # validation: seq_stride not a multiple of 16
+    b.seq_stride = 500
+    with pytest.raises(pa.PamdError, match="multiple of 16"):
+        asm.assemble_device(b)
+    torch.cuda.synchronize()
+
+
+def test_arena_overflow_is_reported(built):
+    """A compact arena that is too small must surface as an error from the host entry point, and the
+    pairs that did not fit must not claim a row."""
+    import pandaseq_amd as pa
+    from pandaseq_amd import synth
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 4000)
+    asm = pa.Assembler(0)
+    with pytest.raises(pa.PamdError, match="arena too small"):
+        asm.assemble_host(fwd, rev, flen, rlen, seq_stride=0, capacity=200_000)
