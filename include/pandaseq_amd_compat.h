@@ -181,6 +181,10 @@ PandaLogProxy panda_assembler_get_logger(PandaAssembler assembler);
 double panda_assembler_get_primer_penalty(PandaAssembler assembler);
 void panda_assembler_set_primer_penalty(PandaAssembler assembler, double threshold);
 
+/* ---- per-base helpers plugins call on the results they are handed (pandaseq-nt.h:76-88, nt.c:120-150) ---- */
+double panda_quality_log_probability(const panda_qual *q);	/* qual_score[PHREDCLAMP(q->qual)] */
+char panda_result_phred(const panda_result *r);			/* the reference's bisection over qual_score, quirks included */
+
 /* ---- extensions (not in the reference) ---- */
 /* which GPU new assemblers are created on (default 0), and how many pairs panda_assembler_next()
  * pulls from the source per kernel launch (default 16384) */

@@ -20,13 +20,18 @@
  *   tables  : PINNED -- compared value-for-value against table.c emitted by the
  *             reference's own mktable.c+tablebuilder.c compiled here
  *             (oracle/Makefile target `ref`, output in oracle/_ref/).
+ *   check modules (min_phred, min_overlapbits) and the result-record layout:
+ *             PINNED -- the reference's own plugin_min_phred.c / plugin_min_overlapbits.c
+ *             compile from their own files (oracle/Makefile `ref` -> _ref/*.so) and
+ *             are run over the device path's results
+ *             (tests/test_compat_gpu.py::test_reference_plugin_binaries).
  *   the rest: PARITY UNPINNED against a live reference build.  Every other
  *             reference .c includes the autoconf-generated config.h, and the
  *             assembler needs ltdl.h/bzlib.h, none of which exist in this
  *             image; writing stand-ins for them is not allowed, so the full
  *             reference is unbuildable here.  The only anchors are the
  *             known answers recorded in SURVEY.md from a real reference run
- *             (tests/test_oracle_known_answers.py).
+ *             (tests/test_oracle_cpu.py).
  */
 #ifndef PANDA_ORACLE_H
 #define PANDA_ORACLE_H

@@ -514,6 +514,46 @@ void ensure_staging(PandaAssembler a, size_t pairs) {
 
 extern "C" {
 
+// ---- per-base helpers (nt.c:120-150) ----
+// Plugins compiled against the reference headers call these on the panda_result rows they are
+// handed (plugin_min_phred.c:16).  The bisection keeps the reference's quirks: 1 at or below
+// qual_score[0] (= -2), "mid == lower" returns lower.
+static const PamdTables &host_tables() {
+	static PamdTables t;
+	static std::once_flag once;
+	std::call_once(once, [] { pamd_build_tables(&t); });
+	return t;
+}
+
+double panda_quality_log_probability(const panda_qual *q) {
+	int v = q->qual < 0 ? 0 : (q->qual > PAMD_NQ - 1 ? PAMD_NQ - 1 : q->qual);
+	return host_tables().score[v];
+}
+
+char panda_result_phred(const panda_result *r) {
+	// same walk as result_phred() in pamd_kernels.hip, on the host copy of qual_score
+	const double *qs = host_tables().score;
+	const double p = r->p;
+	if (p <= qs[0])
+		return 1;
+	int lo = 0, hi = PAMD_NQ - 1;
+	while (lo < hi) {
+		const int mid = lo + (hi - lo) / 2;
+		const double s = qs[mid];
+		if (s == p)
+			return (char) mid;
+		if (mid == lo)
+			break;
+		if (s > p)
+			hi = mid;
+		else if (s < p)
+			lo = mid + 1;
+		else
+			break;	// NaN: the reference would spin forever; stop at the current lower bound
+	}
+	return (char) lo;
+}
+
 void pamd_compat_set_device(int device) {
 	g_device = device;
 }

@@ -6,6 +6,14 @@
  * usage: test_compat <pairs.bin> <out.bin> <algo> <mode>
  *   pairs.bin: u32 n, u32 stride, then n * (u16 flen, u16 rlen, stride*2 bytes fwd, stride*2 bytes rev)
  *   mode 0: plain;  mode 1: fused min_overlapbits:15 + host check module + precheck module
+ *   mode 2: <plugin.so> <module name> <args, or "(null)" for no ":args" at all>: a check plugin BINARY compiled from the reference's own
+ *           plugin source (oracle/Makefile `ref`), opened the way module.c:227-298 does (dlopen, its
+ *           <name>_LTX_opener) and attached as a host callback with panda_module_new
+ *   mode 3: <name:args>: the same filter fused on the device (panda_module_load)
+ *   counters[8] = sequences rejected by the first module (panda_assembler_foreach_module)
+ *
+ * With -DUSE_REFERENCE_HEADERS the client is compiled against the reference's own pandaseq.h instead of
+ * include/pandaseq_amd_compat.h: the structs this program reads are then laid out by the reference.
  *   out.bin: per returned result: u32 index, u32 overlap, u32 seq_len, u32 mism, u32 degen, u32 fo, u32 ro, u32 examined,
  *            f64 quality, f64 est, seq_len nt bytes, seq_len f64;  then u32 0xFFFFFFFF and 10 i64 counters
  */
@@ -13,7 +21,38 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef USE_REFERENCE_HEADERS
+#include <pandaseq.h>
+void pamd_compat_set_batch_pairs(size_t pairs);
+#else
 #include "pandaseq_amd_compat.h"
+#endif
+#include <dlfcn.h>
+#include <stdarg.h>
+
+/* Plugins report bad arguments through the log proxy, which is not on the path and not part of
+ * libpandaseq_amd (in a real integration the reference's proxy.c provides these).  The plugin binaries
+ * resolve them from this executable (-rdynamic); they are only reached on malformed arguments. */
+void panda_log_proxy_write_str(PandaLogProxy proxy, const char *str) {
+	(void) proxy;
+	fprintf(stderr, "plugin: %s", str);
+}
+
+void panda_log_proxy_write_f(PandaLogProxy proxy, const char *format, ...) {
+	va_list va;
+	(void) proxy;
+	va_start(va, format);
+	vfprintf(stderr, format, va);
+	va_end(va);
+}
+
+typedef bool (*plugin_opener) (PandaLogProxy logger, const char *args, PandaPreCheck *precheck, PandaCheck *check, void **user_data, PandaDestroy *destroy);
+
+static bool first_rejected(PandaAssembler a, PandaModule m, size_t rejected, void *data) {
+	(void) a; (void) m;
+	*(int64_t *) data = (int64_t) rejected;
+	return false;
+}
 
 struct source {
 	uint32_t n, stride, pos;
@@ -110,6 +149,39 @@ int main(int argc, char **argv) {
 		panda_module_unref(m2);
 		panda_module_unref(m3);
 	}
+	if (mode == 2) {
+		if (argc < 8)
+			return 2;
+		void *h = dlopen(argv[5], RTLD_NOW | RTLD_LOCAL);
+		if (h == NULL) {
+			fprintf(stderr, "%s\n", dlerror());
+			return 7;
+		}
+		char sym[128];
+		snprintf(sym, sizeof sym, "%s_LTX_opener", argv[6]);
+		plugin_opener opener = (plugin_opener) dlsym(h, sym);
+		snprintf(sym, sizeof sym, "%s_LTX_api", argv[6]);
+		int *api = dlsym(h, sym);
+		PandaCheck check = NULL;
+		PandaPreCheck precheck = NULL;
+		void *user_data = NULL;
+		PandaDestroy destroy = NULL;
+		if (opener == NULL || api == NULL || *api != 3 /* PANDA_API, pandaseq-common.h */ || !opener(NULL, strcmp(argv[7], "(null)") == 0 ? NULL : argv[7], &precheck, &check, &user_data, &destroy))
+			return 7;
+		PandaModule m = panda_module_new(argv[6], check, precheck, user_data, destroy);
+		if (m == NULL)
+			return 5;
+		panda_assembler_add_module(a, m);
+		panda_module_unref(m);
+	} else if (mode == 3) {
+		if (argc < 6)
+			return 2;
+		PandaModule m = panda_module_load(NULL, argv[5]);
+		if (m == NULL)
+			return 5;
+		panda_assembler_add_module(a, m);
+		panda_module_unref(m);
+	}
 	/* getters mirror what was set, with the reference's conversions */
 	if (panda_assembler_get_minimum_overlap(a) != 2 || panda_assembler_get_maximum_overlap(a) != 0 || panda_assembler_get_num_kmer(a) != 2)
 		return 6;
@@ -123,8 +195,8 @@ int main(int argc, char **argv) {
 	uint32_t end = 0xFFFFFFFFu;
 	fwrite(&end, 4, 1, out);
 	int64_t c[10] = { panda_assembler_get_count(a), panda_assembler_get_ok_count(a), panda_assembler_get_failed_alignment_count(a), panda_assembler_get_low_quality_count(a), panda_assembler_get_bad_read_count(a), panda_assembler_get_slow_count(a), (int64_t) panda_assembler_get_longest_overlap(a), noalgn_seen, 0, 0 };
-	struct { int64_t r[3]; } rej = { { 0, 0, 0 } };
-	(void) rej;
+	if (mode >= 2)
+		panda_assembler_foreach_module(a, first_rejected, &c[8]);
 	fwrite(c, 8, 10, out);
 
 	/* the single-pair entry point on the first pairs of the same input, through a second assembler

@@ -15,7 +15,7 @@ def _build_client(tmp):
     exe = os.path.join(tmp, "test_compat")
     subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "c", "test_compat.c"), "-o", exe,
-                           "-L", os.path.join(ROOT, "pandaseq_amd"), "-lpandaseq_amd",
+                           "-rdynamic", "-L", os.path.join(ROOT, "pandaseq_amd"), "-lpandaseq_amd", "-ldl",
                            "-Wl,-rpath," + os.path.join(ROOT, "pandaseq_amd"), "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
@@ -33,6 +33,72 @@ def _read_record(buf, o):
     return dict(index=h[0], overlap=h[1], seq_len=m, mism=h[3], degen=h[4], fo=h[5], ro=h[6], examined=h[7], quality=q, est=e, nt=nt, p=p), o
 
 
+def _write_pairs(path, fwd, rev, flen, rlen):
+    n, stride = fwd.shape[0], fwd.shape[1]
+    blob = bytearray(struct.pack("<2I", n, stride))
+    for i in range(n):
+        blob += struct.pack("<2H", int(flen[i]), int(rlen[i])) + fwd[i].tobytes() + rev[i].tobytes()
+    path.write_bytes(bytes(blob))
+
+
+def _parse_output(buf):
+    o = 0
+    got = []
+    while struct.unpack_from("<I", buf, o)[0] != 0xFFFFFFFF:
+        rec, o = _read_record(buf, o)
+        got.append(rec)
+    o += 4
+    counters = struct.unpack_from("<10q", buf, o)
+    return got, counters, o + 80
+
+
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+@pytest.mark.parametrize("algo,plugin,args", [("simple_bayesian", "min_phred", "4"), ("rdp_mle", "min_phred", "10"),
+                                              ("rdp_mle", "min_overlapbits", "15"), ("pear", "min_overlapbits", "2.5"),
+                                              ("simple_bayesian", "min_overlapbits", None), ("rdp_mle", "min_overlapbits", "")])
+def test_reference_plugin_binaries(built, tmp_path, algo, plugin, args):
+    """The reference's OWN check plugins, compiled from its plugin_*.c (oracle/Makefile `ref`), run as host
+    callbacks over the results the GPU path returns -- in a client compiled against the reference's own
+    pandaseq.h -- and must keep/reject exactly the pairs the fused device filter keeps/rejects (and the
+    oracle says).  This pins rows a15/a16 and the panda_result_seq / panda_result layout (a17) on real
+    reference code."""
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    from util import adversarial_pairs
+    client = os.path.join(REF_DIR, "refclient")
+    so = os.path.join(REF_DIR, plugin + ".so")
+    if not (os.path.exists(client) and os.path.exists(so)):
+        pytest.skip("oracle/_ref was not built (needs /root/reference at build time: make -C oracle ref)")
+    spec = synth.config_spec(1)
+    n = 2500
+    fwd, rev, flen, rlen = adversarial_pairs(spec, n, seed=33)
+    if algo == "pear":
+        rlen = np.minimum(rlen, flen)
+    pin = tmp_path / "pairs.bin"
+    _write_pairs(pin, fwd, rev, flen, rlen)
+    out_host, out_fused, out_ours = tmp_path / "host.bin", tmp_path / "fused.bin", tmp_path / "ours.bin"
+    subprocess.check_call([client, str(pin), str(out_host), algo, "2", so, plugin, "(null)" if args is None else args], timeout=300)
+    spec_str = plugin if args is None else plugin + ":" + args    # module.c:280: no colon -> NULL args
+    subprocess.check_call([client, str(pin), str(out_fused), algo, "3", spec_str], timeout=300)
+    # the same client compiled against OUR compat header must see the same bytes (header layouts agree)
+    subprocess.check_call([_build_client(str(tmp_path)), str(pin), str(out_ours), algo, "3", spec_str], timeout=300)
+    host, fused = out_host.read_bytes(), out_fused.read_bytes()
+    assert host == fused, "reference plugin on the host and the fused device filter disagree"
+    assert out_ours.read_bytes() == fused
+    got, counters, _ = _parse_output(fused)
+    val = 15.0 if args is None else (float(args) if args else 0.0)    # plugin_min_overlapbits.c:26-33
+    o_res, o_nt, o_p, o_ctr = po.assemble_batch(po.make_config(algo, modules=[(plugin, int(val) if plugin == "min_phred" else val)]), fwd, rev, flen, rlen)
+    expected = [i for i in range(n) if flen[i] >= 2 and rlen[i] >= 2 and o_res["status"][i] == 0]
+    assert [g["index"] for g in got] == expected
+    assert counters[8] == o_ctr["rejected"][0] and counters[8] > 0, "the filter must reject something for the test to mean anything"
+    for g in got[:200]:
+        i = g["index"]
+        assert g["quality"] == o_res["quality"][i] and g["est"] == o_res["est_prob"][i]
+        assert np.array_equal(g["nt"], o_nt[i, :g["seq_len"]]) and np.array_equal(g["p"], o_p[i, :g["seq_len"]])
+
+
 @pytest.mark.parametrize("algo,mode", [("simple_bayesian", 0), ("pear", 0), ("rdp_mle", 1)])
 def test_reference_api_client(built, tmp_path, algo, mode):
     from oracle import pyoracle as po
@@ -43,13 +109,9 @@ def test_reference_api_client(built, tmp_path, algo, mode):
     fwd, rev, flen, rlen = adversarial_pairs(spec, n, seed=21)
     if algo == "pear":
         rlen = np.minimum(rlen, flen)
-    stride = fwd.shape[1]
-    blob = bytearray(struct.pack("<2I", n, stride))
-    for i in range(n):
-        blob += struct.pack("<2H", int(flen[i]), int(rlen[i])) + fwd[i].tobytes() + rev[i].tobytes()
     pin = tmp_path / "pairs.bin"
     pout = tmp_path / "out.bin"
-    pin.write_bytes(bytes(blob))
+    _write_pairs(pin, fwd, rev, flen, rlen)
     exe = _build_client(str(tmp_path))
     subprocess.check_call([exe, str(pin), str(pout), algo, str(mode)], timeout=300)
     buf = pout.read_bytes()

@@ -113,6 +113,37 @@ def test_phred_is_one_below_qs0_and_monotone_above(po):
     assert (np.diff(ph) >= 0).all() and ph.min() == 0 and ph.max() == 45
 
 
+def test_exported_result_phred_matches_oracle(po, built):
+    """libpandaseq_amd's host panda_result_phred / panda_quality_log_probability (what a reference-compiled
+    plugin binary links against, plugin_min_phred.c:16) against the oracle's restatement of nt.c:120-150
+    at every breakpoint, its neighbours, and a dense grid."""
+    from pandaseq_amd import _lib
+
+    class Result(C.Structure):
+        _fields_ = [("nt", C.c_char), ("p", C.c_double)]
+
+    class Qual(C.Structure):
+        _fields_ = [("nt", C.c_char), ("qual", C.c_byte)]
+
+    assert C.sizeof(Result) == 16 and C.sizeof(Qual) == 2
+    P = _lib.lib()
+    P.panda_result_phred.restype = C.c_byte
+    P.panda_result_phred.argtypes = [C.POINTER(Result)]
+    P.panda_quality_log_probability.restype = C.c_double
+    P.panda_quality_log_probability.argtypes = [C.POINTER(Qual)]
+    t = po.tables()
+    L = po.lib()
+    qs = po.tables_np()["score"]
+    pts = {-1e300, -700.0, -2.0, 0.0, 1.0, -1.38629}
+    for v in qs:
+        pts |= {float(np.nextafter(v, -np.inf)), float(v), float(np.nextafter(v, np.inf))}
+    pts |= {float(v) for v in np.linspace(-3.0, 0.0, 5001)}
+    for v in sorted(pts):
+        assert P.panda_result_phred(C.byref(Result(b"\x01", v))) == L.po_result_phred(C.byref(t), v), v
+    for q in range(-128, 128):
+        assert P.panda_quality_log_probability(C.byref(Qual(b"\x01", q))) == qs[min(max(q, 0), 46)]
+
+
 def test_kmer_iterator_rules(po):
     """misc.h:41-45: first forward k-mer at position 8; a 9-wide N exclusion window; A and ambiguity codes hash as 0."""
     L = po.lib()
