@@ -764,7 +764,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			const unsigned kmer = __builtin_amdgcn_alignbit(L.fc[(sc >> 4) + 1], L.fc[sc >> 4], 2u * ((unsigned) sc & 15u)) & 0xFFFFu;
 			if (inr && nwin == 0) {
 				const unsigned word = (kmer << 16) | (unsigned) p;
-				unsigned slot = kmer_hash(kmer, hshift);
+				unsigned slot = kmer_hash(kmer, hshift) & ~1u;	// chains start on a slot pair (see the probe)
 				while (atomicCAS(&L.hash[slot], HASH_EMPTY, word) != HASH_EMPTY)
 					slot = (slot + 1) & hmask;
 			}
@@ -780,34 +780,30 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			const unsigned x = __builtin_amdgcn_alignbit(L.rc[(sp >> 4) + 1], L.rc[sp >> 4], 2u * ((unsigned) sp & 15u)) & 0xFFFFu;
 			if (inr && nwin == 0) {
 				const unsigned kmer = __builtin_bitreverse32(x) >> 16;
-				unsigned slot = kmer_hash(kmer, hshift);
-				unsigned m1 = 0xFFFFu, m2 = 0xFFFFu;
-				// walk the probe chain two slots per step (both reads are issued together); keep the two
-				// smallest forward positions of this k-mer, which are the reference's first two
+				const unsigned kk = kmer << 16;
+				unsigned slot = kmer_hash(kmer, hshift) & ~1u;
+				// Walk the probe chain one aligned slot pair per step and keep the two smallest forward
+				// positions of this k-mer, which are the reference's first two.  entry ^ (kmer << 16) is the
+				// bare position (< 0x10000) for an entry of this k-mer and >= 0x10000 for any other k-mer;
+				// an empty slot gives >= 0xFFFF, above every real position, so plain unsigned minima do it.
+				unsigned m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
 				bool more = true;
 				while (more) {
-					const unsigned w0 = L.hash[slot];
-					const unsigned w1 = L.hash[(slot + 1) & hmask];
-					const bool live0 = w0 != HASH_EMPTY;
-					const bool live1 = live0 && w1 != HASH_EMPTY;
-					const unsigned pos0 = (live0 && (w0 >> 16) == kmer) ? (w0 & 0xFFFFu) : 0xFFFFu;
-					const unsigned pos1 = (live1 && (w1 >> 16) == kmer) ? (w1 & 0xFFFFu) : 0xFFFFu;
-					unsigned lo = pos0 < m1 ? pos0 : m1;
-					unsigned mid = pos0 < m1 ? m1 : pos0;
-					m1 = lo;
-					m2 = mid < m2 ? mid : m2;
-					lo = pos1 < m1 ? pos1 : m1;
-					mid = pos1 < m1 ? m1 : pos1;
-					m1 = lo;
-					m2 = mid < m2 ? mid : m2;
+					const uint2 w = *reinterpret_cast<const uint2 *>(&L.hash[slot]);
+					const unsigned x0 = w.x ^ kk, x1 = w.y ^ kk;
+					const unsigned lo0 = x0 < m1 ? x0 : m1, hi0 = x0 < m1 ? m1 : x0;
+					const unsigned lo1 = x1 < lo0 ? x1 : lo0, hi1 = x1 < lo0 ? lo0 : x1;
+					const unsigned h = hi0 < hi1 ? hi0 : hi1;
+					m2 = h < m2 ? h : m2;
+					m1 = lo1;
 					slot = (slot + 2) & hmask;
-					more = live1;
+					more = w.x != HASH_EMPTY && w.y != HASH_EMPTY;
 				}
-				if (m1 != 0xFFFFu) {
+				if (m1 < 0xFFFFu) {
 					const int idx = flen + rlen - p - (int) m1 - minov - 1;	// assembler.c:107
 					if (idx >= 0 && idx < size)
 						atomicOr(&L.bits[idx >> 5], 1u << (idx & 31));
-					if (m2 != 0xFFFFu) {
+					if (m2 < 0xFFFFu) {
 						const int idx2 = flen + rlen - p - (int) m2 - minov - 1;
 						if (idx2 >= 0 && idx2 < size)
 							atomicOr(&L.bits[idx2 >> 5], 1u << (idx2 & 31));
