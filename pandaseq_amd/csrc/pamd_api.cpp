@@ -421,13 +421,9 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.w_rc = o;
 	o += 128;
 	p.w_fn = o;
-	o += 64;
+	o += 128;
 	p.w_rn = o;
-	o += 64;
-	p.w_fpl = o;
-	o += 320;
-	p.w_rpl = o;
-	o += 320;
+	o += 128 + 16;	// the scan may read one word past a stream
 	p.w_bits = o;
 	o += 128;
 	p.w_pend = o;

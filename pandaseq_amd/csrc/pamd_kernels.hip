@@ -26,8 +26,6 @@ namespace {
 // can emit), as many as fit in the log-p staging area it shares (PamdKernelParams::hash_slots)
 constexpr unsigned HASH_EMPTY = 0xFFFFFFFFu;
 constexpr unsigned NT_N = 15;
-constexpr unsigned PLANE_STRIDE = 80;	// one zero dword in front, 64 bytes of bits (512 positions), zero tail
-constexpr unsigned PLANE_BYTES = 4 * PLANE_STRIDE;
 constexpr unsigned long long ARENA_CHUNK = 16384;	// bases a wave reserves from the output arena at a time
 
 typedef unsigned long long u64;
@@ -103,10 +101,9 @@ struct WaveLds {
 	uint16_t *R;	// reverse read
 	uint32_t *fc;	// forward 2-bit codes, 16 per word, first base in the TOP bits
 	uint32_t *rc;	// reverse 2-bit codes, 16 per word, first base in the LOW bits
-	uint32_t *fn;	// forward N bitmap
-	uint32_t *rn;	// reverse N bitmap
-	uint8_t *fpl;	// forward one-hot bit planes A,C,G,T: 4 x PLANE_STRIDE bytes, bit p = base p has that bit
-	uint8_t *rpl;	// reverse one-hot bit planes (natural read order)
+	uint32_t *fn;	// forward "special base" map, 2 bits per base like the codes: 3 = N, 1 = any other nt that is not
+			// exactly one of A C G T, 0 = plain base
+	uint32_t *rn;	// reverse map, the two bits of every entry swapped like the reverse codes (3 = N, 2 = other)
 	uint32_t *bits;	// candidate overlaps (BITS_INIT, assembler.c:41,84)
 	uint8_t *nts;	// merged nt staging
 	double *ps;	// merged log-p staging; the k-mer table lives here while seeding
@@ -128,28 +125,6 @@ __device__ __forceinline__ uint4 load_read(const uint8_t *row, unsigned row_byte
 	return make_uint4(v.x, v.y, 0u, 0u);
 }
 
-// The one-hot bit planes of a read (only needed when many candidates must be scored, see the scan).
-__device__ __forceinline__ void build_planes(const uint16_t *src, int len, int lane, uint8_t *planes) {
-	const uint4 v = lane * 8 < len ? reinterpret_cast<const uint4 *>(src)[lane] : make_uint4(0, 0, 0, 0);
-	const unsigned w[4] = { v.x, v.y, v.z, v.w };
-	unsigned pa = 0, pc = 0, pg = 0, pt = 0;
-#pragma unroll
-	for (int k = 0; k < 8; k++) {
-		const unsigned nt = (w[k >> 1] >> (16 * (k & 1))) & 0xFFu;
-		pa |= (nt & 1u) << k;
-		pc |= ((nt >> 1) & 1u) << k;
-		pg |= ((nt >> 2) & 1u) << k;
-		pt |= ((nt >> 3) & 1u) << k;
-	}
-	int cnt = len - lane * 8;
-	cnt = cnt < 0 ? 0 : (cnt > 8 ? 8 : cnt);
-	const unsigned inmask = (1u << cnt) - 1u;
-	planes[4 + lane] = (uint8_t) (pa & inmask);
-	planes[4 + PLANE_STRIDE + lane] = (uint8_t) (pc & inmask);
-	planes[4 + 2 * PLANE_STRIDE + lane] = (uint8_t) (pg & inmask);
-	planes[4 + 3 * PLANE_STRIDE + lane] = (uint8_t) (pt & inmask);
-}
-
 template <bool FORWARD, int BPL>
 __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint16_t *dst, uint32_t *codes, uint32_t *nmap) {
 	if (lane * BPL < len) {
@@ -166,37 +141,39 @@ __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint
 	//   N          = (nt + 1) >> 4
 	//   qual == 2  = bit 8 of ((qual ^ 2) - 1) taken as an unsigned byte
 	unsigned codes_k = 0, is2 = 0, nbits = 0;
+	// special-base map entry by nt: 3 for N (15), 0 for A C G T (1 2 4 8), 1 for everything else; the
+	// reverse read stores 2 instead of 1 (entries are bit-swapped like its codes)
+	constexpr unsigned SPECIAL_F = 0xD5545441u, SPECIAL_R = 0xEAA8A882u;	// 16 two-bit entries, nt 0 in the low bits
 #pragma unroll
 	for (int k = 0; k < BPL; k++) {
 		const unsigned e = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-		const unsigned nt = e & 0xFFu;
-		const unsigned c = ((FORWARD ? 0x00030210u : 0x00030120u) >> ((nt & 15u) * 2u)) & 3u;
+		const unsigned nt2 = (e & 15u) * 2u;
+		const unsigned c = ((FORWARD ? 0x00030210u : 0x00030120u) >> nt2) & 3u;
 		codes_k |= c << (2 * k);
-		nbits |= (((nt + 1u) >> 4) & 1u) << k;
+		nbits |= (((FORWARD ? SPECIAL_F : SPECIAL_R) >> nt2) & 3u) << (2 * k);
 		is2 |= (((((e >> 8) ^ 2u) & 0xFFu) - 1u) >> 8 & 1u) << k;
 	}
 	// bases at or beyond the read length contribute nothing
 	int cnt = len - lane * BPL;
 	cnt = cnt < 0 ? 0 : (cnt > BPL ? BPL : cnt);
 	const unsigned inmask = (1u << cnt) - 1u;	// bit k set <=> base k of this lane exists
-	nbits &= inmask;
+	const unsigned inmask2 = (1u << (2 * cnt)) - 1u;
+	nbits &= inmask2;
 	const unsigned not2 = ~is2 & inmask;
-	codes_k &= (1u << (2 * cnt)) - 1u;
+	codes_k &= inmask2;
 	// 16 codes per u32, base b at bits 2b..2b+1 of the stream.  A forward k-mer is the 16 bits
 	// ending at its position (oldest base in the low bits).  A reverse k-mer must pair its base t
 	// with the forward k-mer's base 7-t, so the reverse stream stores each code with its two bits
 	// swapped (C=2, G=1) and the probe bit-reverses the 16-bit window: the pair order flips and the
 	// bits inside each pair swap back.  Only equality of k-mers matters (the reference's table index
-	// is just a key), so any consistent encoding gives the same candidate set.
+	// is just a key), so any consistent encoding gives the same candidate set.  The simple_bayesian
+	// scan compares whole 16-base words of the two streams the same way.
 	if (BPL == 8) {
 		reinterpret_cast<uint16_t *>(codes)[lane] = (uint16_t) codes_k;
-		reinterpret_cast<uint8_t *>(nmap)[lane] = (uint8_t) nbits;
+		reinterpret_cast<uint16_t *>(nmap)[lane] = (uint16_t) nbits;
 	} else {
 		reinterpret_cast<uint8_t *>(codes)[lane] = (uint8_t) codes_k;
-		// the N bitmap holds 8 positions per byte: even lanes write their nibble plus the next lane's
-		const unsigned hi = (unsigned) __builtin_amdgcn_mov_dpp((int) nbits, 0xF5, 0xF, 0xF, true);	// quad_perm [1,1,3,3]
-		if ((lane & 1) == 0)
-			reinterpret_cast<uint8_t *>(nmap)[lane >> 1] = (uint8_t) (nbits | (hi << 4));
+		reinterpret_cast<uint8_t *>(nmap)[lane] = (uint8_t) nbits;
 	}
 	const int mine = not2 ? lane * BPL + (31 - __builtin_clz(not2)) + 1 : 0;
 	const u64 has = __ballot(not2 != 0);
@@ -275,56 +252,64 @@ __device__ int primer_offset(const PamdKernelParams &P, const double *ltab, cons
 }
 
 // ---- simple_bayesian overlap_probability for up to 4 candidates at once (algo_simple_bayes.c:33-66) ----
-// The three counts are popcounts over one-hot bit planes.  Lane (row, c): row = lane >> 4 picks the
-// candidate, c = lane & 15 the 32-position chunk i in [32c, 32c + 32) of the overlap walk
-// (fi = flen - ov + i ascending in the forward planes, ri = rlen - 1 - i descending in the reverse
-// planes, so the reverse chunk is extracted at its mirrored position and bit-reversed).
-__device__ __forceinline__ unsigned plane_word(const uint8_t *plane, int start_bit) {
-	// 32 bits of a plane starting at bit `start_bit` (>= -32; the dword in front of the plane is zero)
-	const uint32_t *w = reinterpret_cast<const uint32_t *>(plane) + 1 + (start_bit >> 5);
-	return __builtin_amdgcn_alignbit(w[1], w[0], (unsigned) start_bit & 31u);
-}
-
-__device__ __forceinline__ double score_sb_planes(const PamdKernelParams &P, const WaveLds &L, int flen, int rlen, int ov, bool active, int lane) {
-	const int c = lane & 15;
-	const int i0 = 32 * c;
+// The three counts come from whole words of the 2-bit code streams and special-base maps.  A candidate
+// owns ROWS 16-lane DPP rows (one when both reads fit 256 bases, else two); lane c of it owns the 16
+// overlap positions i in [16c, 16c + 16): forward bases fi = flen - ov + i ascending, reverse bases
+// ri = rlen - 1 - i descending, so the reverse words are taken at the mirrored position and bit-reversed
+// (which also swaps the bits of every entry back, see stage_read).  For bases that are exactly one of
+// A C G T "(f.nt & r.nt) != 0" is equality of the codes; N on either side is an unknown.  Any other nt
+// inside the compared range (IUPAC ambiguity codes, 0) is reported through `odd` and the caller scores
+// that step base by base instead.
+template <int ROWS>
+__device__ __forceinline__ double score_sb_codes(const PamdKernelParams &P, const WaveLds &L, int flen, int rlen, int ov, bool active, int lane, bool &odd) {
+	const int c = lane & (16 * ROWS - 1);
+	const int i0 = 16 * c;
 	// positions that exist on both reads: max(0, ov - flen) <= i < min(ov, rlen)
 	int lo_i = ov - flen;
 	lo_i = lo_i < 0 ? 0 : lo_i;
 	const int hi_i = ov < rlen ? ov : rlen;
 	int lo = lo_i - i0, hi = hi_i - i0;
-	lo = lo < 0 ? 0 : (lo > 32 ? 32 : lo);
-	hi = hi < 0 ? 0 : (hi > 32 ? 32 : hi);
-	const unsigned below_hi = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u);
-	const unsigned below_lo = lo >= 32 ? 0xFFFFFFFFu : ((1u << lo) - 1u);
-	unsigned vmask = active ? (below_hi & ~below_lo) : 0u;
-	unsigned packed = 0;
-	if (vmask != 0) {
-		const int fs = flen - ov + i0;	// >= -31 here
-		const int rs = rlen - 32 - i0;	// >= -31 here
-		const unsigned fa = plane_word(L.fpl, fs), fc = plane_word(L.fpl + PLANE_STRIDE, fs);
-		const unsigned fg = plane_word(L.fpl + 2 * PLANE_STRIDE, fs), ft = plane_word(L.fpl + 3 * PLANE_STRIDE, fs);
-		const unsigned ra = __builtin_bitreverse32(plane_word(L.rpl, rs)), rc = __builtin_bitreverse32(plane_word(L.rpl + PLANE_STRIDE, rs));
-		const unsigned rg = __builtin_bitreverse32(plane_word(L.rpl + 2 * PLANE_STRIDE, rs)), rt = __builtin_bitreverse32(plane_word(L.rpl + 3 * PLANE_STRIDE, rs));
-		const unsigned match = (fa & ra) | (fc & rc) | (fg & rg) | (ft & rt);
-		const unsigned isn = (fa & fc & fg & ft) | (ra & rc & rg & rt);
-		const unsigned unknowns = __popc(vmask & isn);
-		const unsigned matches = __popc(vmask & ~isn & match);
-		const unsigned mismatches = __popc(vmask & ~isn & ~match);
-		packed = unknowns | (matches << 10) | (mismatches << 20);	// each count <= 450 < 1024
-	}
+	lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+	hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
+	const unsigned below_hi = (unsigned) ((1ull << (2 * hi)) - 1ull);
+	const unsigned below_lo = (unsigned) ((1ull << (2 * lo)) - 1ull);
+	const unsigned valid = active ? (below_hi & ~below_lo & 0x55555555u) : 0u;	// bit 2k <=> position i0 + k counts
+	// all eight words are read unconditionally (clamped, the mask discards what does not count) so the
+	// LDS round trips overlap
+	int fs = flen - ov + i0, rs = rlen - 16 - i0;	// first base of the forward / reverse word
+	fs = fs < -16 ? -16 : fs;
+	rs = rs < -16 ? -16 : rs;
+	const int fb = 2 * fs, rb = 2 * rs;
+	const uint32_t *fcw = L.fc + (fb >> 5), *fnw = L.fn + (fb >> 5);
+	const uint32_t *rcw = L.rc + (rb >> 5), *rnw = L.rn + (rb >> 5);
+	const unsigned fc0 = fcw[0], fc1 = fcw[1], fn0 = fnw[0], fn1 = fnw[1];
+	const unsigned rc0 = rcw[0], rc1 = rcw[1], rn0 = rnw[0], rn1 = rnw[1];
+	const unsigned f = __builtin_amdgcn_alignbit(fc1, fc0, (unsigned) fb & 31u);
+	const unsigned fsp = __builtin_amdgcn_alignbit(fn1, fn0, (unsigned) fb & 31u);
+	const unsigned r = __builtin_bitreverse32(__builtin_amdgcn_alignbit(rc1, rc0, (unsigned) rb & 31u));
+	const unsigned rsp = __builtin_bitreverse32(__builtin_amdgcn_alignbit(rn1, rn0, (unsigned) rb & 31u));
+	const unsigned x = f ^ r;
+	const unsigned same = ~(x | (x >> 1));		// bit 2k: the two codes are equal
+	const unsigned sp = fsp | rsp;			// bit 2k: a base that is not plain A C G T; bit 2k+1: an N
+	const unsigned isn = sp >> 1;
+	odd = (valid & sp & ~isn) != 0;
+	unsigned packed = (unsigned) __popc(valid & isn) | ((unsigned) __popc(valid & same & ~isn) << 10);	// each count <= 450 < 1024
 	// sum over the 16 lanes of the row (rotate-and-add inside the DPP row)
 	packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x128, 0xF, 0xF, false);	// row_ror:8
 	packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x124, 0xF, 0xF, false);	// row_ror:4
 	packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x122, 0xF, 0xF, false);	// row_ror:2
 	packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x121, 0xF, 0xF, false);	// row_ror:1
-	const unsigned unknowns = packed & 1023u, matches = (packed >> 10) & 1023u, mismatches = packed >> 20;
+	if (ROWS == 2)
+		packed += (unsigned) __builtin_amdgcn_ds_swizzle((int) packed, 0x401F);	// the other row of the pair (lane ^ 16)
+	const int unknowns = (int) (packed & 1023u), matches = (int) (packed >> 10);
+	const int walked = hi_i > lo_i ? hi_i - lo_i : 0;
+	const int mismatches = walked - unknowns - matches;
 	// size_t arithmetic inside the parenthesis (algo_simple_bayes.c:61-65), wrap included
 	// flen + rlen - 2*ov + unknowns in size_t arithmetic: when it is negative the reference's unsigned
 	// value is 2^64 - |x|, whose conversion to double we reproduce through the 64-bit path; otherwise a
 	// single 32-bit conversion is exact
-	const int fb = (ov >= flen && ov >= rlen) ? (int) unknowns : flen + rlen - 2 * ov + (int) unknowns;
-	const double free_bases = fb >= 0 ? (double) (unsigned) fb : (double) (u64) (long long) fb;
+	const int fbases = (ov >= flen && ov >= rlen) ? unknowns : flen + rlen - 2 * ov + unknowns;
+	const double free_bases = fbases >= 0 ? (double) (unsigned) fbases : (double) (u64) (long long) fbases;
 	return P.qual_nn * free_bases + (double) matches * P.sb_pmatch + (double) mismatches * P.sb_pmismatch;
 }
 
@@ -760,7 +745,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			// both windows are read unconditionally (clamped) so the two LDS round trips overlap
 			const int sn = inr ? p - 8 : 0;	// no N among the 9 positions ending at p (misc.h:41)
 			const int sc = inr ? p - 7 : 0;
-			const unsigned nwin = __builtin_amdgcn_alignbit(L.fn[(sn >> 5) + 1], L.fn[sn >> 5], (unsigned) sn & 31u) & 0x1FFu;
+			const unsigned nwin = __builtin_amdgcn_alignbit(L.fn[(sn >> 4) + 1], L.fn[sn >> 4], 2u * ((unsigned) sn & 15u)) & 0x2AAAAu;	// N = high bit of an entry
 			const unsigned kmer = __builtin_amdgcn_alignbit(L.fc[(sc >> 4) + 1], L.fc[sc >> 4], 2u * ((unsigned) sc & 15u)) & 0xFFFFu;
 			if (inr && nwin == 0) {
 				const unsigned word = (kmer << 16) | (unsigned) p;
@@ -776,7 +761,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			const int p = base + lane;
 			const bool inr = p + 8 < rlen;	// p <= rlen - 9
 			const int sp = inr ? p : 0;	// no N among positions p .. p+8
-			const unsigned nwin = __builtin_amdgcn_alignbit(L.rn[(sp >> 5) + 1], L.rn[sp >> 5], (unsigned) sp & 31u) & 0x1FFu;
+			const unsigned nwin = __builtin_amdgcn_alignbit(L.rn[(sp >> 4) + 1], L.rn[sp >> 4], 2u * ((unsigned) sp & 15u)) & 0x15555u;	// reverse entries are bit-swapped
 			const unsigned x = __builtin_amdgcn_alignbit(L.rc[(sp >> 4) + 1], L.rc[sp >> 4], 2u * ((unsigned) sp & 15u)) & 0xFFFFu;
 			if (inr && nwin == 0) {
 				const unsigned kmer = __builtin_bitreverse32(x) >> 16;
@@ -829,7 +814,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		int examined = 0;
 		int score_parked = 0;	// pear / rdp_mle: the winner's terms sit in L.ps and must be parked
 		int ncand = 0;
-		{
+		if (ALGO != PAMD_ALGO_SIMPLE_BAYES) {
 			u64 nz = __ballot(mybits != 0);
 			while (nz != 0 && ncand <= 4) {	// only "more than four?" matters
 				const int w = __builtin_ctzll(nz);
@@ -837,13 +822,12 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				ncand += __popc((unsigned) __builtin_amdgcn_readlane((int) mybits, w));
 			}
 		}
-		if (ALGO == PAMD_ALGO_SIMPLE_BAYES && ncand > 4) {
-			// Many candidates (tandem repeats, or no seed at all): score them four per step from
-			// one-hot bit planes, one candidate per 16-lane row, still judged in ascending order.
-			build_planes(L.F, flen, lane, L.fpl);
-			build_planes(L.R, rlen, lane, L.rpl);
-			wave_sync();
-			const int row = lane >> 4;
+		if (ALGO == PAMD_ALGO_SIMPLE_BAYES) {
+			// Candidates are scored PER_STEP at a time from the packed code streams, one candidate per
+			// DPP row (pair of rows for long reads), and judged in ascending order.
+			constexpr int ROWS = BPL == 4 ? 1 : 2;
+			constexpr int PER_STEP = 4 / ROWS;
+			const int row = lane / (16 * ROWS);
 			int myov = 0;	// this row's candidate
 			int pending = 0;
 			u64 words = __ballot(mybits != 0);	// non-empty 32-candidate words, ascending
@@ -858,11 +842,13 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 					const int ov = w * 32 + b + minov;
 					myov = row == pending ? ov : myov;
 					pending++;
-					if (pending == 4 || (lastword && m == 0)) {
-						const double sc = score_sb_planes(P, L, flen, rlen, myov, row < pending, lane);
+					if (pending == PER_STEP || (lastword && m == 0)) {
+						bool odd;
+						const double sc = score_sb_codes<ROWS>(P, L, flen, rlen, myov, row < pending, lane, odd);
+						const bool slowstep = __ballot(odd) != 0;	// an nt that is neither A C G T nor N: base by base
 						for (int r = 0; r < pending; r++) {
-							const double pr = lane_f64(sc, 16 * r);
-							const int ovr = __builtin_amdgcn_readlane(myov, 16 * r);
+							const int ovr = __builtin_amdgcn_readlane(myov, 16 * ROWS * r);
+							const double pr = slowstep ? score_overlap<ALGO>(P, ltab, L, flen, rlen, ovr, lane) : lane_f64(sc, 16 * ROWS * r);
 							if (pr > best) {	// strict: ascending scan keeps the smallest overlap on ties
 								best = pr;
 								bo = ovr;
@@ -921,8 +907,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			// any-order sums (error < 1e-9) whenever every comparison is clearer than 1e-6, and its exact
 			// ordered sum is left to the group finish as a fourth chain over the parked terms.  Any
 			// comparison closer than that falls back to summing every candidate in reference order here.
-			bool ambiguous = ALGO == PAMD_ALGO_SIMPLE_BAYES || (EXACT && P.score_scratch == nullptr);
-			if (ALGO != PAMD_ALGO_SIMPLE_BAYES && !ambiguous) {
+			bool ambiguous = EXACT && P.score_scratch == nullptr;
+			if (!ambiguous) {
 				int last_ov = -1;
 				u64 words = __ballot(mybits != 0);
 				while (words != 0) {
@@ -1305,10 +1291,6 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	L.rc = reinterpret_cast<uint32_t *>(wb + P.w_rc);
 	L.fn = reinterpret_cast<uint32_t *>(wb + P.w_fn);
 	L.rn = reinterpret_cast<uint32_t *>(wb + P.w_rn);
-	L.fpl = wb + P.w_fpl;
-	L.rpl = wb + P.w_rpl;
-	for (unsigned i = lane; i < 2 * PLANE_BYTES / 4; i += 64)
-		reinterpret_cast<uint32_t *>(wb + P.w_fpl)[i] = 0;	// plane pads stay zero for the whole kernel
 	L.bits = reinterpret_cast<uint32_t *>(wb + P.w_bits);
 	L.nts = wb + P.w_nt;
 	L.ps = reinterpret_cast<double *>(wb + P.w_p);
