@@ -34,15 +34,27 @@ typedef unsigned long long u64;
 // Costs a few % itself, so it is never compiled into the shipped library.
 #ifdef PAMD_PHASE_TIMING
 #define PH_DECL u64 ph_t0 = __builtin_amdgcn_s_memtime(), ph_t1
+#define PH_MARK_END(k) PH_MARK(k)
 #define PH_MARK(k)                                   \
 	do {                                         \
 		ph_t1 = __builtin_amdgcn_s_memtime(); \
 		ph_acc[k] += ph_t1 - ph_t0;          \
 		ph_t0 = ph_t1;                       \
 	} while (0)
+#elif defined(PAMD_STOP_AFTER)
+// Ablation builds (tools/phase_ablation.py): every pair is abandoned (as NOALGN) after phase
+// PAMD_STOP_AFTER, so the kernel time of build k minus build k-1 is what phase k costs.
+#define PH_DECL
+#define PH_MARK(k)                           \
+	if ((k) == PAMD_STOP_AFTER) {        \
+		status = PAMD_ST_NOALGN;     \
+		break;                       \
+	}
+#define PH_MARK_END(k)
 #else
 #define PH_DECL
 #define PH_MARK(k)
+#define PH_MARK_END(k)
 #endif
 
 __device__ __forceinline__ void wave_sync() {
@@ -1205,7 +1217,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		asm volatile("" : "+v"(cur.flen_v), "+v"(cur.rlen_v), "+v"(cur.f.x), "+v"(cur.f.y), "+v"(cur.f.z), "+v"(cur.f.w), "+v"(cur.r.x), "+v"(cur.r.y), "+v"(cur.r.z), "+v"(cur.r.w));
 	}
 	rec.st = status;
-	PH_MARK(7);
+	PH_MARK_END(7);
 	if (EXACT) {
 		if (lane == 0)
 			*slot_rec = rec;	// park it; finish_group() does the rest
