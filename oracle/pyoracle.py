@@ -72,8 +72,8 @@ def build(force=False):
     """Compile liboracle.so (and, when /root/reference is present, the reference's own table
     generator into oracle/_ref/).  Building the checker is not using it."""
     so = os.path.join(HERE, "liboracle.so")
-    src = os.path.join(HERE, "panda_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(HERE, f) for f in ("panda_oracle.c", "panda_oracle.h", "panda_oracle_io.c", "panda_oracle_io.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", HERE, "liboracle.so"])
     if os.path.isdir("/root/reference") and not os.path.exists(os.path.join(HERE, "_ref", "libreftable.so")):
         subprocess.check_call(["make", "-C", HERE, "ref"])
@@ -224,3 +224,102 @@ def ref_tables_np():
             arr = ((C.c_double * NQ) * NQ).in_dll(L, sym)
         out[k] = np.ctypeslib.as_array(arr).copy()
     return out
+
+
+# ---- FASTQ ingest and FASTA / FASTQ formatting (panda_oracle_io.h) --------------------------------
+TAG_PRESENT, TAG_ABSENT, TAG_OPTIONAL = 0, 1, 2
+IDFMT = ["UNKNOWN", "SRA", "CASAVA_1_4", "CASAVA_1_7", "EBI_SRA", "CASAVA_CONVERTED"]
+FQ_STOP = ["END", "BADID_FWD", "BADID_REV", "NOTPAIRED", "BADNT", "READLEN", "BADSEQ", "NOQUAL", "EOF"]
+
+
+class SeqId(C.Structure):
+    _fields_ = [("instrument", C.c_char * 100), ("run", C.c_char * 100), ("flowcell", C.c_char * 100),
+                ("lane", C.c_int), ("tile", C.c_int), ("x", C.c_int), ("y", C.c_int), ("tag", C.c_char * 50)]
+
+    def fields(self):
+        return (self.instrument.decode("latin1"), self.run.decode("latin1"), self.flowcell.decode("latin1"),
+                self.lane, self.tile, self.x, self.y, self.tag.decode("latin1"))
+
+
+class FastqStatus(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("n_records", C.c_uint64), ("n_dropped", C.c_uint64),
+                ("stop_code", C.c_int32), ("stop_in_reverse", C.c_int32), ("stop_record", C.c_uint64),
+                ("seen_under_64", C.c_int32), ("non_empty", C.c_int32)]
+
+
+_io_ready = False
+
+
+def _io():
+    global _io_ready
+    L = lib()
+    if not _io_ready:
+        L.po_seqid_parse.restype = C.c_int
+        L.po_seqid_parse.argtypes = [C.POINTER(SeqId), C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+        L.po_seqid_equal.restype = C.c_int
+        L.po_seqid_equal.argtypes = [C.POINTER(SeqId), C.POINTER(SeqId)]
+        L.po_seqid_print.restype = C.c_int
+        L.po_seqid_print.argtypes = [C.POINTER(SeqId), C.c_char_p]
+        L.po_fastq_read.restype = None
+        L.po_fastq_read.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t,
+                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.POINTER(FastqStatus)]
+        L.po_output_fasta.restype = C.c_size_t
+        L.po_output_fasta.argtypes = [C.POINTER(SeqId), C.c_double, C.c_void_p, C.c_size_t, C.c_char_p]
+        L.po_output_fastq.restype = C.c_size_t
+        L.po_output_fastq.argtypes = [C.POINTER(Tables), C.POINTER(SeqId), C.c_double, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p]
+        L.po_nt_from_ascii.restype = C.c_uint8
+        L.po_nt_from_ascii.argtypes = [C.c_char]
+        L.po_nt_from_ascii_complement.restype = C.c_uint8
+        L.po_nt_from_ascii_complement.argtypes = [C.c_char]
+        L.po_nt_to_ascii.restype = C.c_char
+        L.po_nt_to_ascii.argtypes = [C.c_uint8]
+        _io_ready = True
+    return L
+
+
+def seqid_parse(header, policy=TAG_OPTIONAL):
+    """panda_seqid_parse_fail on the text after the '@'. Returns (direction, format, SeqId, end_offset)."""
+    if isinstance(header, str):
+        header = header.encode("latin1")
+    sid, fmt, end = SeqId(), C.c_int(0), C.c_size_t(0)
+    d = _io().po_seqid_parse(C.byref(sid), header, policy, C.byref(fmt), C.byref(end))
+    return d, fmt.value, sid, end.value
+
+
+def seqid_str(sid):
+    buf = C.create_string_buffer(512)
+    n = _io().po_seqid_print(C.byref(sid), buf)
+    return buf.raw[:n]
+
+
+def fastq_read(fwd_text, rev_text, qualmin=33, policy=TAG_OPTIONAL, max_pairs=None, stride=456):
+    """The paired reader over two FASTQ texts (bytes). Returns (fwd, rev, flen, rlen, ids, status):
+    fwd / rev uint8 [n, stride, 2], ids a ctypes array of SeqId."""
+    n_max = fwd_text.count(b"\n") // 4 + 1 if max_pairs is None else max_pairs
+    fwd = np.zeros((n_max, stride, 2), dtype=np.uint8)
+    rev = np.zeros((n_max, stride, 2), dtype=np.uint8)
+    flen = np.zeros(n_max, dtype=np.uint16)
+    rlen = np.zeros(n_max, dtype=np.uint16)
+    ids = (SeqId * n_max)()
+    st = FastqStatus()
+    _io().po_fastq_read(fwd_text, len(fwd_text), rev_text, len(rev_text), qualmin, policy, n_max,
+                        fwd.ctypes.data, stride, rev.ctypes.data, stride, flen.ctypes.data, rlen.ctypes.data,
+                        C.cast(ids, C.c_void_p), C.byref(st))
+    n = st.n_pairs
+    return fwd[:n], rev[:n], flen[:n], rlen[:n], ids, st
+
+
+def output_fasta(sid, quality, seq_nt):
+    seq_nt = np.ascontiguousarray(seq_nt, dtype=np.uint8)
+    buf = C.create_string_buffer(1024 + 2 * len(seq_nt))
+    n = _io().po_output_fasta(C.byref(sid), quality, seq_nt.ctypes.data, len(seq_nt), buf)
+    return buf.raw[:n]
+
+
+def output_fastq(sid, quality, seq_nt, seq_p):
+    seq_nt = np.ascontiguousarray(seq_nt, dtype=np.uint8)
+    seq_p = np.ascontiguousarray(seq_p, dtype=np.float64)
+    buf = C.create_string_buffer(1024 + 2 * len(seq_nt))
+    n = _io().po_output_fastq(C.byref(tables()), C.byref(sid), quality, seq_nt.ctypes.data, seq_p.ctypes.data, len(seq_nt), buf)
+    return buf.raw[:n]

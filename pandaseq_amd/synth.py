@@ -203,3 +203,61 @@ def generate_device(spec: SynthSpec, start: int, n: int, device="cuda:0", stream
                                              fwd.data_ptr(), rev.data_ptr(), stride, flen.data_ptr(), rlen.data_ptr(),
                                              C.c_void_p(st.cuda_stream)))
     return fwd, rev, flen, rlen
+
+
+# ---- FASTQ rendering of synthetic pairs (input of the ingest path) --------------
+_NT_ASCII = np.frombuffer(b"NACMGRSVTWYHKDBN", dtype=np.uint8)  # ntchar, nt.c:25
+_NT_COMP = np.array([((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3) for v in range(16)], dtype=np.uint8)
+
+
+def fastq_ids(start: int, n: int):
+    """CASAVA 1.7 names of SURVEY.md 8d: SIM:1:FC:1:<tile>:<x>:<y>, every numeric field of fixed width."""
+    i = np.arange(start, start + n, dtype=np.int64)
+    tile = 1101 + (i // 8_100_000_000) % 8899
+    x = 10000 + (i // 90000) % 90000
+    y = 10000 + i % 90000
+    return tile, x, y
+
+
+def render_fastq(fwd, rev, flen, rlen, start: int = 0, qualmin: int = 33, tag: str = "1", crlf: bool = False):
+    """Rows of panda_qual (all reads of one length L) -> (forward FASTQ bytes, reverse FASTQ bytes).
+    The reverse file shows the read as sequenced: the stored row is its complement, base by base
+    (iupac_reverse, nt.c:81-114), so the text is the complement of the stored codes in the same order."""
+    n = fwd.shape[0]
+    L = int(flen[0]) if n else 0
+    assert n == 0 or (np.all(flen == L) and np.all(rlen == L)), "render_fastq wants equal read lengths"
+    tile, x, y = fastq_ids(start, n)
+    out = []
+    eol = b"\r\n" if crlf else b"\n"
+    for mate, rows, comp in ((1, fwd, False), (2, rev, True)):
+        head0 = b"@SIM:1:FC:1:"
+        tail = (" %d:N:0:%s" % (mate, tag)).encode() + eol
+        hw = len(head0) + 4 + 1 + 5 + 1 + 5 + len(tail)
+        rec = hw + L + len(eol) + 1 + len(eol) + L + len(eol)
+        buf = np.empty((n, rec), dtype=np.uint8)
+        c = 0
+        buf[:, c:c + len(head0)] = np.frombuffer(head0, dtype=np.uint8)
+        c += len(head0)
+        for val, w in ((tile, 4), (x, 5), (y, 5)):
+            for d in range(w):
+                buf[:, c + d] = 48 + (val // 10 ** (w - 1 - d)) % 10
+            c += w
+            if w != 5 or val is x:
+                buf[:, c] = ord(":")
+                c += 1
+        buf[:, c:c + len(tail)] = np.frombuffer(tail, dtype=np.uint8)
+        c += len(tail)
+        nt = rows[:, :L, 0] & 15
+        if comp:
+            nt = _NT_COMP[nt]
+        buf[:, c:c + L] = _NT_ASCII[nt]
+        c += L
+        sep = eol + b"+" + eol
+        buf[:, c:c + len(sep)] = np.frombuffer(sep, dtype=np.uint8)
+        c += len(sep)
+        buf[:, c:c + L] = (rows[:, :L, 1].view(np.int8).astype(np.int16) + qualmin).astype(np.uint8)
+        c += L
+        buf[:, c:c + len(eol)] = np.frombuffer(eol, dtype=np.uint8)
+        assert c + len(eol) == rec
+        out.append(buf.tobytes())
+    return out[0], out[1]

@@ -117,3 +117,80 @@ def compare_counters(dev, ora):
     assert list(dev["rejected"]) == [int(x) for x in ora["rejected"]]
     assert np.array_equal(np.asarray(dev["overlapcount"]), np.asarray(ora["overlapcount"]))
     assert dev["longest_overlap"] == int(ora["longest_overlap"])
+
+
+# ---- FASTQ ingest: hand-made edge cases ---------------------------------------
+def _rec(header, seq, qual=None, plus="+", eol="\n"):
+    if qual is None:
+        qual = "I" * len(seq)
+    return (header + eol + seq + eol + plus + eol + qual + eol).encode("latin1")
+
+
+def fastq_cases():
+    """(name, forward text, reverse text, qualmin, policy, expected stop) -- every stop condition of
+    fastq.c:45-198 / seqid.c:142-285 / linebuf.c:57-89 and the shapes that must NOT stop the reader.
+    policy: 0 PRESENT, 1 ABSENT, 2 OPTIONAL."""
+    ok17 = ("@M01:7:FC9:2:1101:15000:1400 1:N:0:ACGT", "@M01:7:FC9:2:1101:15000:1400 2:N:0:ACGT")
+    s, q = "ACGTNACGTRYKM", "IIII#IIII5555"
+    good = (_rec(ok17[0], s, q), _rec(ok17[1], s, q))
+    cases = []
+
+    def add(name, f, r, stop, qualmin=33, policy=2, lead=True):
+        # a good record first, so that the stop lands on record 1 and record 0 must survive
+        cases.append((name, (good[0] if lead else b"") + f, (good[1] if lead else b"") + r, qualmin, policy, stop))
+
+    add("plain", b"", b"", "END")
+    add("casava14", _rec("@HWI-1:3:44:1000:2000#ACGTAC/1", s, q), _rec("@HWI-1:3:44:1000:2000#ACGTAC/2", s, q), "END")
+    add("casava14_notag", _rec("@HWI-1:3:44:1000:2000/1", s, q), _rec("@HWI-1:3:44:1000:2000/2", s, q), "END")
+    add("converted", _rec("@MS3:18:FCX:1:1101:14774:1712#GATA/1", s, q), _rec("@MS3:18:FCX:1:1101:14774:1712#GATA/2", s, q), "END")
+    add("sra", _rec("@SRR001666.1 071112_SLXA-EAS1_s_7:5:1:817:345 length=13", s, q), _rec("@SRR001666.1 071112_SLXA-EAS1_s_7:5:1:817:345 length=13", s, q), "END")
+    add("ebi", _rec("@ERR000017.25 a/1", s, q), _rec("@ERR000017.25 a/2", s, q), "END")
+    add("sra_mismatch", _rec("@SRR001666.1 x", s, q), _rec("@SRR001667.1 x", s, q), "NOTPAIRED")
+    add("crlf", _rec(ok17[0], s, q, eol="\r\n"), _rec(ok17[1], s, q, eol="\r\n"), "END")
+    add("lowercase_iupac", _rec(ok17[0], "acgtnubdhvxwsk", "I" * 14), _rec(ok17[1], "ACGTNUBDHVXWSK", "I" * 14), "END")
+    add("qual_range", _rec(ok17[0], "ACGTACGT", "!\"#Ojk~\x7f"[:8]), _rec(ok17[1], "ACGTACGT", " \x1f!PQ\x80\xff~"), "END")
+    add("qual64", _rec(ok17[0], "ACGTACGT", "@ABhno~!"), _rec(ok17[1], "ACGTACGT", "hhhhhhhh"), "END", qualmin=64)
+    add("empty_forward_dropped", _rec(ok17[0], "", "") + good[0], _rec(ok17[1], s, q)[:0] + _rec(ok17[1], "", "") + good[1], "END")
+    add("empty_reverse_kept", _rec(ok17[0], s, q), _rec(ok17[1], "", ""), "END")
+    add("seq_451_qual_450", _rec(ok17[0], "A" * 451, "I" * 450), _rec(ok17[1], "C" * 450, "I" * 450), "END")
+    add("seq_460_qual_460", _rec(ok17[0], "A" * 460, "I" * 460), _rec(ok17[1], "C" * 450, "I" * 450), "NOQUAL")
+    add("len_450", _rec(ok17[0], "ACGTN" * 90), _rec(ok17[1], "TTGCA" * 90), "END")
+    add("bad_fwd_id", _rec("@garbage", s, q), _rec(ok17[1], s, q), "BADID_FWD")
+    add("bad_rev_id", _rec(ok17[0], s, q), _rec("@M01:7:FC9:2:11x1:15000:1400 2:N:0:ACGT", s, q), "BADID_REV")
+    add("empty_header", _rec("", s, q), _rec(ok17[1], s, q), "BADID_FWD")
+    add("at_only", _rec("@", s, q), _rec(ok17[1], s, q), "BADID_FWD")
+    add("mate_zero", _rec("@M01:7:FC9:2:1101:15000:1400 0:N:0:ACGT", s, q), _rec(ok17[1], s, q), "BADID_FWD")
+    add("not_paired_y", _rec(ok17[0], s, q), _rec("@M01:7:FC9:2:1101:15000:1401 2:N:0:ACGT", s, q), "NOTPAIRED")
+    add("not_paired_tag", _rec(ok17[0], s, q), _rec("@M01:7:FC9:2:1101:15000:1400 2:N:0:ACGA", s, q), "NOTPAIRED")
+    add("not_paired_instr", _rec(ok17[0], s, q), _rec("@M02:7:FC9:2:1101:15000:1400 2:N:0:ACGT", s, q), "NOTPAIRED")
+    add("same_direction", _rec(ok17[0], s, q), _rec(ok17[0], s, q), "NOTPAIRED")
+    add("policy_present_fail", _rec("@M01:7:FC9:2:1101:15000:1400 1:N:0:", s, q), _rec("@M01:7:FC9:2:1101:15000:1400 2:N:0:", s, q), "BADID_FWD", policy=0, lead=False)
+    add("policy_absent_fail", _rec(ok17[0], s, q), _rec(ok17[1], s, q), "BADID_FWD", policy=1, lead=False)
+    add("policy_absent_ok", _rec("@M01:7:FC9:2:1101:15000:1400 1:N:0:", s, q), _rec("@M01:7:FC9:2:1101:15000:1400 2:N:0:", s, q), "END", policy=1, lead=False)
+    add("tag_50", _rec("@M01:7:FC9:2:1101:15000:1400 1:N:0:" + "A" * 50, s, q), _rec("@M01:7:FC9:2:1101:15000:1400 2:N:0:" + "A" * 50, s, q), "END")
+    add("tag_51", _rec("@M01:7:FC9:2:1101:15000:1400 1:N:0:" + "A" * 51, s, q), _rec("@M01:7:FC9:2:1101:15000:1400 2:N:0:" + "A" * 51, s, q), "BADID_FWD")
+    add("instr_99", _rec("@" + "I" * 99 + ":7:FC9:2:1101:15000:1400 1:N:0:A", s, q), _rec("@" + "I" * 99 + ":7:FC9:2:1101:15000:1400 2:N:0:A", s, q), "END")
+    add("instr_100", _rec("@" + "I" * 100 + ":7:FC9:2:1101:15000:1400 1:N:0:A", s, q), _rec("@" + "I" * 100 + ":7:FC9:2:1101:15000:1400 2:N:0:A", s, q), "BADID_FWD")
+    add("int_wrap", _rec("@M01:7:FC9:2:1101:99999999999:007 1:N:0:A", s, q), _rec("@M01:7:FC9:2:1101:99999999999:7 2:N:0:A", s, q), "END")
+    add("slash_in_17", _rec("@M01:7:FC9:2:1101:15000:1400 1:N:0:A/C", s, q), _rec(ok17[1], s, q), "BADID_FWD")
+    add("bad_nt_fwd", _rec(ok17[0], "ACG1ACG", "IIIIIII"), _rec(ok17[1], s, q), "BADNT")
+    add("bad_nt_rev", _rec(ok17[0], s, q), _rec(ok17[1], "ACGT ACG", "IIIIIIII"), "BADNT")
+    add("bad_nt_beyond_450_ignored", _rec(ok17[0], "A" * 450 + "1", "I" * 450), _rec(ok17[1], s, q), "END")
+    add("no_plus_seq", _rec(ok17[0], s, q, plus="ACGT"), _rec(ok17[1], s, q), "READLEN")
+    add("no_plus_junk", _rec(ok17[0], s, q, plus="1junk"), _rec(ok17[1], s, q), "BADSEQ")
+    add("empty_plus", _rec(ok17[0], s, q, plus=""), _rec(ok17[1], s, q), "BADSEQ")
+    add("plus_with_text", _rec(ok17[0], s, q, plus="+M01 again"), _rec(ok17[1], s, q), "END")
+    add("short_qual", _rec(ok17[0], s, q[:-1]), _rec(ok17[1], s, q), "NOQUAL")
+    add("long_qual_rev", _rec(ok17[0], s, q), _rec(ok17[1], s, q + "I"), "NOQUAL")
+    add("nul_in_seq", _rec(ok17[0], "ACGT\0ACG", "IIII"), _rec(ok17[1], "ACGT", "IIII"), "END")
+    add("nul_in_qual", _rec(ok17[0], "ACGT", "IIII\0II"), _rec(ok17[1], "ACGT", "II\0II"), "NOQUAL")
+    add("nul_in_header", _rec("@M01:7:FC9:2:1101:15000:1400 1:N:0:AC\0GT", s, q), _rec("@M01:7:FC9:2:1101:15000:1400 2:N:0:AC", s, q), "END")
+    add("long_header_fwd", _rec("@" + "x" * 4500, s, q), _rec(ok17[1], s, q), "END")
+    add("header_4499", _rec(ok17[0] + "y" * (4499 - len(ok17[0])), s, q), _rec(ok17[1], s, q), "BADID_FWD")
+    add("long_seq_line", _rec(ok17[0], "A" * 4500, "I" * 450), _rec(ok17[1], s, q), "EOF")
+    add("long_qual_line_rev", _rec(ok17[0], s, q), _rec(ok17[1], s, "I" * 4600), "EOF")
+    add("qual_4400", _rec(ok17[0], "A" * 450, "I" * 4400), _rec(ok17[1], s, q), "NOQUAL")
+    add("partial_tail", _rec(ok17[0], s, q)[:-5], _rec(ok17[1], s, q), "EOF")  # whole-file view; a chunked caller carries the tail over
+    add("rev_shorter", good[0] + good[0], b"", "END")
+    add("unterminated_last_line", _rec(ok17[0], s, q)[:-1], _rec(ok17[1], s, q)[:-1], "EOF")
+    return cases
