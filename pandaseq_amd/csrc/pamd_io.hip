@@ -805,7 +805,8 @@ __device__ __forceinline__ bool pair_prints(const FormatParams &P, u64 i, unsign
 	const uint4 b = r[1], c = r[2];
 	seq_len = b.z & 0xFFFFu;
 	status = (c.y >> 16) & 0xFFu;
-	return status == PAMD_ST_OK && seq_len > 0;	// output.c:89,107
+	const bool has_row = (b.x & b.y) != 0xFFFFFFFFu;	// ~0 = the output arena was too small for this pair's row
+	return status == PAMD_ST_OK && seq_len > 0 && has_row;	// output.c:89,107
 }
 
 __global__ __launch_bounds__(1024) void fmt_len_kernel(const FormatParams P) {

@@ -1,0 +1,232 @@
+"""GPU parity tests of the ingest / formatting rows: the HIP kernels behind
+include/pandaseq_amd_io.h against the I/O oracle, on the same texts, byte for byte."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from pandaseq_amd import synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def io(built):
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import pandaseq_amd as pa
+    from pandaseq_amd import textio
+    return pa, textio, textio.FastqParser(0), textio.Formatter(0)
+
+
+def parse_both(textio, ft, rt, qualmin=33, policy=2, stride=456, parser=None, max_pairs=None):
+    own = parser is None
+    if own:
+        parser = textio.FastqParser(0, qualmin, policy)
+    n_max = ft.count(b"\n") // 4 + 2 if max_pairs is None else max_pairs
+    out, st = parser.parse(textio.text_to_device(ft + b"\0" * 0) if ft else textio.text_to_device(b"\n")[:0],
+                           textio.text_to_device(rt) if rt else textio.text_to_device(b"\n")[:0], n_max, stride)
+    ora = po.fastq_read(ft, rt, qualmin=qualmin, policy=policy, stride=stride, max_pairs=n_max)
+    if own:
+        parser.close()
+    return out, st, ora
+
+
+def check_parse(textio, ft, rt, qualmin=33, policy=2, stride=456, parser=None):
+    out, st, (pf, pr, pfl, prl, oids, ost) = parse_both(textio, ft, rt, qualmin, policy, stride, parser)
+    ng = int(st.n_good)
+    assert ng == ost.n_records, (st.as_dict(), ost.n_records)
+    ostop = po.FQ_STOP[ost.stop_code]
+    dstop = textio.FQ_STOP[st.stop_code]
+    if ostop == "EOF" and ng == st.n_records:
+        assert dstop == "END"  # a record that lacks lines is the chunk's tail: carried over, not an error yet
+    elif ostop == "END" and ng < st.n_records:
+        assert dstop == "LONG_HEADER"  # the reference ends the stream silently on such a line
+    else:
+        assert dstop == ostop, (dstop, ostop)
+        assert int(st.stop_in_reverse) == int(ost.stop_in_reverse)
+    assert int(st.n_dropped) == ost.n_dropped
+    ids = out["ids"].cpu().numpy().view(textio.SEQID_DTYPE).reshape(-1)[:ng]
+    keep = np.nonzero(ids["flag"] == 0)[0]
+    assert np.all((ids["flag"] == 0) | (ids["flag"] == 1))
+    assert keep.size == ost.n_pairs
+    dfl = out["flen"].cpu().numpy().view(np.uint16)[:ng]
+    drl = out["rlen"].cpu().numpy().view(np.uint16)[:ng]
+    assert np.array_equal(dfl[keep], pfl) and np.array_equal(drl[keep], prl)
+    assert np.all(dfl[ids["flag"] == 1] == 0)
+    assert np.array_equal(out["fwd"].cpu().numpy()[:ng][keep], pf), "forward rows"
+    assert np.array_equal(out["rev"].cpu().numpy()[:ng][keep], pr), "reverse rows"
+    for j, k in enumerate(keep):
+        assert textio.seqid_fields(ids[k], ft) == oids[j].fields(), (k, textio.seqid_fields(ids[k], ft), oids[j].fields())
+    assert int(st.seen_under_64) == int(ost.seen_under_64)
+    if keep.size:
+        assert int(st.max_flen) == int(pfl.max()) and int(st.max_rlen) == int(prl.max())
+    return out, st
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_parse_synthetic_config1(io, crlf):
+    pa, textio, parser, _ = io
+    spec = synth.config_spec(1)
+    f, r, fl, rl = synth.generate_numpy(spec, 0, 20000)
+    ft, rt = synth.render_fastq(f, r, fl, rl, crlf=crlf)
+    out, st = check_parse(textio, ft, rt, stride=spec.row_stride(), parser=parser)
+    assert st.n_good == 20000 and st.fwd_consumed == len(ft) and st.rev_consumed == len(rt)
+    # round trip: text -> rows gives back the rows the text was rendered from
+    assert np.array_equal(out["fwd"].cpu().numpy()[:20000], f) and np.array_equal(out["rev"].cpu().numpy()[:20000], r)
+
+
+@pytest.mark.parametrize("case", util.fastq_cases(), ids=lambda c: c[0])
+def test_parse_edge_cases(io, case):
+    pa, textio, _, _ = io
+    name, ft, rt, qualmin, policy, stop = case
+    check_parse(textio, ft, rt, qualmin=qualmin, policy=policy)
+
+
+def _random_fastq(n, seed):
+    """Ragged reads, every header format, IUPAC letters, odd qualities; one text pair."""
+    rng = np.random.default_rng(seed)
+    letters = np.frombuffer(b"ACGTACGTACGTACGTNRYKMSWBDHVUXacgtn", dtype=np.uint8)
+    fo, ro = [], []
+    for i in range(n):
+        kind = i % 5
+        x, y = int(rng.integers(0, 99999)), int(rng.integers(0, 99999))
+        tag = "".join(rng.choice(list("ACGT"), size=int(rng.integers(0, 9))))
+        if kind == 0:
+            hf, hr = f"@M0{i % 7}:{i % 90}:FC-{i % 13}:{1 + i % 8}:{1101 + i % 50}:{x}:{y} 1:N:0:{tag}", None
+            hr = hf.replace(" 1:N", " 2:Y")
+        elif kind == 1:
+            hf = f"@HWUSI-EAS100R:{1 + i % 8}:{i % 120}:{x}:{y}#{tag}/1"
+            hr = hf[:-1] + "2"
+        elif kind == 2:
+            hf = f"@MS{i % 3}:18:000-A1{i % 9}:{1 + i % 8}:{1101 + i % 50}:{x}:{y}#{tag}/1"
+            hr = hf[:-1] + "2"
+        elif kind == 3:
+            hf = hr = f"@SRR{i % 1000:06d}.{i} some comment {x}"
+        else:
+            hf = hr = f"@ERR{i % 1000}.{i} {y}/1"
+        lf, lr = (0 if i % 97 == 5 else int(rng.integers(1, 451))), int(rng.integers(0, 451))
+        for h, ln, dst in ((hf, lf, fo), (hr, lr, ro)):
+            seq = letters[rng.integers(0, len(letters), size=ln)].tobytes()
+            qual = rng.integers(33, 127, size=ln).astype(np.uint8).tobytes()
+            eol = b"\r\n" if i % 11 == 0 else b"\n"
+            dst.append(h.encode() + eol + seq + eol + b"+" + (h[1:].encode() if i % 4 == 0 else b"") + eol + qual + eol)
+    return b"".join(fo), b"".join(ro)
+
+
+def test_parse_mixed_formats_ragged(io):
+    pa, textio, parser, _ = io
+    ft, rt = _random_fastq(6000, 5)
+    out, st = check_parse(textio, ft, rt, parser=parser)
+    assert st.n_good == 6000 and st.n_dropped > 0
+
+
+def test_parse_in_chunks(io):
+    """Cutting the texts anywhere and resuming at fwd_consumed / rev_consumed gives the same rows."""
+    pa, textio, parser, _ = io
+    ft, rt = _random_fastq(3000, 9)
+    whole, wst = check_parse(textio, ft, rt, parser=parser)
+    rows_f, rows_r, lens = [], [], []
+    fpos = rpos = 0
+    cuts = [(len(ft) // 3 + 7, len(rt) // 2 + 3), (2 * len(ft) // 3 + 1, len(rt) // 2 + 4000), (len(ft), len(rt))]
+    for fcut, rcut in cuts:
+        fchunk, rchunk = ft[fpos:fcut], rt[rpos:rcut]
+        out, st = parser.parse(textio.text_to_device(fchunk), textio.text_to_device(rchunk), 4000, 456)
+        assert st.stop_code == 0
+        ng = int(st.n_good)
+        rows_f.append(out["fwd"].cpu().numpy()[:ng])
+        rows_r.append(out["rev"].cpu().numpy()[:ng])
+        lens.append(out["flen"].cpu().numpy()[:ng])
+        fpos += int(st.fwd_consumed)
+        rpos += int(st.rev_consumed)
+    assert fpos == len(ft) and rpos == len(rt)
+    n = int(wst.n_good)
+    assert np.array_equal(np.concatenate(rows_f), whole["fwd"].cpu().numpy()[:n])
+    assert np.array_equal(np.concatenate(rows_r), whole["rev"].cpu().numpy()[:n])
+    assert np.array_equal(np.concatenate(lens), whole["flen"].cpu().numpy()[:n])
+
+
+def test_parse_row_overflow_and_validation(io):
+    pa, textio, parser, _ = io
+    spec = synth.config_spec(1)
+    f, r, fl, rl = synth.generate_numpy(spec, 0, 64)
+    ft, rt = synth.render_fastq(f, r, fl, rl)
+    out, st = parser.parse(textio.text_to_device(ft), textio.text_to_device(rt), 100, stride=128)
+    assert textio.FQ_STOP[st.stop_code] == "ROW_OVERFLOW" and st.n_good == 0
+    with pytest.raises(pa.PamdError):
+        parser.parse(textio.text_to_device(ft), textio.text_to_device(rt), 100, stride=130)
+
+
+def _assemble(pa, rows, n, algo="simple_bayesian", modules=()):
+    import torch
+    asm = pa.Assembler(0)
+    asm.set_algorithm(algo)
+    for m in modules:
+        asm.add_module(m)
+    outs = pa.alloc_outputs(n, n * 912 + 16384 * 4096, "cuda:0")  # every wave reserves a 16384-base arena chunk
+    b = pa.DeviceBatch(n=n, fwd=rows["fwd"][:n], rev=rows["rev"][:n], flen=rows["flen"][:n], rlen=rows["rlen"][:n], **outs)
+    asm.assemble_device(b)
+    torch.cuda.synchronize()
+    return asm, b
+
+
+@pytest.mark.parametrize("fmt", ["fasta", "fastq"])
+@pytest.mark.parametrize("source", ["config1", "mixed"])
+def test_format_matches_oracle(io, fmt, source):
+    """FASTQ text -> rows -> assembly -> FASTA / FASTQ text, all on the device, against the oracle chain
+    (reader -> assembler -> output.c formatting) on the host."""
+    pa, textio, parser, formatter = io
+    if source == "config1":
+        spec = synth.config_spec(1)
+        f, r, fl, rl = util.adversarial_pairs(spec, 4000, ragged=False, weird_quals=False)
+        ft, rt = synth.render_fastq(f, r, fl, rl, tag="ACGT")
+        stride = spec.row_stride()
+    else:
+        ft, rt = _random_fastq(3000, 21)
+        stride = 456
+    ftd = textio.text_to_device(ft)
+    rows, st = parser.parse(ftd, textio.text_to_device(rt), ft.count(b"\n") // 4 + 1, stride)
+    n = int(st.n_good)
+    asm, b = _assemble(pa, rows, n)
+    which = textio.OUT_FASTA if fmt == "fasta" else textio.OUT_FASTQ
+    out, nbytes, fixups = formatter.format(b, rows["ids"], ftd, which)
+    text = bytearray(out[:nbytes].cpu().numpy().tobytes())
+    res = b.results_numpy()
+    textio.apply_fixups(text, fixups, res["quality"])
+    # oracle chain
+    pf, pr, pfl, prl, oids, ost = po.fastq_read(ft, rt, stride=stride)
+    cfg = po.make_config("simple_bayesian")
+    ores, ont, op, _ = po.assemble_batch(cfg, pf, pr, pfl, prl)
+    want = []
+    for i in range(len(ores)):
+        if ores["status"][i] == 0:
+            m = int(ores["seq_len"][i])
+            if fmt == "fasta":
+                want.append(po.output_fasta(oids[i], float(ores["quality"][i]), ont[i, :m]))
+            else:
+                want.append(po.output_fastq(oids[i], float(ores["quality"][i]), ont[i, :m], op[i, :m]))
+    want = b"".join(want)
+    assert len(want) > 0
+    assert bytes(text) == want
+
+
+def test_format_with_rejections_and_fastq_phred_range(io):
+    """rdp_mle + both check modules: rejected pairs print nothing; phred bytes span the table."""
+    pa, textio, parser, formatter = io
+    spec = synth.config_spec(3)
+    f, r, fl, rl = synth.generate_numpy(spec, 0, 3000)
+    ft, rt = synth.render_fastq(f, r, fl, rl)
+    ftd = textio.text_to_device(ft)
+    rows, st = parser.parse(ftd, textio.text_to_device(rt), 3001, spec.row_stride())
+    asm, b = _assemble(pa, rows, 3000, "rdp_mle", ("min_phred:2", "min_overlapbits:15"))
+    out, nbytes, fixups = formatter.format(b, rows["ids"], ftd, textio.OUT_FASTQ)
+    text = bytearray(out[:nbytes].cpu().numpy().tobytes())
+    res = b.results_numpy()
+    textio.apply_fixups(text, fixups, res["quality"])
+    pf, pr, pfl, prl, oids, ost = po.fastq_read(ft, rt, stride=spec.row_stride())
+    cfg = po.make_config("rdp_mle", modules=(("min_phred", 2), ("min_overlapbits", 15)))
+    ores, ont, op, _ = po.assemble_batch(cfg, pf, pr, pfl, prl)
+    want = b"".join(po.output_fastq(oids[i], float(ores["quality"][i]), ont[i, :int(ores["seq_len"][i])], op[i, :int(ores["seq_len"][i])])
+                    for i in range(3000) if ores["status"][i] == 0)
+    assert (ores["status"] == 6).sum() > 0
+    assert bytes(text) == want
