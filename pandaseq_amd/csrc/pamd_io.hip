@@ -5,9 +5,10 @@
 //   fq_count_kernel   newlines per 8 KB tile of each text                      (one wave per tile)
 //   fq_scan_kernel    exclusive scan of the tile counts                        (one workgroup per text)
 //   fq_index_kernel   byte offset of every '\n', in order                      (one wave per tile)
-//   fq_parse_kernel   64 records per wave: headers parsed one record per LANE (a serial character
-//                     walk, 64 of them side by side), then reads converted one record per WAVE
-//                     (4 bases per lane, 8-byte row stores)
+//   fq_ids_kernel     headers: two LANES per record (forward / reverse header), a serial character walk
+//                     driven by a per-format field program; the pair compares through lane exchanges
+//   fq_reads_kernel   reads: 32 records per wave, each converted by the whole WAVE (4 characters per lane
+//                     as one word, loaded one record ahead; 8-byte row stores)
 //   fq_final_kernel   first failing record, dropped records, longest reads, bytes consumed
 // Formatting (replaces output.c:85-126 + seqid.c:109-116 + nt.c:126-150,167-173):
 //   fmt_len_kernel    text length of every pair + per-workgroup sums
@@ -73,6 +74,7 @@ __device__ __forceinline__ unsigned nl_mask16(const uint8_t *text, u64 bytes, u6
 struct TextRef {
 	const uint8_t *text;
 	u64 bytes;
+	unsigned last_word;	// byte offset of the aligned word that holds the last byte
 	unsigned *tile_counts;	// becomes the exclusive prefix after the scan
 	unsigned *line_end;
 	unsigned n_tiles;
@@ -191,106 +193,67 @@ __device__ __forceinline__ bool ends_chunk(int ch) {	// PARSE_CHUNK_MAYBE, seqid
 	return ch == 0 || ch == ':' || ch == '#' || ch == '/' || ch == ' ';
 }
 
-__device__ __forceinline__ bool step(Str &h, unsigned &i) {	// PARSE_PUSH, seqid.c:141
-	if (h.at(i) == 0)
-		return false;
-	i++;
-	return true;
+// panda_seqid_parse_fail (seqid.c:142-285) as a small interpreter: each header format is a list of field
+// steps, one nibble each, and ONE scanning loop serves every step -- the whole parser is a few hundred
+// instructions instead of one inlined loop per field (which overflowed the instruction cache).
+//   STR_*    PARSE_STR  + PARSE_PUSH   (a chunk that must not start at the terminator; 100 characters or
+//                                       more fail: the reference overruns its 100-byte field there)
+//   INT_*    PARSE_INT  + PARSE_PUSH   (digits only; 32-bit wrap)
+//   SKIP     PARSE_CHUNK + PARSE_PUSH  (CASAVA 1.7 "filtered")
+//   TAG      the tag chunk: may be empty, at most PAMD_TAG_LEN characters, no push
+//   HASHTAG  CASAVA <= 1.6: a tag chunk + push, only when the character before the cursor is '#'
+//   POLICY   the PandaTagging test
+//   MATE     the final PARSE_INT (no push); RET returns the mate number
+enum { OP_STR_INSTR = 1, OP_STR_RUN, OP_STR_FC, OP_INT_LANE, OP_INT_TILE, OP_INT_X, OP_INT_Y, OP_INT_MATE, OP_SKIP, OP_INT_DROP, OP_TAG, OP_POLICY, OP_HASHTAG, OP_MATE, OP_RET };
+
+constexpr u64 id_program(const int *ops, int n) {
+	u64 v = 0;
+	for (int k = 0; k < n; k++)
+		v |= (u64) ops[k] << (4 * k);
+	return v;
 }
 
-__device__ __forceinline__ bool chunk_int(Str &h, unsigned &i, int &out) {	// PARSE_INT, seqid.c:138 (32-bit wrap)
-	unsigned v = 0;
-	int ch = h.at(i);
-	if (ch == 0)
-		return false;
-	while (!ends_chunk(ch)) {
-		if (ch < '0' || ch > '9')
-			return false;
-		v = v * 10u + (unsigned) (ch - '0');
-		i++;
-		ch = h.at(i);
-	}
-	out = (int) v;
-	return true;
-}
+constexpr int OPS_17[] = { OP_STR_INSTR, OP_STR_RUN, OP_STR_FC, OP_INT_LANE, OP_INT_TILE, OP_INT_X, OP_INT_Y, OP_INT_MATE, OP_SKIP, OP_INT_DROP, OP_TAG, OP_POLICY, OP_RET };	// seqid.c:236-284
+constexpr int OPS_14[] = { OP_STR_INSTR, OP_INT_LANE, OP_INT_TILE, OP_INT_X, OP_INT_Y, OP_HASHTAG, OP_POLICY, OP_MATE, OP_RET };	// seqid.c:201-235
+constexpr int OPS_CONV[] = { OP_STR_INSTR, OP_STR_RUN, OP_STR_FC, OP_INT_LANE, OP_INT_TILE, OP_INT_X, OP_INT_Y, OP_HASHTAG, OP_POLICY, OP_MATE, OP_RET };	// seqid.c:181-200,219-235
+constexpr u64 PROG_17 = id_program(OPS_17, 13), PROG_14 = id_program(OPS_14, 9), PROG_CONV = id_program(OPS_CONV, 11);
 
-__device__ __forceinline__ bool sra_int(Str &h, unsigned &i, int &out) {	// PARSE_SRA_INT, seqid.c:139
-	unsigned v = 0;
-	for (;;) {
-		const int ch = h.at(i);
-		if (ch == 0 || ch == '.' || ch == ' ')
-			break;
-		if (ch < '0' || ch > '9')
-			return false;
-		v = v * 10u + (unsigned) (ch - '0');
-		i++;
-	}
-	out = (int) v;
-	return true;
-}
-
-// PARSE_STR, seqid.c:140; a chunk of 100 characters or more fails (the reference overruns its field there)
-__device__ __forceinline__ bool chunk_str(Str &h, unsigned &i, unsigned &off, unsigned &len) {
-	if (h.at(i) == 0)
-		return false;
-	off = i;
-	while (!ends_chunk(h.at(i))) {
-		if (i - off + 1 >= ID_STR_MAX)
-			return false;
-		i++;
-	}
-	len = i - off;
-	return true;
-}
-
-__device__ __forceinline__ bool chunk_tag(Str &h, unsigned &i, unsigned &off, unsigned &len) {	// seqid.c:222-228,268-274
-	off = i;
-	while (!ends_chunk(h.at(i))) {
-		if (i - off >= PAMD_TAG_LEN)
-			return false;
-		i++;
-	}
-	len = i - off;
-	return true;
-}
-
-__device__ __forceinline__ bool policy_ok(unsigned tag_len, int policy) {
-	if (policy == PAMD_TAG_OPTIONAL)
-		return true;
-	return policy == (tag_len == 0 ? PAMD_TAG_ABSENT : PAMD_TAG_PRESENT);
-}
-
-#define NEED(x)               \
-	do {                  \
-		if (!(x))     \
-			return 0; \
-	} while (0)
-
-// panda_seqid_parse_fail (seqid.c:142-285): the mate direction, 0 = not parsed
+// returns the mate direction, 0 = not parsed
 __device__ int parse_header(Str &h, int policy, IdOut &o) {
 	unsigned i = 0;
-	int value = 0;
 	o.instr_len = o.run_off = o.run_len = o.fc_off = o.fc_len = o.tag_off = o.tag_len = 0;
 	o.lane = o.tile = o.x = o.y = 0;
 	o.sra = -1;
 	o.fmt = PAMD_IDFMT_UNKNOWN;
 	const int c0 = h.at(0), c1 = h.at(1), c2 = h.at(2), c3 = h.at(3);
 	if (c0 != 0 && c1 != 0 && c2 != 0 && c3 != 0 && (c0 == 'E' || c0 == 'S') && c1 == 'R' && c2 == 'R') {
+		// Short Read Archive (seqid.c:157-172): <E|S>RR<number>.<number> and nothing else is kept
 		o.fmt = c0 == 'S' ? PAMD_IDFMT_SRA : PAMD_IDFMT_EBI_SRA;
-		i = 3;
-		NEED(sra_int(h, i, value));
-		NEED(step(h, i));
-		o.sra = value;
 		o.instr_len = 3;
-		NEED(sra_int(h, i, value));
-		NEED(step(h, i));
-		o.lane = value;
-		NEED(step(h, i));
-		return 1;
+		i = 3;
+		for (int field = 0; field < 2; field++) {	// PARSE_SRA_INT + PARSE_PUSH, twice
+			unsigned v = 0;
+			for (;;) {
+				const int ch = h.at(i);
+				if (ch == 0 || ch == '.' || ch == ' ')
+					break;
+				if (ch < '0' || ch > '9')
+					return 0;
+				v = v * 10u + (unsigned) (ch - '0');
+				i++;
+			}
+			if (h.at(i) == 0)
+				return 0;
+			i++;
+			if (field == 0)
+				o.sra = (int) v;
+			else
+				o.lane = (int) v;
+		}
+		return h.at(i) == 0 ? 0 : 1;	// the last PARSE_PUSH
 	}
-	bool slash = false;
+	bool slash = false, before_hash = true;
 	unsigned colons = 0;
-	bool before_hash = true;
 	for (unsigned k = 0;; k++) {
 		const int ch = h.at(k);
 		if (ch == 0)
@@ -299,105 +262,78 @@ __device__ int parse_header(Str &h, int policy, IdOut &o) {
 		before_hash &= ch != '#';
 		colons += (before_hash && ch == ':') ? 1u : 0u;
 	}
-	unsigned off, len;
-	if (slash) {
-		if (colons == 6) {
-			o.fmt = PAMD_IDFMT_CASAVA_CONVERTED;
-			NEED(chunk_str(h, i, off, len));
+	o.fmt = !slash ? PAMD_IDFMT_CASAVA_1_7 : (colons == 6 ? PAMD_IDFMT_CASAVA_CONVERTED : PAMD_IDFMT_CASAVA_1_4);
+	u64 prog = !slash ? PROG_17 : (colons == 6 ? PROG_CONV : PROG_14);
+	int mate = 0;
+	for (;;) {
+		const int op = (int) (prog & 15ull);
+		prog >>= 4;
+		if (op == OP_RET)
+			return mate;
+		if (op == OP_POLICY) {
+			if (policy != PAMD_TAG_OPTIONAL && policy != (o.tag_len == 0 ? PAMD_TAG_ABSENT : PAMD_TAG_PRESENT))
+				return 0;
+			continue;
+		}
+		if (op == OP_HASHTAG && h.at(i - 1) != '#')
+			continue;
+		const bool is_int = (op >= OP_INT_LANE && op <= OP_INT_MATE) || op == OP_INT_DROP || op == OP_MATE;
+		const bool is_tag = op == OP_TAG || op == OP_HASHTAG;
+		const bool push = op <= OP_INT_DROP || op == OP_HASHTAG;
+		const unsigned limit = op <= OP_STR_FC ? ID_STR_MAX - 1u : (is_tag ? (unsigned) PAMD_TAG_LEN : 0xFFFFFFFFu);
+		int ch = h.at(i);
+		if (!is_tag && ch == 0)
+			return 0;
+		const unsigned off = i;
+		unsigned v = 0;
+		while (!ends_chunk(ch)) {
+			if (is_int && (ch < '0' || ch > '9'))
+				return 0;
+			if (i - off >= limit)
+				return 0;
+			v = v * 10u + (unsigned) (ch - '0');
+			i++;
+			ch = h.at(i);
+		}
+		const unsigned len = i - off;
+		if (op == OP_STR_INSTR)
 			o.instr_len = len;
-			NEED(step(h, i));
-			NEED(chunk_str(h, i, off, len));
+		if (op == OP_STR_RUN) {
 			o.run_off = off;
 			o.run_len = len;
-			NEED(step(h, i));
-			NEED(chunk_str(h, i, off, len));
+		}
+		if (op == OP_STR_FC) {
 			o.fc_off = off;
 			o.fc_len = len;
-			NEED(step(h, i));
-		} else {
-			o.fmt = PAMD_IDFMT_CASAVA_1_4;
-			NEED(chunk_str(h, i, off, len));
-			o.instr_len = len;
-			NEED(step(h, i));
 		}
-		NEED(chunk_int(h, i, o.lane));
-		NEED(step(h, i));
-		NEED(chunk_int(h, i, o.tile));
-		NEED(step(h, i));
-		NEED(chunk_int(h, i, o.x));
-		NEED(step(h, i));
-		NEED(chunk_int(h, i, o.y));
-		NEED(step(h, i));
-		if (h.at(i - 1) == '#') {
-			NEED(chunk_tag(h, i, off, len));
+		if (is_tag) {
 			o.tag_off = off;
 			o.tag_len = len;
-			NEED(step(h, i));
 		}
-		NEED(policy_ok(o.tag_len, policy));
-		NEED(chunk_int(h, i, value));
-		return value;
+		o.lane = op == OP_INT_LANE ? (int) v : o.lane;
+		o.tile = op == OP_INT_TILE ? (int) v : o.tile;
+		o.x = op == OP_INT_X ? (int) v : o.x;
+		o.y = op == OP_INT_Y ? (int) v : o.y;
+		mate = (op == OP_INT_MATE || op == OP_MATE) ? (int) v : mate;
+		if (push) {
+			if (ch == 0)
+				return 0;
+			i++;
+		}
 	}
-	int mate = 0;
-	o.fmt = PAMD_IDFMT_CASAVA_1_7;
-	NEED(chunk_str(h, i, off, len));
-	o.instr_len = len;
-	NEED(step(h, i));
-	NEED(chunk_str(h, i, off, len));
-	o.run_off = off;
-	o.run_len = len;
-	NEED(step(h, i));
-	NEED(chunk_str(h, i, off, len));
-	o.fc_off = off;
-	o.fc_len = len;
-	NEED(step(h, i));
-	NEED(chunk_int(h, i, o.lane));
-	NEED(step(h, i));
-	NEED(chunk_int(h, i, o.tile));
-	NEED(step(h, i));
-	NEED(chunk_int(h, i, o.x));
-	NEED(step(h, i));
-	NEED(chunk_int(h, i, o.y));
-	NEED(step(h, i));
-	NEED(chunk_int(h, i, mate));
-	NEED(step(h, i));
-	NEED(h.at(i) != 0);	// "filtered": any chunk, but not the end of the string
-	while (!ends_chunk(h.at(i)))
-		i++;
-	NEED(step(h, i));
-	NEED(chunk_int(h, i, value));	// control bits
-	NEED(step(h, i));
-	NEED(chunk_tag(h, i, off, len));
-	o.tag_off = off;
-	o.tag_len = len;
-	NEED(policy_ok(o.tag_len, policy));
-	return mate;
 }
 
-#undef NEED
-
-__device__ bool span_equal(Str &a, unsigned aoff, unsigned alen, Str &b, unsigned boff, unsigned blen) {
-	if (alen != blen)
-		return false;
-	for (unsigned k = 0; k < alen; k++)
-		if (a.at(aoff + k) != b.at(boff + k))
-			return false;
-	return true;
-}
-
-// panda_seqid_equal (seqid.c:96-101) on the parsed spans
-__device__ bool ids_equal(Str &f, const IdOut &a, Str &r, const IdOut &b) {
-	if (a.lane != b.lane || a.tile != b.tile || a.x != b.x || a.y != b.y)
-		return false;
-	if ((a.sra >= 0) != (b.sra >= 0))
-		return false;	// "<E|S>RR<n>" can never equal a parsed instrument chunk: such a chunk would itself be read as SRA
-	if (a.sra >= 0) {
-		if (a.sra != b.sra || f.at(0) != r.at(0))
-			return false;
-	} else if (!span_equal(f, 0, a.instr_len, r, 0, b.instr_len)) {
-		return false;
+// are the spans [aoff, aoff+len) of this lane's string and [boff, ...) of its partner's (lane ^ 1) equal?
+// Both lanes of a pair call this with mirrored arguments.
+__device__ __forceinline__ bool span_equal_pair(Str &h, unsigned off, unsigned len) {
+	const unsigned plen = (unsigned) __shfl_xor((int) len, 1);
+	bool same = len == plen;
+	const unsigned n = same ? len : 0u;	// the same trip count on both lanes of the pair
+	for (unsigned k = 0; k < n; k++) {
+		const int c = h.at(off + k);
+		same &= c == __shfl_xor(c, 1);
 	}
-	return span_equal(f, a.run_off, a.run_len, r, b.run_off, b.run_len) && span_equal(f, a.fc_off, a.fc_len, r, b.fc_off, b.fc_len) && span_equal(f, a.tag_off, a.tag_len, r, b.tag_off, b.tag_len);
+	return same;
 }
 
 // ---- ASCII -> nt ------------------------------------------------------------------------------------
@@ -441,13 +377,14 @@ __device__ __forceinline__ unsigned nt_complement(unsigned v) {
 	return ((v & 1u) << 3) | ((v & 2u) << 1) | ((v & 4u) >> 1) | ((v & 8u) >> 3);
 }
 
-// four bytes of a text starting at byte offset a (any alignment), from two aligned words
-__device__ __forceinline__ unsigned load4(const uint8_t *text, u64 bytes, unsigned a) {
+// four bytes of a text starting at byte offset a < bytes (any alignment), from two aligned words; no
+// branch: the second word's address is clamped to the text's last word (bytes past the text are always
+// past the line too, and the callers mask those)
+__device__ __forceinline__ unsigned load4(const TextRef &T, unsigned a) {
 	const unsigned a0 = a & ~3u;
-	const unsigned lo = *reinterpret_cast<const unsigned *>(text + a0);
-	unsigned hi = 0;
-	if ((a & 3u) != 0 && (u64) a0 + 4u < bytes)
-		hi = *reinterpret_cast<const unsigned *>(text + a0 + 4u);
+	const unsigned a1 = a0 + 4u < T.last_word ? a0 + 4u : T.last_word;
+	const unsigned lo = *reinterpret_cast<const unsigned *>(T.text + a0);
+	const unsigned hi = *reinterpret_cast<const unsigned *>(T.text + a1);
 	return __builtin_amdgcn_alignbyte(hi, lo, a & 3u);
 }
 
@@ -465,99 +402,187 @@ struct ParseParams {
 	int policy;
 };
 
+// ---- four characters at a time ----------------------------------------------------------------------
+// 0x80 in every byte of x that is zero (exact: no borrow between bytes)
+__device__ __forceinline__ unsigned zero_bytes(unsigned x) {
+	return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+
+// 0xFF in each of the first n (0..4) bytes
+__device__ __forceinline__ unsigned first_bytes(int n) {
+	n = n < 0 ? 0 : (n > 4 ? 4 : n);
+	return n == 4 ? 0xFFFFFFFFu : (1u << (8 * n)) - 1u;
+}
+
+// The 32-entry tables as bytes, eight entries per 64-bit word: a v_perm_b32 looks four characters up in one
+// eight-entry slice, two bit-selects pick the slice each character belongs to.
+constexpr u64 nt_slice(int slice, bool complement) {
+	u64 v = 0;
+	for (int k = 0; k < 8; k++) {
+		const int idx = slice * 8 + k;
+		unsigned e = (unsigned) ((idx < 16 ? NT_LO : NT_HI) >> (4 * (idx & 15))) & 15u;
+		if (complement)
+			e = ((e & 1u) << 3) | ((e & 2u) << 1) | ((e & 4u) >> 1) | ((e & 8u) >> 3);
+		v |= (u64) e << (8 * k);
+	}
+	return v;
+}
+
+template <bool COMPLEMENT>
+__device__ __forceinline__ unsigned nt_of_chars(unsigned w) {
+	constexpr u64 S0 = nt_slice(0, COMPLEMENT), S1 = nt_slice(1, COMPLEMENT), S2 = nt_slice(2, COMPLEMENT), S3 = nt_slice(3, COMPLEMENT);
+	const unsigned sel = w & 0x07070707u;
+	const unsigned p0 = __builtin_amdgcn_perm((unsigned) (S0 >> 32), (unsigned) S0, sel);
+	const unsigned p1 = __builtin_amdgcn_perm((unsigned) (S1 >> 32), (unsigned) S1, sel);
+	const unsigned p2 = __builtin_amdgcn_perm((unsigned) (S2 >> 32), (unsigned) S2, sel);
+	const unsigned p3 = __builtin_amdgcn_perm((unsigned) (S3 >> 32), (unsigned) S3, sel);
+	const unsigned b3 = (w >> 3) & 0x01010101u, b4 = (w >> 4) & 0x01010101u;
+	const unsigned m3 = (b3 << 8) - b3, m4 = (b4 << 8) - b4;	// 0xFF where the bit is set
+	const unsigned lo = (p1 & m3) | (p0 & ~m3), hi = (p3 & m3) | (p2 & ~m3);
+	return (hi & m4) | (lo & ~m4);
+}
+
+// TOINDEX (fastq.c:44) on four characters: below the offset -> 0, above offset + 46 -> 46 - offset
+// (the reference's own clamp quirk), else c - offset; characters are signed.  `valid` marks the bytes
+// that belong to the line.  The wave takes the one-subtraction path when every lane's characters are
+// inside [offset, offset + 46].
+__device__ __forceinline__ unsigned quals_of_chars(unsigned w, int qualmin, unsigned valid) {
+	const unsigned ones = 0x01010101u;
+	const unsigned x = (w & valid) | ((unsigned) qualmin * ones & ~valid);
+	const unsigned ge = ((x | 0x80808080u) - (unsigned) qualmin * ones) & 0x80808080u;		// bit 7 kept <=> byte >= offset
+	const unsigned le = (((unsigned) (qualmin + 46) * ones | 0x80808080u) - x) & 0x80808080u;	// bit 7 kept <=> byte <= offset + 46
+	const bool plain = qualmin <= 81 && ((x & 0x80808080u) == 0u) && ge == 0x80808080u && le == 0x80808080u;
+	if (__ballot(!plain) == 0)
+		return (x - (unsigned) qualmin * ones) & valid;
+	unsigned out = 0;
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const int v = (int) (int8_t) ((w >> (8 * k)) & 0xFFu);
+		const int q = v < qualmin ? 0 : ((v > qualmin + 46 ? 46 : v) - qualmin);
+		out |= ((unsigned) q & 0xFFu) << (8 * k);
+	}
+	return out & valid;
+}
+
+// The characters one lane owns of one read's three lines: 4 of the sequence and 4 of the quality line
+// per step of 256 (two steps cover PAMD_MAX_LEN), and the first character of the '+' line.  Loaded in one
+// go, one record ahead of their use, so the memory round trips overlap the previous record's arithmetic.
+struct ReadWords {
+	unsigned seq[2], qual[2], plus;
+};
+
+struct ReadSpan {	// wave-uniform: start and length of the three lines, "too long for the line reader" flags
+	unsigned s_seq, l_seq, s_plus, l_plus, s_q, l_q;
+	bool seq_long, plus_long, q_long;
+};
+
+__device__ __forceinline__ ReadWords load_words(const TextRef &T, const ReadSpan &R, int lane) {
+	ReadWords W;
+	// no branch around a load: a lane past the end of its line re-reads the line's first word (masked later)
+	const unsigned i0 = 4u * (unsigned) lane;
+	W.seq[0] = load4(T, R.s_seq + (i0 < R.l_seq ? i0 : 0u));
+	W.qual[0] = load4(T, R.s_q + (i0 < R.l_q ? i0 : 0u));
+	W.plus = load4(T, R.s_plus) & 0xFFu;
+	W.seq[1] = 0;
+	W.qual[1] = 0;
+	if (R.l_seq > 256u || R.l_q > 256u) {	// wave-uniform: reads of up to 256 bases take one step
+		const unsigned i1 = 256u + i0;
+		W.seq[1] = load4(T, R.s_seq + (i1 < R.l_seq ? i1 : 0u));
+		W.qual[1] = load4(T, R.s_q + (i1 < R.l_q ? i1 : 0u));
+	}
+	return W;
+}
+
 // One read: its three lines -> one row.  Returns 0 or the PAMD_FQ_* code read_seq() fails with
-// (fastq.c:45-107).  Wave-uniform arguments and result.
-__device__ int convert_read(const TextRef &T, bool complement, int qualmin, unsigned s_seq, unsigned l_seq, bool seq_long, unsigned s_plus, unsigned l_plus, bool plus_long, unsigned s_q, unsigned l_q, bool q_long, uint8_t *row, unsigned stride, int lane, unsigned &len_out, bool &under64) {
+// (fastq.c:45-107).  Wave-uniform result.  Lane l owns characters 4l .. 4l+3 of a step of 256.
+template <bool COMPLEMENT>
+__device__ __forceinline__ int finish_read(const TextRef &T, const ReadSpan &R, const ReadWords &W, int qualmin, uint8_t *row, unsigned stride, int lane, unsigned &len_out, bool &under64) {
 	len_out = 0;
-	if (seq_long)
+	if (R.seq_long)
 		return PAMD_FQ_EOF;
-	// sequence line: the first PAMD_MAX_LEN characters, up to the first NUL (fastq.c:62)
-	unsigned nts[2] = { 0u, 0u };	// four nt codes per step, one byte each
-	unsigned eff = 0xFFFFFFFFu, bad = 0xFFFFFFFFu;
+	// sequence line: the first PAMD_MAX_LEN characters, up to the first NUL (fastq.c:62).  Characters past
+	// the line read as NUL, so the first NUL found is the string length.
+	unsigned nts[2] = { 0u, 0u };
+	unsigned eff = 512u, bad = 0xFFFFFFFFu;
 #pragma unroll
 	for (int it = 0; it < 2; it++) {
+		if (it == 1 && eff < 512u)
+			break;
 		const unsigned idx = 256u * it + 4u * (unsigned) lane;
-		unsigned w = 0;
-		if (idx < l_seq)
-			w = load4(T.text, T.bytes, s_seq + idx);
-		unsigned packed = 0, zero_at = 4, bad_at = 4;
-#pragma unroll
-		for (int k = 3; k >= 0; k--) {
-			const unsigned c = idx + k < l_seq ? (w >> (8 * k)) & 0xFFu : 0u;
-			unsigned nt = nt_forward(c);
-			if (complement)
-				nt = nt_complement(nt);
-			packed |= nt << (8 * k);
-			zero_at = c == 0 ? (unsigned) k : zero_at;
-			bad_at = (c != 0 && nt == 0) ? (unsigned) k : bad_at;
-		}
-		nts[it] = packed;
-		const u64 zb = __ballot(zero_at < 4);
-		if (zb != 0 && eff == 0xFFFFFFFFu) {
+		const unsigned vs = first_bytes((int) R.l_seq - (int) idx);
+		const unsigned w = W.seq[it] & vs;
+		const unsigned nt4 = nt_of_chars<COMPLEMENT>(w);
+		const unsigned zw = zero_bytes(w);
+		const unsigned bw = zero_bytes(nt4) & ~zw;	// a character that is no nucleotide
+		nts[it] = nt4;
+		const u64 zb = __ballot(zw != 0u);
+		if (zb != 0) {
 			const int l0 = __builtin_ctzll(zb);
-			eff = 256u * it + 4u * l0 + (unsigned) __builtin_amdgcn_readlane((int) zero_at, l0);
+			eff = 256u * it + 4u * l0 + ((unsigned) __builtin_ctz((unsigned) __builtin_amdgcn_readlane((int) zw, l0)) >> 3);
 		}
-		const u64 bb = __ballot(bad_at < 4);
+		const u64 bb = __ballot(bw != 0u);
 		if (bb != 0 && bad == 0xFFFFFFFFu) {
 			const int l0 = __builtin_ctzll(bb);
-			bad = 256u * it + 4u * l0 + (unsigned) __builtin_amdgcn_readlane((int) bad_at, l0);
+			bad = 256u * it + 4u * l0 + ((unsigned) __builtin_ctz((unsigned) __builtin_amdgcn_readlane((int) bw, l0)) >> 3);
 		}
 	}
 	const unsigned pos = eff < PAMD_MAX_LEN ? eff : PAMD_MAX_LEN;
 	if (bad < pos)
 		return PAMD_FQ_BADNT;
 	// '+' line (fastq.c:68-83)
-	if (plus_long)
+	if (R.plus_long)
 		return PAMD_FQ_EOF;
 	{
-		unsigned c = 0;
-		if (l_plus > 0)
-			c = load4(T.text, T.bytes, s_plus) & 0xFFu;
-		c = (unsigned) uni((int) c);
+		const unsigned c = R.l_plus > 0 ? (unsigned) uni((int) W.plus) : 0u;
 		if (c != '+')
-			return nt_forward(c) != 0 ? PAMD_FQ_READLEN : PAMD_FQ_BADSEQ;
+			return (nt_of_chars<false>(c) & 0xFFu) != 0 ? PAMD_FQ_READLEN : PAMD_FQ_BADSEQ;
 	}
 	// quality line: every character up to the first NUL counts (fastq.c:89-94)
-	if (q_long)
+	if (R.q_long)
 		return PAMD_FQ_EOF;
-	unsigned quals0 = 0u, quals1 = 0u;
+	unsigned quals[2] = { 0u, 0u };
 	unsigned qeff = 0xFFFFFFFFu;
 	bool u64seen = false;
-	for (unsigned base = 0; base < l_q || base < 512u; base += 256u) {
-		const unsigned idx = base + 4u * (unsigned) lane;
-		unsigned w = 0;
-		if (idx < l_q)
-			w = load4(T.text, T.bytes, s_q + idx);
-		unsigned packed = 0, zero_at = 4;
-		bool low = false;
 #pragma unroll
-		for (int k = 3; k >= 0; k--) {
-			const unsigned c = idx + k < l_q ? (w >> (8 * k)) & 0xFFu : 0u;
-			const int v = (int) (int8_t) c;
-			// TOINDEX, fastq.c:44 (above qualmin + 46 the result is 46 - qualmin: the reference's own quirk)
-			const int q = v < qualmin ? 0 : ((v > qualmin + 46 ? 46 : v) - qualmin);
-			packed |= ((unsigned) q & 0xFFu) << (8 * k);
-			zero_at = c == 0 ? (unsigned) k : zero_at;
-		}
-		// characters before this lane's first NUL that are below 64
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const unsigned c = (w >> (8 * k)) & 0xFFu;
-			low |= (unsigned) k < zero_at && idx + k < l_q && (int) (int8_t) c < 64;
-		}
-		if (base == 0u)
-			quals0 = packed;
-		else if (base == 256u)
-			quals1 = packed;
-		const u64 zb = __ballot(zero_at < 4);
+	for (int it = 0; it < 2; it++) {
+		if (it == 1 && qeff != 0xFFFFFFFFu)
+			break;
+		const unsigned idx = 256u * it + 4u * (unsigned) lane;
+		const unsigned valid = first_bytes((int) R.l_q - (int) idx);
+		const unsigned w = W.qual[it] & valid;
+		const unsigned zw = zero_bytes(w);
+		// valid characters before this lane's first NUL that are below 64 (signed: 128.. count as well)
+		const unsigned before = zw != 0u ? (1u << (__builtin_ctz(zw) & ~7)) - 1u : 0xFFFFFFFFu;
+		const unsigned ge64 = ((w & 0x7F7F7F7Fu) + 0x40404040u) & ~w & 0x80808080u;	// bit 7 <=> 64 <= byte < 128
+		const bool low = (~ge64 & 0x80808080u & valid & before) != 0u;
+		quals[it] = quals_of_chars(w, qualmin, valid);
+		const u64 zb = __ballot(zw != 0u);
 		const u64 lowb = __ballot(low);
 		if (zb != 0) {
 			const int l0 = __builtin_ctzll(zb);
-			qeff = base + 4u * l0 + (unsigned) __builtin_amdgcn_readlane((int) zero_at, l0);
+			qeff = 256u * it + 4u * l0 + ((unsigned) __builtin_ctz((unsigned) __builtin_amdgcn_readlane((int) zw, l0)) >> 3);
 			u64seen |= (lowb & ((2ull << l0) - 1ull)) != 0;
-			break;
+		} else {
+			u64seen |= lowb != 0;
 		}
-		u64seen |= lowb != 0;
+	}
+	if (qeff == 0xFFFFFFFFu) {
+		// 512 characters and no end yet: already too long for any read (NOQUAL below); only the under-64
+		// hint still looks at the rest
+		qeff = R.l_q;
+		for (unsigned base = 512u; base < R.l_q; base += 64u) {
+			const unsigned i = base + (unsigned) lane;
+			const int c = i < R.l_q ? (int) T.text[R.s_q + i] : 1;
+			const u64 zb = __ballot(c == 0);
+			const u64 lowb = __ballot(i < R.l_q && (int) (int8_t) c < 64);
+			if (zb != 0) {
+				const int l0 = __builtin_ctzll(zb);
+				qeff = base + (unsigned) l0;
+				u64seen |= (lowb & ((1ull << l0) - 1ull)) != 0;
+				break;
+			}
+			u64seen |= lowb != 0;
+		}
 	}
 	under64 |= u64seen;
 	if (qeff != pos)
@@ -570,109 +595,172 @@ __device__ int convert_read(const TextRef &T, bool complement, int qualmin, unsi
 	for (int it = 0; it < 2; it++) {
 		const unsigned idx = 256u * it + 4u * (unsigned) lane;
 		if (idx < stride) {
-			const unsigned n4 = nts[it], q4 = it == 0 ? quals0 : quals1;
-			unsigned o[4];
-#pragma unroll
-			for (int k = 0; k < 4; k++)
-				o[k] = idx + k < pos ? (((n4 >> (8 * k)) & 0xFFu) | (((q4 >> (8 * k)) & 0xFFu) << 8)) : 0u;
-			*reinterpret_cast<uint2 *>(row + 2u * idx) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+			const unsigned keep = first_bytes((int) pos - (int) idx);
+			const unsigned n4 = nts[it] & keep, q4 = quals[it] & keep;
+			// interleave: nt0 q0 nt1 q1 | nt2 q2 nt3 q3
+			*reinterpret_cast<uint2 *>(row + 2u * idx) = make_uint2(__builtin_amdgcn_perm(q4, n4, 0x05010400u), __builtin_amdgcn_perm(q4, n4, 0x07030602u));
 		}
 	}
 	return 0;
 }
 
-__global__ __launch_bounds__(256) void fq_parse_kernel(const ParseParams P) {
+// a monotone device minimum that stops issuing atomics once it has converged
+__device__ __forceinline__ void note_first(u64 *word, u64 rec) {
+	if (rec < __atomic_load_n(word, __ATOMIC_RELAXED))
+		atomicMin(word, rec);
+}
+
+// the four lines of record `rec` of one text: start and length (without the line end) of each, and a bit
+// per line that is too long for the reference's line reader
+struct Lines {
+	unsigned s0, l0, s1, l1, s2, l2, s3, l3, toolong;
+};
+
+__device__ __forceinline__ void one_line(const TextRef &T, unsigned &prev, unsigned end, unsigned &start, unsigned &len, unsigned &toolong, unsigned bit) {
+	len = end - prev;
+	toolong |= len >= PAMD_LINE_MAX ? bit : 0u;	// the '\n' must lie inside the line reader's buffer, linebuf.c:68
+	if (len > 0 && T.text[end - 1] == '\r')	// DOS line ends, linebuf.c:81-84
+		len--;
+	start = prev;
+	prev = end + 1u;
+}
+
+__device__ __forceinline__ Lines record_lines(const TextRef &T, u64 rec) {
+	Lines L;
+	unsigned prev = rec == 0 ? 0u : T.line_end[4 * rec - 1] + 1u;
+	const unsigned e0 = T.line_end[4 * rec], e1 = T.line_end[4 * rec + 1], e2 = T.line_end[4 * rec + 2], e3 = T.line_end[4 * rec + 3];
+	L.toolong = 0;
+	one_line(T, prev, e0, L.s0, L.l0, L.toolong, 1u);
+	one_line(T, prev, e1, L.s1, L.l1, L.toolong, 2u);
+	one_line(T, prev, e2, L.s2, L.l2, L.toolong, 4u);
+	one_line(T, prev, e3, L.s3, L.l3, L.toolong, 8u);
+	return L;
+}
+
+__device__ __forceinline__ ReadSpan span_of(const Lines &L, int j) {
+	ReadSpan R;
+	R.s_seq = (unsigned) __builtin_amdgcn_readlane((int) L.s1, j);
+	R.l_seq = (unsigned) __builtin_amdgcn_readlane((int) L.l1, j);
+	R.s_plus = (unsigned) __builtin_amdgcn_readlane((int) L.s2, j);
+	R.l_plus = (unsigned) __builtin_amdgcn_readlane((int) L.l2, j);
+	R.s_q = (unsigned) __builtin_amdgcn_readlane((int) L.s3, j);
+	R.l_q = (unsigned) __builtin_amdgcn_readlane((int) L.l3, j);
+	const unsigned t = (unsigned) __builtin_amdgcn_readlane((int) L.toolong, j);
+	R.seq_long = (t & 2u) != 0;
+	R.plus_long = (t & 4u) != 0;
+	R.q_long = (t & 8u) != 0;
+	return R;
+}
+
+// ---- headers (fastq.c:123-144): two lanes per record, the even one on the forward header, the odd one on
+// the reverse header; the pair compares its results through lane exchanges (panda_seqid_equal, seqid.c:96-101)
+__global__ __launch_bounds__(256) void fq_ids_kernel(const ParseParams P) {
+	const u64 tid = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+	const u64 rec = tid >> 1;
+	const bool rev = (tid & 1ull) != 0;
+	const bool have = rec < P.n_records;	// both lanes of a pair agree
+	const TextRef &T = rev ? P.r : P.f;
+	unsigned start = 0, len = 0;
+	bool toolong = false;
+	if (have) {
+		start = rec == 0 ? 0u : T.line_end[4 * rec - 1] + 1u;
+		const unsigned end = T.line_end[4 * rec];
+		len = end - start;
+		toolong = len >= PAMD_LINE_MAX;	// the '\n' must lie inside the line reader's buffer, linebuf.c:68
+		if (len > 0 && T.text[end - 1] == '\r')	// DOS line ends, linebuf.c:81-84
+			len--;
+	}
+	Str h = { T.text, start + 1u, len > 0 ? len - 1u : 0u, 0xFFFFFFFFu, 0u };
+	IdOut id;
+	id.instr_len = id.run_off = id.run_len = id.fc_off = id.fc_len = id.tag_off = id.tag_len = 0;
+	id.lane = id.tile = id.x = id.y = 0;
+	id.sra = -1;
+	id.fmt = 0;
+	int dir = 0;
+	if (have && !toolong && len > 0)	// an empty header line fails too (the reference reads past its terminator)
+		dir = parse_header(h, P.policy, id);
+	// ---- the pair compares ----
+	const bool p_toolong = __shfl_xor((int) toolong, 1) != 0;
+	const int p_dir = __shfl_xor(dir, 1);
+	bool equal = id.lane == __shfl_xor(id.lane, 1) && id.tile == __shfl_xor(id.tile, 1) && id.x == __shfl_xor(id.x, 1) && id.y == __shfl_xor(id.y, 1);
+	const int p_sra = __shfl_xor(id.sra, 1);
+	// "<E|S>RR<n>" can never equal a parsed instrument chunk (such a chunk would itself be read as SRA)
+	equal &= (id.sra >= 0) == (p_sra >= 0);
+	const int first = h.at(0);
+	const bool sra_same = id.sra == p_sra && first == __shfl_xor(first, 1);
+	const bool instr_same = span_equal_pair(h, 0, id.sra >= 0 ? 0u : id.instr_len);
+	equal &= id.sra >= 0 ? sra_same : instr_same;
+	equal &= span_equal_pair(h, id.run_off, id.run_len);
+	equal &= span_equal_pair(h, id.fc_off, id.fc_len);
+	equal &= span_equal_pair(h, id.tag_off, id.tag_len);
+	if (!have || rev)
+		return;
+	int err = 0;
+	if (toolong)
+		err = PAMD_FQ_LONG_HEADER;
+	else if (dir == 0)
+		err = PAMD_FQ_BADID_FWD;
+	else if (p_toolong)
+		err = PAMD_FQ_LONG_HEADER;
+	else if (p_dir == 0)
+		err = PAMD_FQ_BADID_REV;
+	else if (!equal || (id.fmt != PAMD_IDFMT_SRA && id.fmt != PAMD_IDFMT_EBI_SRA && p_dir == dir))
+		err = PAMD_FQ_NOTPAIRED;
+	const unsigned flag = err != 0 ? 16u + (unsigned) err : 0u;
+	P.flags[rec] = (uint8_t) flag;
+	const u64 hdr = (u64) start + 1ull;
+	uint4 *dst = reinterpret_cast<uint4 *>(&P.ids[rec]);
+	dst[0] = make_uint4((unsigned) hdr, (unsigned) (hdr >> 32), (unsigned) id.lane, (unsigned) id.tile);
+	dst[1] = make_uint4((unsigned) id.x, (unsigned) id.y, (unsigned) id.sra, id.instr_len | (id.run_off << 16));
+	dst[2] = make_uint4(id.run_len | (id.fc_off << 16), id.fc_len | (id.tag_off << 16), id.tag_len | ((unsigned) id.fmt << 16) | (((unsigned) dir & 0xFFu) << 24), flag);
+	if (err != 0)
+		note_first(P.first_bad, rec);
+	else if (id.fmt == PAMD_IDFMT_CASAVA_1_7)	// CASAVA 1.7+ is always PHRED+33: fastq.c:141-144
+		note_first(P.first_u64, rec);
+}
+
+// ---- reads (fastq.c:145-154): 32 records per wave, converted one record at a time by the whole wave;
+// lanes 0..31 hold the forward line spans of the 32 records, lanes 32..63 the reverse ones, and record
+// j+1's characters are loaded while record j is converted
+constexpr int READS_PER_WAVE = 32;
+
+__global__ __launch_bounds__(256) void fq_reads_kernel(const ParseParams P) {
 	const int lane = threadIdx.x & 63;
 	const u64 wave = ((u64) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	const u64 rec0 = wave * 64ull;
+	const u64 rec0 = wave * READS_PER_WAVE;
 	if (rec0 >= P.n_records)
 		return;
-	const u64 rec = rec0 + (u64) lane;
-	const bool have = rec < P.n_records;
-	// ---- this lane's record: line spans ----
-	unsigned fs[4], fl[4], rs[4], rl[4];
-	bool flong[4], rlong[4];
-#pragma unroll
-	for (int k = 0; k < 4; k++) {
-		fs[k] = fl[k] = rs[k] = rl[k] = 0;
-		flong[k] = rlong[k] = false;
-	}
-	if (have) {
-#pragma unroll
-		for (int t = 0; t < 2; t++) {
-			const TextRef &T = t == 0 ? P.f : P.r;
-			unsigned prev = rec == 0 ? 0u : T.line_end[4 * rec - 1] + 1u;
-#pragma unroll
-			for (int k = 0; k < 4; k++) {
-				const unsigned end = T.line_end[4 * rec + k];
-				unsigned len = end - prev;
-				const bool toolong = len >= PAMD_LINE_MAX;	// the '\n' must lie inside the line reader's buffer, linebuf.c:68
-				if (len > 0 && T.text[end - 1] == '\r')	// DOS line ends, linebuf.c:81-84
-					len--;
-				if (t == 0) {
-					fs[k] = prev;
-					fl[k] = len;
-					flong[k] = toolong;
-				} else {
-					rs[k] = prev;
-					rl[k] = len;
-					rlong[k] = toolong;
-				}
-				prev = end + 1u;
-			}
-		}
-	}
-	// ---- headers, one record per lane (fastq.c:123-144) ----
+	const int nrec = (int) (P.n_records - rec0 < (u64) READS_PER_WAVE ? P.n_records - rec0 : (u64) READS_PER_WAVE);
+	const int slot = lane & (READS_PER_WAVE - 1);
+	const u64 rec = rec0 + (u64) slot;
+	Lines L = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
 	int err = 0;
-	IdOut fid;
-	fid.instr_len = fid.run_off = fid.run_len = fid.fc_off = fid.fc_len = fid.tag_off = fid.tag_len = 0;
-	fid.lane = fid.tile = fid.x = fid.y = 0;
-	fid.sra = -1;
-	fid.fmt = 0;
-	int fdir = 0;
-	if (have) {
-		Str hf = { P.f.text, fs[0] + 1u, fl[0] > 0 ? fl[0] - 1u : 0u, 0xFFFFFFFFu, 0u };
-		Str hr = { P.r.text, rs[0] + 1u, rl[0] > 0 ? rl[0] - 1u : 0u, 0xFFFFFFFFu, 0u };
-		IdOut rid;
-		if (flong[0]) {
-			err = PAMD_FQ_LONG_HEADER;
-		} else if (fl[0] == 0 || (fdir = parse_header(hf, P.policy, fid)) == 0) {
-			err = PAMD_FQ_BADID_FWD;	// an empty header line fails too (the reference reads past its terminator)
-		} else if (rlong[0]) {
-			err = PAMD_FQ_LONG_HEADER;
-		} else {
-			const int rdir = rl[0] == 0 ? 0 : parse_header(hr, P.policy, rid);
-			if (rdir == 0)
-				err = PAMD_FQ_BADID_REV;
-			else if (!ids_equal(hf, fid, hr, rid) || (fid.fmt != PAMD_IDFMT_SRA && fid.fmt != PAMD_IDFMT_EBI_SRA && rdir == fdir))
-				err = PAMD_FQ_NOTPAIRED;
-		}
+	if (slot < nrec) {
+		L = record_lines(lane < READS_PER_WAVE ? P.f : P.r, rec);
+		err = P.flags[rec];	// the headers may already have stopped the reader here
 	}
-	bool lane_u64 = have && err == 0 && fid.fmt == PAMD_IDFMT_CASAVA_1_7;	// fastq.c:141-144
+	bool lane_u64 = false;
 	int in_rev = 0;
 	unsigned my_flen = 0, my_rlen = 0;
-	// ---- reads, one record per wave (fastq.c:145-154) ----
-	const int nrec = (int) (P.n_records - rec0 < 64ull ? P.n_records - rec0 : 64ull);
+	ReadSpan nf = span_of(L, 0), nr = span_of(L, READS_PER_WAVE);
+	ReadWords nwf = load_words(P.f, nf, lane), nwr = load_words(P.r, nr, lane);
 	for (int j = 0; j < nrec; j++) {
+		const ReadSpan cf = nf, cr = nr;
+		const ReadWords wf = nwf, wr = nwr;
+		const int jn = j + 1 < nrec ? j + 1 : j;
+		nf = span_of(L, jn);
+		nr = span_of(L, READS_PER_WAVE + jn);
+		nwf = load_words(P.f, nf, lane);
+		nwr = load_words(P.r, nr, lane);
 		if (__builtin_amdgcn_readlane(err, j) != 0)
 			continue;
-		unsigned a[7], b[7];
-#pragma unroll
-		for (int k = 1; k < 4; k++) {
-			a[k] = (unsigned) __builtin_amdgcn_readlane((int) fs[k], j);
-			a[k + 3] = (unsigned) __builtin_amdgcn_readlane((int) fl[k], j);
-			b[k] = (unsigned) __builtin_amdgcn_readlane((int) rs[k], j);
-			b[k + 3] = (unsigned) __builtin_amdgcn_readlane((int) rl[k], j);
-		}
-		const bool fL1 = __builtin_amdgcn_readlane((int) flong[1], j), fL2 = __builtin_amdgcn_readlane((int) flong[2], j), fL3 = __builtin_amdgcn_readlane((int) flong[3], j);
-		const bool rL1 = __builtin_amdgcn_readlane((int) rlong[1], j), rL2 = __builtin_amdgcn_readlane((int) rlong[2], j), rL3 = __builtin_amdgcn_readlane((int) rlong[3], j);
 		unsigned flen_j = 0, rlen_j = 0;
 		bool low64 = false;
 		const u64 recj = rec0 + (u64) j;
-		int code = convert_read(P.f, false, P.qualmin, a[1], a[4], fL1, a[2], a[5], fL2, a[3], a[6], fL3, P.frows + recj * (u64) P.fstride * 2ull, P.fstride, lane, flen_j, low64);
+		int code = finish_read<false>(P.f, cf, wf, P.qualmin, P.frows + recj * (u64) P.fstride * 2ull, P.fstride, lane, flen_j, low64);
 		int rev_fail = 0;
 		if (code == 0) {
-			code = convert_read(P.r, true, P.qualmin, b[1], b[4], rL1, b[2], b[5], rL2, b[3], b[6], rL3, P.rrows + recj * (u64) P.rstride * 2ull, P.rstride, lane, rlen_j, low64);
+			code = finish_read<true>(P.r, cr, wr, P.qualmin, P.rrows + recj * (u64) P.rstride * 2ull, P.rstride, lane, rlen_j, low64);
 			rev_fail = code != 0;
 		}
 		if (lane == j) {
@@ -680,27 +768,31 @@ __global__ __launch_bounds__(256) void fq_parse_kernel(const ParseParams P) {
 			in_rev = rev_fail;
 			my_flen = code == 0 ? flen_j : 0u;
 			my_rlen = code == 0 ? rlen_j : 0u;
-			lane_u64 |= low64;
+			lane_u64 = low64;
 		}
 	}
-	// ---- per-record outputs ----
-	if (have) {
-		const unsigned flag = err != 0 ? (16u + (unsigned) err) | (in_rev ? 128u : 0u) : (my_flen == 0 ? 1u : 0u);
+	// ---- per-record outputs (lanes 0..31) ----
+	const bool mine = lane < nrec;
+	if (mine) {
+		const bool from_header = my_flen == 0 && my_rlen == 0 && err != 0 && P.flags[rec] != 0;
 		P.flen[rec] = (uint16_t) my_flen;
 		P.rlen[rec] = (uint16_t) my_rlen;
-		P.flags[rec] = (uint8_t) flag;
-		const u64 hdr = (u64) fs[0] + 1ull;
-		uint4 *dst = reinterpret_cast<uint4 *>(&P.ids[rec]);
-		dst[0] = make_uint4((unsigned) hdr, (unsigned) (hdr >> 32), (unsigned) fid.lane, (unsigned) fid.tile);
-		dst[1] = make_uint4((unsigned) fid.x, (unsigned) fid.y, (unsigned) fid.sra, fid.instr_len | (fid.run_off << 16));
-		dst[2] = make_uint4(fid.run_len | (fid.fc_off << 16), fid.fc_len | (fid.tag_off << 16), fid.tag_len | ((unsigned) fid.fmt << 16) | (((unsigned) fdir & 0xFFu) << 24), flag);
+		if (!from_header) {
+			const unsigned flag = err != 0 ? (16u + (unsigned) err) | (in_rev ? 128u : 0u) : (my_flen == 0 ? 1u : 0u);
+			if (flag != 0) {
+				P.flags[rec] = (uint8_t) flag;
+				reinterpret_cast<uint8_t *>(&P.ids[rec])[44] = (uint8_t) flag;
+			}
+		} else {
+			err = 0;	// already reported by the header kernel
+		}
 	}
-	const u64 badb = __ballot(have && err != 0);
+	const u64 badb = __ballot(mine && err != 0);
 	if (badb != 0 && lane == 0)
-		atomicMin(P.first_bad, rec0 + (u64) __builtin_ctzll(badb));
-	const u64 ub = __ballot(lane_u64);
+		note_first(P.first_bad, rec0 + (u64) __builtin_ctzll(badb));
+	const u64 ub = __ballot(mine && lane_u64);
 	if (ub != 0 && lane == 0)
-		atomicMin(P.first_u64, rec0 + (u64) __builtin_ctzll(ub));
+		note_first(P.first_u64, rec0 + (u64) __builtin_ctzll(ub));
 }
 
 struct FinalOut {	// device words the host reads back
@@ -1170,9 +1262,11 @@ int pamd_fastq_parse_device(pamd_fastq_parser *p, const char *fwd_text, size_t f
 	F.text = reinterpret_cast<const uint8_t *>(fwd_text);
 	F.bytes = fwd_bytes;
 	F.n_tiles = (unsigned) ((fwd_bytes + TILE_BYTES - 1) / TILE_BYTES);
+	F.last_word = (unsigned) ((fwd_bytes - 1) & ~(size_t) 3);
 	R.text = reinterpret_cast<const uint8_t *>(rev_text);
 	R.bytes = rev_bytes;
 	R.n_tiles = (unsigned) ((rev_bytes + TILE_BYTES - 1) / TILE_BYTES);
+	R.last_word = (unsigned) ((rev_bytes - 1) & ~(size_t) 3);
 	int rc;
 	if ((rc = p->counts_f.ensure((size_t) F.n_tiles * 4)) != PAMD_OK || (rc = p->counts_r.ensure((size_t) R.n_tiles * 4)) != PAMD_OK || (rc = p->small.ensure(256)) != PAMD_OK)
 		return rc;
@@ -1224,8 +1318,9 @@ int pamd_fastq_parse_device(pamd_fastq_parser *p, const char *fwd_text, size_t f
 		P.first_u64 = &d_final->first_u64;
 		P.qualmin = p->qualmin;
 		P.policy = p->policy;
-		const u64 waves = (n_records + 63) / 64;
-		hipLaunchKernelGGL(fq_parse_kernel, dim3((unsigned) ((waves + 3) / 4)), dim3(256), 0, st, P);
+		hipLaunchKernelGGL(fq_ids_kernel, dim3((unsigned) ((2 * n_records + 255) / 256)), dim3(256), 0, st, P);
+		const u64 waves = (n_records + READS_PER_WAVE - 1) / READS_PER_WAVE;
+		hipLaunchKernelGGL(fq_reads_kernel, dim3((unsigned) ((waves + 3) / 4)), dim3(256), 0, st, P);
 		hipLaunchKernelGGL(fq_final_kernel, dim3(grid_for((n_records + 63) / 64, 4, 1024)), dim3(256), 0, st, P, d_final);
 		HIP_TRY(hipEventRecord(p->ev[2], st));
 		HIP_TRY(hipMemcpyAsync(&fin, d_final, sizeof fin, hipMemcpyDeviceToHost, st));
