@@ -2,9 +2,8 @@
 // and accepted pairs -> FASTA / FASTQ text.  Byte work bounded by HBM bandwidth; no MFMA.
 //
 // Ingest (replaces fastq.c:45-198 + linebuf.c:57-89 + seqid.c:142-285 + nt.c:46-114):
-//   fq_count_kernel   newlines per 8 KB tile of each text                      (one wave per tile)
-//   fq_scan_kernel    exclusive scan of the tile counts                        (one workgroup per text)
-//   fq_index_kernel   byte offset of every '\n', in order                      (one wave per tile)
+//   fq_index_kernel   byte offset of every '\n', in order: one pass over the text, 8 KB tiles, one wave per
+//                     tile, line counts carried from tile to tile by a chained scan with look-back
 //   fq_ids_kernel     headers: two LANES per record (forward / reverse header), a serial character walk
 //                     driven by a per-format field program; the pair compares through lane exchanges
 //   fq_reads_kernel   reads: 32 records per wave, each converted by the whole WAVE (4 characters per lane
@@ -75,109 +74,155 @@ struct TextRef {
 	const uint8_t *text;
 	u64 bytes;
 	unsigned last_word;	// byte offset of the aligned word that holds the last byte
-	unsigned *tile_counts;	// becomes the exclusive prefix after the scan
-	unsigned *line_end;
+	u64 *tile_state;	// one word per group of 16 tiles for the chained scan (zeroed before the launch)
+	unsigned *line_end;	// byte offset of the first line_cap newlines
+	unsigned line_cap;
 	unsigned n_tiles;
 };
 
-__global__ __launch_bounds__(256) void fq_count_kernel(const TextRef a, const TextRef b) {
-	const int lane = threadIdx.x & 63;
-	const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-	for (unsigned t = wave; t < a.n_tiles + b.n_tiles; t += nwaves) {
-		const TextRef &T = t < a.n_tiles ? a : b;
-		const unsigned tile = t < a.n_tiles ? t : t - a.n_tiles;
-		const u64 base = (u64) tile * TILE_BYTES + (u64) lane * 16u;
-		unsigned cnt = 0;
-#pragma unroll
-		for (unsigned s = 0; s < TILE_STEPS; s++)
-			cnt += __popc(nl_mask16(T.text, T.bytes, base + (u64) s * 1024u));
-		for (int o = 32; o > 0; o >>= 1)
-			cnt += __shfl_xor(cnt, o);
-		if (lane == 0)
-			T.tile_counts[tile] = cnt;
-	}
-}
+// One pass over both texts: every wave takes the next tile (a ticket, so that every tile it may have
+// to wait for is already owned by a running wave), counts the tile's newlines, learns how many lines
+// precede the tile from its predecessors' published states (chained scan with look-back: a state is
+// "aggregate" = this tile's count, or "prefix" = count of this and all earlier tiles), and writes the
+// byte offsets of its newlines at their final positions.  The text is read once.
+constexpr u64 STATE_AGGREGATE = 1ull << 62, STATE_PREFIX = 2ull << 62, STATE_VALUE = (1ull << 62) - 1ull;
 
-// exclusive scan of n unsigned values in place by one workgroup; total -> *total
-__device__ void block_scan_u32(unsigned *c, unsigned n, unsigned *total) {
-	__shared__ unsigned part[1024];
-	const unsigned tid = threadIdx.x;
-	const unsigned per = (n + 1023u) / 1024u;
-	const unsigned lo = tid * per < n ? tid * per : n;
-	const unsigned hi = lo + per < n ? lo + per : n;
-	unsigned s = 0;
-	for (unsigned i = lo; i < hi; i++)
-		s += c[i];
-	part[tid] = s;
+constexpr unsigned INDEX_WAVES = 16;	// waves (8 KB tiles) per workgroup: one chained-scan step per 128 KB of text
+
+__global__ __launch_bounds__(INDEX_WAVES * 64) void fq_index_kernel(const TextRef a, const TextRef b, unsigned *ticket, unsigned *totals) {
+	const int lane = threadIdx.x & 63;
+	const unsigned wv = threadIdx.x >> 6;
+	__shared__ unsigned group_ticket, group_before;
+	__shared__ unsigned wave_count[INDEX_WAVES];
+	if (threadIdx.x == 0)
+		group_ticket = atomicAdd(ticket, 1u);	// groups enter the chain in the order they start running
 	__syncthreads();
-	for (unsigned off = 1; off < 1024; off <<= 1) {
-		const unsigned v = tid >= off ? part[tid - off] : 0u;
-		__syncthreads();
-		part[tid] += v;
-		__syncthreads();
+	const unsigned ga = (a.n_tiles + INDEX_WAVES - 1) / INDEX_WAVES, gb = (b.n_tiles + INDEX_WAVES - 1) / INDEX_WAVES;
+	const unsigned g = group_ticket;
+	if (g >= ga + gb)
+		return;
+	const bool second = g >= ga;
+	const TextRef &T = second ? b : a;
+	const unsigned group = second ? g - ga : g;
+	const unsigned n_groups = second ? gb : ga;
+	const unsigned tile = group * INDEX_WAVES + wv;
+	// newline maps of this wave's 8 KB: 8 steps of 64 lanes x 16 bytes, two 16-bit maps per register
+	unsigned maps[TILE_STEPS / 2];
+	unsigned cnt = 0;
+#pragma unroll
+	for (unsigned s = 0; s < TILE_STEPS; s += 2) {
+		const u64 off = (u64) tile * TILE_BYTES + (u64) s * 1024u + (u64) lane * 16u;
+		const unsigned m0 = nl_mask16(T.text, T.bytes, off), m1 = nl_mask16(T.text, T.bytes, off + 1024u);
+		maps[s / 2] = m0 | (m1 << 16);
+		cnt += __popc(maps[s / 2]);
 	}
-	unsigned run = part[tid] - s;
-	for (unsigned i = lo; i < hi; i++) {
-		const unsigned t = c[i];
-		c[i] = run;
-		run += t;
-	}
-	if (tid == 1023)
-		*total = part[1023];
-}
-
-__global__ __launch_bounds__(1024) void fq_scan_kernel(unsigned *c0, unsigned n0, unsigned *c1, unsigned n1, unsigned *totals) {
-	if (blockIdx.x == 0)
-		block_scan_u32(c0, n0, &totals[0]);
-	else
-		block_scan_u32(c1, n1, &totals[1]);
-}
-
-__global__ __launch_bounds__(256) void fq_index_kernel(const TextRef a, const TextRef b) {
-	const int lane = threadIdx.x & 63;
-	const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-	for (unsigned t = wave; t < a.n_tiles + b.n_tiles; t += nwaves) {
-		const TextRef &T = t < a.n_tiles ? a : b;
-		const unsigned tile = t < a.n_tiles ? t : t - a.n_tiles;
-		unsigned out = T.tile_counts[tile];
-		for (unsigned s = 0; s < TILE_STEPS; s++) {
-			const u64 off = (u64) tile * TILE_BYTES + (u64) s * 1024u + (u64) lane * 16u;
-			unsigned m = nl_mask16(T.text, T.bytes, off);
-			const unsigned cnt = __popc(m);
-			unsigned incl = cnt;	// inclusive prefix over lanes
-			for (int o = 1; o < 64; o <<= 1) {
-				const unsigned v = __shfl_up(incl, o);
-				if (lane >= o)
-					incl += v;
+	unsigned agg = cnt;
+	for (int o = 32; o > 0; o >>= 1)
+		agg += __shfl_xor(agg, o);
+	if (lane == 0)
+		wave_count[wv] = agg;
+	__syncthreads();
+	// ---- wave 0: lines before this group, from the groups before it ----
+	if (wv == 0) {
+		unsigned gsum = lane < (int) INDEX_WAVES ? wave_count[lane] : 0u;
+		for (int o = 32; o > 0; o >>= 1)
+			gsum += __shfl_xor(gsum, o);
+		unsigned before = 0;
+		if (group != 0) {
+			if (lane == 0)
+				__hip_atomic_store(&T.tile_state[group], STATE_AGGREGATE | (u64) gsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			int pos = (int) group - 1;	// nearest predecessor not yet accounted for
+			unsigned spins = 0;
+			for (;;) {
+				const int idx = pos - lane;
+				u64 st = STATE_PREFIX;	// before the first group: a prefix of zero
+				if (idx >= 0)
+					st = __hip_atomic_load(&T.tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const u64 ready = __ballot((st >> 62) != 0ull);
+				const u64 isprefix = __ballot((st >> 62) == 2ull);
+				// usable: the run of ready states from lane 0 up to and including the first prefix
+				const int first_gap = ~ready != 0 ? __builtin_ctzll(~ready) : 64;
+				const int first_prefix = isprefix != 0 ? __builtin_ctzll(isprefix) : 64;
+				if (first_prefix < first_gap) {
+					unsigned v = lane <= first_prefix ? (unsigned) (st & STATE_VALUE) : 0u;
+					for (int o = 32; o > 0; o >>= 1)
+						v += __shfl_xor(v, o);
+					before += v;
+					break;
+				}
+				if (first_gap == 64) {	// 64 aggregates, no prefix yet: take them all and look further back
+					unsigned v = (unsigned) (st & STATE_VALUE);
+					for (int o = 32; o > 0; o >>= 1)
+						v += __shfl_xor(v, o);
+					before += v;
+					pos -= 64;
+				} else {
+					__builtin_amdgcn_s_sleep(1);	// a predecessor has not published yet
+					if (++spins > (1u << 24)) {	// never seen; reported instead of hanging the GPU
+						if (lane == 0)
+							atomicAdd(&totals[2], 1u);
+						break;
+					}
+				}
 			}
-			unsigned at = out + incl - cnt;
-			while (m != 0) {
-				const unsigned bit = __builtin_ctz(m);
-				m &= m - 1;
-				T.line_end[at++] = (unsigned) off + bit;
-			}
-			out += __shfl(incl, 63);
 		}
+		if (lane == 0) {
+			__hip_atomic_store(&T.tile_state[group], STATE_PREFIX | (u64) (before + gsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			group_before = before;
+			if (group == n_groups - 1)
+				totals[second ? 1 : 0] = before + gsum;
+		}
+	}
+	__syncthreads();
+	unsigned out = group_before;
+	for (unsigned k = 0; k < wv; k++)
+		out += wave_count[k];
+	// ---- positions ----
+	if (out >= T.line_cap)
+		return;
+#pragma unroll
+	for (unsigned s = 0; s < TILE_STEPS; s++) {
+		unsigned m = (maps[s / 2] >> (16 * (s & 1))) & 0xFFFFu;
+		const unsigned c = __popc(m);
+		unsigned incl = c;	// inclusive prefix over lanes
+		for (int o = 1; o < 64; o <<= 1) {
+			const unsigned v = __shfl_up(incl, o);
+			if (lane >= o)
+				incl += v;
+		}
+		unsigned at = out + incl - c;
+		const unsigned off = tile * TILE_BYTES + s * 1024u + (unsigned) lane * 16u;
+		while (m != 0) {
+			const unsigned bit = __builtin_ctz(m);
+			m &= m - 1;
+			if (at < T.line_cap)
+				T.line_end[at] = off + bit;
+			at++;
+		}
+		out += __shfl(incl, 63);
 	}
 }
 
 // ---- header parsing, one header per lane ----------------------------------------------------------
 // A header as the C string the reference's parser sees: the bytes of the line after the '@', then a
 // terminator.  Bytes come from aligned words of the text, one word cached in registers.
+constexpr unsigned STAGE_WORDS = 24;	// words of each header staged in LDS (96 bytes from the 16-byte group the header starts in)
+
 struct Str {
 	const uint8_t *text;	// 4-byte aligned
 	unsigned start, len;
 	unsigned cached;	// byte offset of the cached word, ~0 = none
 	unsigned word;
+	const unsigned *lds;	// this lane's column of the staged words (word w at lds[64 * w])
+	unsigned base16;	// text offset of staged word 0
 	__device__ __forceinline__ int at(unsigned i) {
 		if (i >= len)
 			return 0;
 		const unsigned a = start + i;
 		if ((a & ~3u) != cached) {
 			cached = a & ~3u;
-			word = *reinterpret_cast<const unsigned *>(text + cached);
+			const unsigned rel = (cached - base16) >> 2;
+			word = rel < STAGE_WORDS ? lds[64u * rel] : *reinterpret_cast<const unsigned *>(text + cached);
 		}
 		return (int) ((word >> (8u * (a & 3u))) & 0xFFu);
 	}
@@ -670,7 +715,29 @@ __global__ __launch_bounds__(256) void fq_ids_kernel(const ParseParams P) {
 		if (len > 0 && T.text[end - 1] == '\r')	// DOS line ends, linebuf.c:81-84
 			len--;
 	}
-	Str h = { T.text, start + 1u, len > 0 ? len - 1u : 0u, 0xFFFFFFFFu, 0u };
+	// The first 96 bytes of the header go to LDS with six independent 16-byte loads, so the character
+	// walk below waits on LDS, not on one dependent global load per word.  Word w of lane l sits at
+	// [w][l]: lanes walking in step hit 64 different banks.
+	__shared__ unsigned stage[4][STAGE_WORDS * 64];
+	unsigned *col = &stage[threadIdx.x >> 6][threadIdx.x & 63];
+	const unsigned base16 = (start + 1u) & ~15u;
+	{
+		uint4 v[STAGE_WORDS / 4];
+#pragma unroll
+		for (unsigned k = 0; k < STAGE_WORDS / 4; k++) {
+			const unsigned a = base16 + 16u * k;
+			// a 16-byte group is read whole when any of it lies inside the text (allocations are at least that granular)
+			v[k] = (have && (u64) a < T.bytes) ? *reinterpret_cast<const uint4 *>(T.text + a) : make_uint4(0u, 0u, 0u, 0u);
+		}
+#pragma unroll
+		for (unsigned k = 0; k < STAGE_WORDS / 4; k++) {
+			col[64u * (4u * k + 0u)] = v[k].x;
+			col[64u * (4u * k + 1u)] = v[k].y;
+			col[64u * (4u * k + 2u)] = v[k].z;
+			col[64u * (4u * k + 3u)] = v[k].w;
+		}
+	}
+	Str h = { T.text, start + 1u, len > 0 ? len - 1u : 0u, 0xFFFFFFFFu, 0u, col, base16 };
 	IdOut id;
 	id.instr_len = id.run_off = id.run_len = id.fc_off = id.fc_len = id.tag_off = id.tag_len = 0;
 	id.lane = id.tile = id.x = id.y = 0;
@@ -1162,7 +1229,7 @@ struct pamd_fastq_parser {
 	int device = 0;
 	int qualmin = 33;
 	int policy = PAMD_TAG_OPTIONAL;
-	DevBuf counts_f, counts_r, lines_f, lines_r, flags, small;
+	DevBuf counts_f, lines_f, lines_r, flags, small;	// counts_f: chained-scan tile states + ticket
 	hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
 	float index_ms = -1.f, parse_ms = -1.f;
 };
@@ -1219,7 +1286,6 @@ void pamd_fastq_parser_destroy(pamd_fastq_parser *p) {
 		return;
 	(void) hipSetDevice(p->device);
 	p->counts_f.release();
-	p->counts_r.release();
 	p->lines_f.release();
 	p->lines_r.release();
 	p->flags.release();
@@ -1268,27 +1334,35 @@ int pamd_fastq_parse_device(pamd_fastq_parser *p, const char *fwd_text, size_t f
 	R.n_tiles = (unsigned) ((rev_bytes + TILE_BYTES - 1) / TILE_BYTES);
 	R.last_word = (unsigned) ((rev_bytes - 1) & ~(size_t) 3);
 	int rc;
-	if ((rc = p->counts_f.ensure((size_t) F.n_tiles * 4)) != PAMD_OK || (rc = p->counts_r.ensure((size_t) R.n_tiles * 4)) != PAMD_OK || (rc = p->small.ensure(256)) != PAMD_OK)
+	// the chained scan needs one state word per tile; the line index holds the lines of max_pairs records
+	const size_t cap64 = 4 * (size_t) max_pairs + 4;
+	const unsigned line_cap = cap64 > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (unsigned) cap64;
+	const unsigned groups_f = (F.n_tiles + INDEX_WAVES - 1) / INDEX_WAVES, groups_r = (R.n_tiles + INDEX_WAVES - 1) / INDEX_WAVES;
+	const size_t state_bytes = ((size_t) groups_f + groups_r) * 8;
+	if ((rc = p->counts_f.ensure(state_bytes + 64)) != PAMD_OK || (rc = p->small.ensure(256)) != PAMD_OK
+	    || (rc = p->lines_f.ensure((size_t) line_cap * 4 + 16)) != PAMD_OK || (rc = p->lines_r.ensure((size_t) line_cap * 4 + 16)) != PAMD_OK)
 		return rc;
-	F.tile_counts = static_cast<unsigned *>(p->counts_f.p);
-	R.tile_counts = static_cast<unsigned *>(p->counts_r.p);
-	F.line_end = R.line_end = nullptr;
+	F.tile_state = static_cast<u64 *>(p->counts_f.p);
+	R.tile_state = F.tile_state + groups_f;
+	unsigned *d_ticket = reinterpret_cast<unsigned *>(F.tile_state + groups_f + groups_r);
+	F.line_end = static_cast<unsigned *>(p->lines_f.p);
+	R.line_end = static_cast<unsigned *>(p->lines_r.p);
+	F.line_cap = R.line_cap = line_cap;
 	unsigned *d_totals = static_cast<unsigned *>(p->small.p);	// [0..1] line totals; FinalOut at +64 bytes
 	FinalOut *d_final = reinterpret_cast<FinalOut *>(static_cast<uint8_t *>(p->small.p) + 64);
 
 	HIP_TRY(hipEventRecord(p->ev[0], st));
-	const unsigned tiles = F.n_tiles + R.n_tiles;
-	hipLaunchKernelGGL(fq_count_kernel, dim3(grid_for(tiles, 4, 65535)), dim3(256), 0, st, F, R);
-	hipLaunchKernelGGL(fq_scan_kernel, dim3(2), dim3(1024), 0, st, F.tile_counts, F.n_tiles, R.tile_counts, R.n_tiles, d_totals);
-	unsigned totals[2] = { 0, 0 };
+	HIP_TRY(hipMemsetAsync(p->counts_f.p, 0, state_bytes + 64, st));
+	HIP_TRY(hipMemsetAsync(d_totals, 0, 16, st));
+	hipLaunchKernelGGL(fq_index_kernel, dim3(groups_f + groups_r), dim3(INDEX_WAVES * 64), 0, st, F, R, d_ticket, d_totals);
+	HIP_TRY(hipEventRecord(p->ev[1], st));
+	unsigned totals[3] = { 0, 0, 0 };
 	HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof totals, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
-	if ((rc = p->lines_f.ensure((size_t) totals[0] * 4 + 16)) != PAMD_OK || (rc = p->lines_r.ensure((size_t) totals[1] * 4 + 16)) != PAMD_OK)
-		return rc;
-	F.line_end = static_cast<unsigned *>(p->lines_f.p);
-	R.line_end = static_cast<unsigned *>(p->lines_r.p);
-	hipLaunchKernelGGL(fq_index_kernel, dim3(grid_for(tiles, 4, 65535)), dim3(256), 0, st, F, R);
-	HIP_TRY(hipEventRecord(p->ev[1], st));
+	if (totals[2] != 0) {
+		pamd_set_error("FASTQ line index: the chained scan gave up waiting on %u tiles", totals[2]);
+		return PAMD_ENODEVICE;
+	}
 
 	u64 n_records = (totals[0] < totals[1] ? totals[0] : totals[1]) / 4u;
 	if (n_records > max_pairs)
