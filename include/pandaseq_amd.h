@@ -50,8 +50,11 @@ typedef struct {
 } pamd_qual;
 
 /* replaces the `.name = "simple_bayesian" / "pear" / "rdp_mle"` classes
- * (algo_simple_bayes.c:100-108, algo_pear.c:93-101, algo_rdp_mle.c:84-92) */
-enum { PAMD_ALGO_SIMPLE_BAYES = 0, PAMD_ALGO_PEAR = 1, PAMD_ALGO_RDP_MLE = 2 };
+ * (algo_simple_bayes.c:100-108, algo_pear.c:93-101, algo_rdp_mle.c:84-92) and the four remaining scorers
+ * "uparse" / "flash" / "ea_util" / "stitch" (algo_uparse.c:94-102, algo_flash.c:91-99, algo_ea_util.c:79-87,
+ * algo_stitch.c:79-87), all of which score an overlap from three integer counts */
+enum { PAMD_ALGO_SIMPLE_BAYES = 0, PAMD_ALGO_PEAR = 1, PAMD_ALGO_RDP_MLE = 2,
+       PAMD_ALGO_UPARSE = 3, PAMD_ALGO_FLASH = 4, PAMD_ALGO_EA_UTIL = 5, PAMD_ALGO_STITCH = 6 };
 
 /* per-pair outcome; one value per rejection counter of assembler.h:59-67 */
 enum {
@@ -133,8 +136,11 @@ pamd_assembler *pamd_assembler_create(int device);
 void pamd_assembler_destroy(pamd_assembler *a);
 
 /* replaces panda_assembler_set_algorithm + panda_algorithm_*_new/_set_* (algo_simple_bayes.c:110-135,
- * algo_pear.c:103-116, algo_rdp_mle.c:94-98).  param: simple_bayes -> error estimation q in (0,1),
- * pear -> log of the random-base probability; NaN = keep the class default. */
+ * algo_pear.c:103-116, algo_rdp_mle.c:94-98, algo_uparse.c:104-135).  param: simple_bayes / uparse ->
+ * error estimation q in (0,1), pear -> log of the random-base probability; NaN = keep the class default.
+ * flash / ea_util / stitch take no parameter.  For ea_util and stitch `est_overlap_prob` is a device log()
+ * of a ratio of small integers (within 1 ulp of the host's); every decision is exact because distinct
+ * ratios are far apart and equal ratios give equal values. */
 int pamd_set_algorithm(pamd_assembler *a, int algo, double param);
 /* the setters below mirror assembler_support.c:201-410, including "silently ignore bad values" */
 int pamd_set_threshold(pamd_assembler *a, double threshold);		/* (0,1), stored as log */
@@ -162,10 +168,10 @@ int pamd_clear_modules(pamd_assembler *a);
 int pamd_set_exact_sums(pamd_assembler *a, int exact);
 
 /* The probability tables this library computes (host side; works without a GPU).
- * Order: qual_nn, qual_score[47], qual_score_err[47], then six 47x47 row-major matrices:
+ * Order: qual_nn, qual_score[47], qual_score_err[47], then eight 47x47 row-major matrices:
  * match_simple_bayesian, mismatch_simple_bayesian, match_pear, mismatch_pear, mismatch_rdp_mle,
- * mismatch_assembled_rdp_mle  (table.h as generated by mktable.c:132-155). */
-#define PAMD_TABLE_DOUBLES (1 + 47 + 47 + 6 * 47 * 47)
+ * mismatch_assembled_rdp_mle, match_uparse, mismatch_uparse  (table.h as generated by mktable.c:132-155). */
+#define PAMD_TABLE_DOUBLES (1 + 47 + 47 + 8 * 47 * 47)
 int pamd_tables_get(double *out, size_t n_doubles);
 
 /* Enqueue the assembly of one batch on `stream`; returns once launched (asynchronous). */

@@ -143,6 +143,17 @@ PandaAlgorithm panda_algorithm_pear_new(void);
 double panda_algorithm_pear_get_random_base_log_p(PandaAlgorithm algorithm);
 void panda_algorithm_pear_set_random_base_log_p(PandaAlgorithm algorithm, double log_p);
 PandaAlgorithm panda_algorithm_rdp_mle_new(void);
+/* the four remaining scorers (algo_uparse.c, algo_flash.c, algo_ea_util.c, algo_stitch.c; pandaseq-algorithm.h:57-215) */
+extern const struct panda_algorithm_class panda_algorithm_uparse_class;
+extern const struct panda_algorithm_class panda_algorithm_flash_class;
+extern const struct panda_algorithm_class panda_algorithm_ea_util_class;
+extern const struct panda_algorithm_class panda_algorithm_stitch_class;
+PandaAlgorithm panda_algorithm_uparse_new(void);
+double panda_algorithm_uparse_get_error_estimation(PandaAlgorithm algorithm);
+void panda_algorithm_uparse_set_error_estimation(PandaAlgorithm algorithm, double q);
+PandaAlgorithm panda_algorithm_flash_new(void);
+PandaAlgorithm panda_algorithm_ea_util_new(void);
+PandaAlgorithm panda_algorithm_stitch_new(void);
 
 /* ---- getters / setters (pandaseq-assembler.h:199-405, assembler_support.c:177-410) ---- */
 PandaAlgorithm panda_assembler_get_algorithm(PandaAssembler assembler);

@@ -72,6 +72,18 @@ static double f_mismatch_rdp_asm(double p, double q) {
 	return (v == 0) ? DBL_MIN : v;
 }
 
+/* mktable.c:106-117 */
+static double f_match_uparse(double p, double q) {
+	double v = 1 - p * q / (1 - p - q + 4 * p * q / 3);
+	return (v <= 0) ? DBL_MIN : v;
+}
+
+/* mktable.c:119-130 */
+static double f_mismatch_uparse(double p, double q) {
+	double v = 1 - (p + q / 3) / (p + q - 4 * p * q / 3);
+	return (v <= 0) ? DBL_MIN : v;
+}
+
 void po_build_tables(po_tables *t) {
 	int i, j;
 	t->qual_nn = six_digits(log(0.25));	/* mktable.c:141 + tablebuilder.c:124 -> -1.38629 */
@@ -89,6 +101,8 @@ void po_build_tables(po_tables *t) {
 			t->mismatch_pear[i][j] = six_digits(log(f_mismatch_pear(p, q)));
 			t->mismatch_rdp[i][j] = six_digits(log(f_mismatch(p, q)));
 			t->mismatch_rdp_asm[i][j] = six_digits(log(f_mismatch_rdp_asm(p, q)));
+			t->match_uparse[i][j] = six_digits(log(f_match_uparse(p, q)));
+			t->mismatch_uparse[i][j] = six_digits(log(f_mismatch_uparse(p, q)));
 		}
 	}
 }
@@ -103,10 +117,19 @@ void po_config_set_sb_q(po_config *c, double q) {	/* algo_simple_bayes.c:126-135
 	}
 }
 
+void po_config_set_uparse_q(po_config *c, double q) {	/* algo_uparse.c:126-135 */
+	if (q > 0 && q < 1) {
+		c->up_q = q;
+		c->up_pmatch = log(1 - q * q * (1 - 2 * q + 4 * q * q / 3));
+		c->up_pmismatch = log(1 - 4 * q / 3 / (2 * q - 4 * q * q / 3));
+	}
+}
+
 void po_config_default(po_config *c) {	/* assembler_support.c:61-97 */
 	memset(c, 0, sizeof *c);
 	c->algo = PO_ALGO_SIMPLE_BAYES;
 	po_config_set_sb_q(c, 0.36);	/* algo_simple_bayes.c:113 */
+	po_config_set_uparse_q(c, 0.36);	/* algo_uparse.c:103 */
 	c->pear_random_base = log(0.25);	/* algo_pear.c:106 */
 	c->threshold = log(0.6);
 	c->minoverlap = 2;
@@ -228,8 +251,49 @@ static double overlap_rdp(const po_tables *t, const po_qual *f, size_t flen, con
 	return p;
 }
 
+/* The walk the four remaining scorers share (algo_uparse.c:44-59, algo_flash.c:44-58, algo_ea_util.c:43-54,
+ * algo_stitch.c:39-54): bases that exist on both reads, split into unknown (an N on either side),
+ * matching and mismatching. */
+static void overlap_counts(const po_qual *f, size_t flen, const po_qual *r, size_t rlen, size_t ov, size_t *unknowns, size_t *matches, size_t *mismatches) {
+	*unknowns = *matches = *mismatches = 0;
+	for (size_t i = 0; i < ov; i++) {
+		int fi = (int) (flen + i - ov);
+		int ri = (int) (rlen - i - 1);
+		if (fi < 0 || ri < 0 || (size_t) fi >= flen || (size_t) ri >= rlen)
+			continue;
+		unsigned a = f[fi].nt, b = r[ri].nt;
+		if (a == NT_N || b == NT_N)
+			(*unknowns)++;
+		else if ((a & b) != 0)
+			(*matches)++;
+		else
+			(*mismatches)++;
+	}
+}
+
 double po_overlap_probability(const po_config *c, const po_tables *t, const po_qual *f, size_t flen, const po_qual *r, size_t rlen, size_t ov) {
+	size_t u, m, mm;
 	switch (c->algo) {
+	case PO_ALGO_UPARSE:	/* algo_uparse.c:33-66: simple_bayesian's form with its own two constants */
+		overlap_counts(f, flen, r, rlen, ov, &u, &m, &mm);
+		if (ov >= flen && ov >= rlen)
+			return t->qual_nn * u + m * c->up_pmatch + mm * c->up_pmismatch;
+		return t->qual_nn * (flen + rlen - 2 * ov + u) + m * c->up_pmatch + mm * c->up_pmismatch;
+	case PO_ALGO_FLASH: {	/* algo_flash.c:30-61: an N counts as a mismatch; the quotient is an INTEGER division (sic) */
+		overlap_counts(f, flen, r, rlen, ov, &u, &m, &mm);
+		size_t bad = u + mm, real = u + m + mm;
+		return real == 0 ? -2 : log(bad / real);
+	}
+	case PO_ALGO_EA_UTIL: {	/* algo_ea_util.c:29-56 */
+		overlap_counts(f, flen, r, rlen, ov, &u, &m, &mm);
+		size_t bad = u + mm, real = u + m + mm;
+		return log((((double) bad) * bad + 1) / real);
+	}
+	case PO_ALGO_STITCH: {	/* algo_stitch.c:28-57: the score is a size_t, so more mismatches than matches wraps */
+		overlap_counts(f, flen, r, rlen, ov, &u, &m, &mm);
+		size_t score = m - mm;
+		return log(score / (double) (flen + rlen));
+	}
 	case PO_ALGO_PEAR:
 		return overlap_pear(c, t, f, flen, r, rlen, ov);
 	case PO_ALGO_RDP_MLE:
@@ -242,6 +306,25 @@ double po_overlap_probability(const po_config *c, const po_tables *t, const po_q
 /* algo_simple_bayes.c:68-75, algo_pear.c:61-68, algo_rdp_mle.c:29-41 */
 double po_match_probability(const po_config *c, const po_tables *t, int match, int8_t a, int8_t b) {
 	switch (c->algo) {
+	case PO_ALGO_UPARSE:	/* algo_uparse.c:68-75 */
+		return (match ? t->match_uparse : t->mismatch_uparse)[clampq(a)][clampq(b)];
+	case PO_ALGO_FLASH: {	/* algo_flash.c:63-80 */
+		int score;
+		if (match) {
+			score = (a > b) ? clampq(a) : clampq(b);
+		} else {
+			score = clampq(a) - clampq(b);
+			if (score < 0)
+				score = -score;
+			if (score < 2)
+				score = 2;
+		}
+		return t->score[score];
+	}
+	case PO_ALGO_EA_UTIL:	/* algo_ea_util.c:58-67 */
+		return t->score[(a > b) ? clampq(a) : clampq(b)];
+	case PO_ALGO_STITCH:	/* algo_stitch.c:59-67: simple_bayesian's tables */
+		return (match ? t->match_sb : t->mismatch_sb)[clampq(a)][clampq(b)];
 	case PO_ALGO_PEAR:
 		return (match ? t->match_pear : t->mismatch_pear)[clampq(a)][clampq(b)];
 	case PO_ALGO_RDP_MLE:

@@ -12,6 +12,7 @@
  *   - the 8-mer iterator                 (misc.h:36-45)
  *   - align(): seed, scan, argmax, merge (assembler.c:48-250)
  *   - the three scoring algorithms       (algo_simple_bayes.c:33-75, algo_pear.c:32-68, algo_rdp_mle.c:29-74)
+ *   - the four remaining scorers         (algo_uparse.c:33-75, algo_flash.c:30-80, algo_ea_util.c:29-67, algo_stitch.c:28-67)
  *   - the primer offset scan             (offset.c:47-112)
  *   - assemble_seq() control + counters  (assembler.c:252-348)
  *   - panda_result_phred + min_phred / min_overlapbits (nt.c:126-150, plugin_min_phred.c:8-22, plugin_min_overlapbits.c:17-23)
@@ -53,7 +54,8 @@ typedef struct {
 	int8_t qual;		/* PHRED score, raw (may lie outside 0..46) */
 } po_qual;
 
-enum { PO_ALGO_SIMPLE_BAYES = 0, PO_ALGO_PEAR = 1, PO_ALGO_RDP_MLE = 2 };
+enum { PO_ALGO_SIMPLE_BAYES = 0, PO_ALGO_PEAR = 1, PO_ALGO_RDP_MLE = 2,
+       PO_ALGO_UPARSE = 3, PO_ALGO_FLASH = 4, PO_ALGO_EA_UTIL = 5, PO_ALGO_STITCH = 6 };	/* SURVEY.md 8f row 4 */
 
 /* per-pair outcome, in the order assemble_seq() tests them (assembler.c:252-348) */
 enum {
@@ -86,6 +88,8 @@ typedef struct {
 	double mismatch_pear[PO_NQ][PO_NQ];
 	double mismatch_rdp[PO_NQ][PO_NQ];	/* qual_mismatch_rdp_mle */
 	double mismatch_rdp_asm[PO_NQ][PO_NQ];	/* qual_mismatch_assembled_rdp_mle */
+	double match_uparse[PO_NQ][PO_NQ];	/* qual_match_uparse */
+	double mismatch_uparse[PO_NQ][PO_NQ];	/* qual_mismatch_uparse: the one asymmetric table */
 } po_tables;
 
 typedef struct {
@@ -104,6 +108,7 @@ typedef struct {
 	double primer_penalty;
 	int n_modules;
 	po_module modules[PO_MAX_MODULES];
+	double up_q, up_pmatch, up_pmismatch;	/* algo_uparse.c:126-135 */
 } po_config;
 
 typedef struct {
@@ -134,6 +139,7 @@ typedef struct po_scratch po_scratch;
 void po_build_tables(po_tables *t);
 void po_config_default(po_config *c);
 void po_config_set_sb_q(po_config *c, double q);
+void po_config_set_uparse_q(po_config *c, double q);
 po_scratch *po_scratch_new(void);
 void po_scratch_free(po_scratch *s);
 

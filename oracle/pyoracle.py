@@ -14,7 +14,7 @@ MAX_LEN = 450
 NQ = 47
 MAX_MODULES = 8
 
-ALGO = {"simple_bayesian": 0, "pear": 1, "rdp_mle": 2}
+ALGO = {"simple_bayesian": 0, "pear": 1, "rdp_mle": 2, "uparse": 3, "flash": 4, "ea_util": 5, "stitch": 6}
 STATUS = ["OK", "BADR", "NOFP", "NORP", "NOALGN", "LOWQ", "REJECT"]
 MOD_MIN_PHRED, MOD_MIN_OVERLAPBITS = 1, 2
 
@@ -36,6 +36,7 @@ class Config(C.Structure):
         ("primer_penalty", C.c_double),
         ("n_modules", C.c_int),
         ("modules", Module * MAX_MODULES),
+        ("up_q", C.c_double), ("up_pmatch", C.c_double), ("up_pmismatch", C.c_double),
     ]
 
 
@@ -50,6 +51,8 @@ class Tables(C.Structure):
         ("mismatch_pear", (C.c_double * NQ) * NQ),
         ("mismatch_rdp", (C.c_double * NQ) * NQ),
         ("mismatch_rdp_asm", (C.c_double * NQ) * NQ),
+        ("match_uparse", (C.c_double * NQ) * NQ),
+        ("mismatch_uparse", (C.c_double * NQ) * NQ),
     ]
 
 
@@ -88,6 +91,7 @@ def lib():
         L.po_build_tables.argtypes = [C.POINTER(Tables)]
         L.po_config_default.argtypes = [C.POINTER(Config)]
         L.po_config_set_sb_q.argtypes = [C.POINTER(Config), C.c_double]
+        L.po_config_set_uparse_q.argtypes = [C.POINTER(Config), C.c_double]
         L.po_overlap_probability.restype = C.c_double
         L.po_overlap_probability.argtypes = [C.POINTER(Config), C.POINTER(Tables), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]
         L.po_match_probability.restype = C.c_double
@@ -122,7 +126,8 @@ def tables():
 def tables_np():
     t = tables()
     out = {"qual_nn": t.qual_nn}
-    for name in ("score", "score_err", "match_sb", "mismatch_sb", "match_pear", "mismatch_pear", "mismatch_rdp", "mismatch_rdp_asm"):
+    for name in ("score", "score_err", "match_sb", "mismatch_sb", "match_pear", "mismatch_pear", "mismatch_rdp", "mismatch_rdp_asm",
+                 "match_uparse", "mismatch_uparse"):
         out[name] = np.ctypeslib.as_array(getattr(t, name)).copy()
     return out
 
@@ -137,7 +142,10 @@ def make_config(algo="simple_bayesian", q=None, pear_random_base_log=None, thres
     lib().po_config_default(C.byref(c))
     c.algo = ALGO[algo]
     if q is not None:
-        lib().po_config_set_sb_q(C.byref(c), q)
+        if algo == "uparse":
+            lib().po_config_set_uparse_q(C.byref(c), q)
+        else:
+            lib().po_config_set_sb_q(C.byref(c), q)
     if pear_random_base_log is not None:
         c.pear_random_base = pear_random_base_log
     if threshold is not None and 0 < threshold < 1:  # assembler_support.c:391-397
@@ -216,6 +224,7 @@ def ref_tables_np():
         "match_sb": "qual_match_simple_bayesian", "mismatch_sb": "qual_mismatch_simple_bayesian",
         "match_pear": "qual_match_pear", "mismatch_pear": "qual_mismatch_pear",
         "mismatch_rdp": "qual_mismatch_rdp_mle", "mismatch_rdp_asm": "qual_mismatch_assembled_rdp_mle",
+        "match_uparse": "qual_match_uparse", "mismatch_uparse": "qual_mismatch_uparse",
     }
     for k, sym in names.items():
         if k in ("score", "score_err"):

@@ -14,9 +14,9 @@ LIB_PATH = os.path.join(HERE, "libpandaseq_amd.so")
 MAX_LEN = 450
 MAX_MODULES = 8
 NUM_COUNTERS = 8 + MAX_MODULES + 2 * MAX_LEN
-TABLE_DOUBLES = 1 + 47 + 47 + 6 * 47 * 47
+TABLE_DOUBLES = 1 + 47 + 47 + 8 * 47 * 47
 
-ALGO = {"simple_bayesian": 0, "pear": 1, "rdp_mle": 2}
+ALGO = {"simple_bayesian": 0, "pear": 1, "rdp_mle": 2, "uparse": 3, "flash": 4, "ea_util": 5, "stitch": 6}
 STATUS = ["OK", "BADR", "NOFP", "NORP", "NOALGN", "LOWQ", "REJECT"]
 CTR = {"count": 0, "badr": 1, "nofp": 2, "norp": 3, "noalgn": 4, "lowq": 5, "ok": 6, "slow": 7}
 CTR_REJECTED0 = 8
@@ -136,7 +136,7 @@ def tables():
     check(lib().pamd_tables_get(buf.ctypes.data, buf.size))
     out = {"qual_nn": float(buf[0]), "score": buf[1:48].copy(), "score_err": buf[48:95].copy()}
     o = 95
-    for name in ("match_sb", "mismatch_sb", "match_pear", "mismatch_pear", "mismatch_rdp", "mismatch_rdp_asm"):
+    for name in ("match_sb", "mismatch_sb", "match_pear", "mismatch_pear", "mismatch_rdp", "mismatch_rdp_asm", "match_uparse", "mismatch_uparse"):
         out[name] = buf[o:o + 2209].reshape(47, 47).copy()
         o += 2209
     return out

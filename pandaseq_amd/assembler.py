@@ -117,10 +117,10 @@ class Assembler:
 
     # ---- configuration: names follow pandaseq-assembler.h ----
     def set_algorithm(self, name: str, param: Optional[float] = None):
-        """`-A name[:param]` (args_assembler.c:26-60). param: simple_bayesian -> q; pear -> random-base
-        probability (NOT its log; algo_pear.c:84-89 takes the log)."""
+        """`-A name[:param]` (args_assembler.c:26-60). param: simple_bayesian / uparse -> q; pear -> random-base
+        probability (NOT its log; algo_pear.c:84-89 takes the log); the others take none."""
         if name not in ALGO:
-            raise _lib.PamdError(f"algorithm {name!r} is not on the device path (simple_bayesian, pear, rdp_mle)")
+            raise _lib.PamdError(f"algorithm {name!r} is not on the device path ({', '.join(ALGO)})")
         p = float("nan") if param is None else float(param)
         if name == "pear" and param is not None:
             p = math.log(param)

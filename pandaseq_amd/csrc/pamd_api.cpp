@@ -50,6 +50,7 @@ struct pamd_assembler {
 	// configuration
 	int algo = PAMD_ALGO_SIMPLE_BAYES;
 	double sb_q = 0.36, sb_pmatch = 0, sb_pmismatch = 0;
+	double up_q = 0.36, up_pmatch = 0, up_pmismatch = 0;	// uparse (algo_uparse.c:126-135)
 	double pear_random_base = 0;
 	double threshold = 0;
 	int minoverlap = 2;
@@ -106,13 +107,21 @@ int pamd_tables_get(double *out, size_t n_doubles) {
 	o += PAMD_NQ;
 	memcpy(o, t->score_err, sizeof t->score_err);
 	o += PAMD_NQ;
-	const double *mats[6] = { t->match_sb, t->mismatch_sb, t->match_pear, t->mismatch_pear, t->mismatch_rdp, t->mismatch_rdp_asm };
-	for (int m = 0; m < 6; m++) {
+	const double *mats[8] = { t->match_sb, t->mismatch_sb, t->match_pear, t->mismatch_pear, t->mismatch_rdp, t->mismatch_rdp_asm, t->match_uparse, t->mismatch_uparse };
+	for (int m = 0; m < 8; m++) {
 		memcpy(o, mats[m], sizeof(double) * PAMD_TAB);
 		o += PAMD_TAB;
 	}
 	delete t;
 	return PAMD_OK;
+}
+
+static void set_uparse_q(pamd_assembler *a, double q) {	// algo_uparse.c:126-135
+	if (q > 0 && q < 1) {
+		a->up_q = q;
+		a->up_pmatch = std::log(1 - q * q * (1 - 2 * q + 4 * q * q / 3));
+		a->up_pmismatch = std::log(1 - 4 * q / 3 / (2 * q - 4 * q * q / 3));
+	}
 }
 
 static void set_sb_q(pamd_assembler *a, double q) {	// algo_simple_bayes.c:126-135
@@ -147,6 +156,7 @@ pamd_assembler *pamd_assembler_create(int device) {
 	a->cu_count = prop.multiProcessorCount;
 	pamd_build_tables(&a->tabs);
 	set_sb_q(a, 0.36);	// algo_simple_bayes.c:113
+	set_uparse_q(a, 0.36);	// algo_uparse.c:103
 	a->pear_random_base = std::log(0.25);	// algo_pear.c:106
 	a->threshold = std::log(0.6);	// assembler_support.c:76
 	memset(a->primers, 0, sizeof a->primers);
@@ -183,8 +193,8 @@ void pamd_assembler_destroy(pamd_assembler *a) {
 }
 
 int pamd_set_algorithm(pamd_assembler *a, int algo, double param) {
-	if (a == nullptr || algo < 0 || algo > PAMD_ALGO_RDP_MLE) {
-		pamd_set_error("pamd_set_algorithm: unknown algorithm %d (only simple_bayesian, pear, rdp_mle run on the device)", algo);
+	if (a == nullptr || algo < 0 || algo > PAMD_ALGO_STITCH) {
+		pamd_set_error("pamd_set_algorithm: unknown algorithm %d", algo);
 		return PAMD_EUNSUPPORTED;
 	}
 	a->algo = algo;
@@ -192,6 +202,8 @@ int pamd_set_algorithm(pamd_assembler *a, int algo, double param) {
 		set_sb_q(a, std::isnan(param) ? 0.36 : param);
 	} else if (algo == PAMD_ALGO_PEAR) {
 		a->pear_random_base = std::isnan(param) ? std::log(0.25) : param;
+	} else if (algo == PAMD_ALGO_UPARSE) {
+		set_uparse_q(a, std::isnan(param) ? 0.36 : param);
 	}
 	return PAMD_OK;
 }
@@ -305,7 +317,11 @@ static int upload_tables(pamd_assembler *a, hipStream_t st) {
 			B = a->tabs.mismatch_rdp;
 			C = a->tabs.mismatch_rdp_asm;
 			break;
-		default:	// algo_simple_bayes.c:74
+		case PAMD_ALGO_UPARSE:	// algo_uparse.c:74
+			A = a->tabs.match_uparse;
+			B = a->tabs.mismatch_uparse;
+			break;
+		default:	// algo_simple_bayes.c:74, algo_stitch.c:66 (flash / ea_util only read qual_score)
 			A = a->tabs.match_sb;
 			B = a->tabs.mismatch_sb;
 			break;
@@ -390,8 +406,8 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.threshold = a->threshold;
 	p.primer_penalty = a->primer_penalty;
 	p.qual_nn = a->tabs.qual_nn;
-	p.sb_pmatch = a->sb_pmatch;
-	p.sb_pmismatch = a->sb_pmismatch;
+	p.sb_pmatch = a->algo == PAMD_ALGO_UPARSE ? a->up_pmatch : a->sb_pmatch;
+	p.sb_pmismatch = a->algo == PAMD_ALGO_UPARSE ? a->up_pmismatch : a->sb_pmismatch;
 	p.pear_random_base = a->pear_random_base;
 	p.exact_sums = a->exact_sums;
 	memcpy(p.modules, a->modules, sizeof p.modules);
@@ -465,7 +481,7 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	a->last_waves = waves;
 	a->last_lds = (int) lds_bytes;
 
-	if (a->algo != PAMD_ALGO_SIMPLE_BAYES && a->exact_sums) {
+	if ((a->algo == PAMD_ALGO_PEAR || a->algo == PAMD_ALGO_RDP_MLE) && a->exact_sums) {
 		const size_t rows = (size_t) wgs * (size_t) waves * 8u;	// GROUP parked rows per wave
 		if (rows > a->scratch_rows) {
 			if (a->d_scratch)

@@ -69,7 +69,38 @@ static PandaAlgorithm rdp_create(const char *arg) {	// algo_rdp_mle.c:76-82
 	return nullptr;
 }
 
+static PandaAlgorithm uparse_create(const char *arg) {	// algo_uparse.c:77-98
+	PandaAlgorithm a = panda_algorithm_uparse_new();
+	if (arg != nullptr) {
+		char *end;
+		double q = strtod(arg, &end);
+		if (*end != '\0' || q < 0 || q > 1) {
+			panda_algorithm_unref(a);
+			return nullptr;
+		}
+		panda_algorithm_uparse_set_error_estimation(a, q);
+	}
+	return a;
+}
+
+// algo_flash.c:82-89, algo_ea_util.c:69-77, algo_stitch.c:69-77: "No arguments allowed"
+static PandaAlgorithm flash_create(const char *arg) {
+	return arg == nullptr ? panda_algorithm_flash_new() : nullptr;
+}
+
+static PandaAlgorithm ea_util_create(const char *arg) {
+	return arg == nullptr ? panda_algorithm_ea_util_new() : nullptr;
+}
+
+static PandaAlgorithm stitch_create(const char *arg) {
+	return arg == nullptr ? panda_algorithm_stitch_new() : nullptr;
+}
+
 extern "C" {
+const struct panda_algorithm_class panda_algorithm_uparse_class = { 3 * sizeof(double), "uparse", uparse_create, nullptr, nullptr, nullptr, -1.38629 };
+const struct panda_algorithm_class panda_algorithm_flash_class = { 0, "flash", flash_create, nullptr, nullptr, nullptr, -1.38629 };
+const struct panda_algorithm_class panda_algorithm_ea_util_class = { 0, "ea_util", ea_util_create, nullptr, nullptr, nullptr, -1.38629 };
+const struct panda_algorithm_class panda_algorithm_stitch_class = { 0, "stitch", stitch_create, nullptr, nullptr, nullptr, -1.38629 };
 const struct panda_algorithm_class panda_algorithm_simple_bayes_class = { 3 * sizeof(double), "simple_bayesian", sb_create, nullptr, nullptr, nullptr, -1.38629 };
 const struct panda_algorithm_class panda_algorithm_pear_class = { sizeof(double), "pear", pear_create, nullptr, nullptr, nullptr, -1.38629 };
 const struct panda_algorithm_class panda_algorithm_rdp_mle_class = { 0, "rdp_mle", rdp_create, nullptr, nullptr, nullptr, -1.38629 };
@@ -146,6 +177,36 @@ void panda_algorithm_pear_set_random_base_log_p(PandaAlgorithm a, double log_p) 
 
 PandaAlgorithm panda_algorithm_rdp_mle_new(void) {
 	return panda_algorithm_new(&panda_algorithm_rdp_mle_class);
+}
+
+PandaAlgorithm panda_algorithm_uparse_new(void) {	// algo_uparse.c:104-109
+	PandaAlgorithm a = panda_algorithm_new(&panda_algorithm_uparse_class);
+	panda_algorithm_uparse_set_error_estimation(a, 0.36);
+	return a;
+}
+
+double panda_algorithm_uparse_get_error_estimation(PandaAlgorithm a) {	// algo_uparse.c:111-118
+	return panda_algorithm_is_a(a, &panda_algorithm_uparse_class) ? a->data[0] : -1;
+}
+
+void panda_algorithm_uparse_set_error_estimation(PandaAlgorithm a, double q) {	// algo_uparse.c:120-135
+	if (q > 0 && q < 1 && panda_algorithm_is_a(a, &panda_algorithm_uparse_class)) {
+		a->data[0] = q;
+		a->data[1] = std::log(1 - q * q * (1 - 2 * q + 4 * q * q / 3));
+		a->data[2] = std::log(1 - 4 * q / 3 / (2 * q - 4 * q * q / 3));
+	}
+}
+
+PandaAlgorithm panda_algorithm_flash_new(void) {	// algo_flash.c:101-104
+	return panda_algorithm_new(&panda_algorithm_flash_class);
+}
+
+PandaAlgorithm panda_algorithm_ea_util_new(void) {	// algo_ea_util.c:89-92
+	return panda_algorithm_new(&panda_algorithm_ea_util_class);
+}
+
+PandaAlgorithm panda_algorithm_stitch_new(void) {	// algo_stitch.c:89-92
+	return panda_algorithm_new(&panda_algorithm_stitch_class);
 }
 }	// extern "C"
 
@@ -307,8 +368,17 @@ int push_config(PandaAssembler a) {
 		param = panda_algorithm_pear_get_random_base_log_p(a->algo);
 	} else if (panda_algorithm_is_a(a->algo, &panda_algorithm_rdp_mle_class)) {
 		algo = PAMD_ALGO_RDP_MLE;
+	} else if (panda_algorithm_is_a(a->algo, &panda_algorithm_uparse_class)) {
+		algo = PAMD_ALGO_UPARSE;
+		param = panda_algorithm_uparse_get_error_estimation(a->algo);
+	} else if (panda_algorithm_is_a(a->algo, &panda_algorithm_flash_class)) {
+		algo = PAMD_ALGO_FLASH;
+	} else if (panda_algorithm_is_a(a->algo, &panda_algorithm_ea_util_class)) {
+		algo = PAMD_ALGO_EA_UTIL;
+	} else if (panda_algorithm_is_a(a->algo, &panda_algorithm_stitch_class)) {
+		algo = PAMD_ALGO_STITCH;
 	} else {
-		pamd_set_error("algorithm %s has no device implementation (simple_bayesian, pear, rdp_mle only)", a->algo ? panda_algorithm_class(a->algo)->name : "(null)");
+		pamd_set_error("algorithm %s has no device implementation (user-registered classes are not supported)", a->algo ? panda_algorithm_class(a->algo)->name : "(null)");
 		return PAMD_EUNSUPPORTED;
 	}
 	pamd_assembler *d = a->dev;

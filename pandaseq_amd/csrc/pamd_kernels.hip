@@ -263,7 +263,44 @@ __device__ int primer_offset(const PamdKernelParams &P, const double *ltab, cons
 	return uni(besti);
 }
 
-// ---- simple_bayesian overlap_probability for up to 4 candidates at once (algo_simple_bayes.c:33-66) ----
+// Five of the seven scorers judge an overlap from three integer counts -- unknown (an N on either side),
+// matching and mismatching bases among those present on both reads -- and differ only in the closed form:
+// simple_bayesian (algo_simple_bayes.c:61-65), uparse (algo_uparse.c:61-65), flash (algo_flash.c:60),
+// ea_util (algo_ea_util.c:56) and stitch (algo_stitch.c:56).  pear and rdp_mle sum per-base table values.
+template <int ALGO>
+__device__ __forceinline__ constexpr bool counting_algo() {
+	return ALGO != PAMD_ALGO_PEAR && ALGO != PAMD_ALGO_RDP_MLE;
+}
+
+// walked = bases present on both reads (the reference's real_overlap)
+template <int ALGO>
+__device__ __forceinline__ double count_score(const PamdKernelParams &P, int flen, int rlen, int ov, int unknowns, int matches, int walked) {
+	const int mismatches = walked - unknowns - matches;
+	if (ALGO == PAMD_ALGO_FLASH) {
+		// log(mismatches / real_overlap) with an INTEGER quotient (sic): 1 when nothing matches, else 0;
+		// an N counts as a mismatch here
+		if (walked == 0)
+			return -2.0;
+		return walked - matches == walked ? 0.0 : -__builtin_inf();
+	}
+	if (ALGO == PAMD_ALGO_EA_UTIL) {
+		const double bad = (double) (walked - matches);
+		return log((bad * bad + 1.0) / (double) walked);
+	}
+	if (ALGO == PAMD_ALGO_STITCH) {
+		// the score is a size_t: more mismatches than matches wraps to just under 2^64
+		const u64 sc = (u64) (long long) (matches - mismatches);
+		return log((double) sc / (double) (flen + rlen));
+	}
+	// simple_bayesian / uparse: size_t arithmetic inside the parenthesis (algo_simple_bayes.c:61-65), wrap
+	// included: when flen + rlen - 2*ov + unknowns is negative the reference's unsigned value is
+	// 2^64 - |x|, whose conversion to double goes through the 64-bit path; otherwise one 32-bit conversion is exact
+	const int fbases = (ov >= flen && ov >= rlen) ? unknowns : flen + rlen - 2 * ov + unknowns;
+	const double free_bases = fbases >= 0 ? (double) (unsigned) fbases : (double) (u64) (long long) fbases;
+	return P.qual_nn * free_bases + (double) matches * P.sb_pmatch + (double) mismatches * P.sb_pmismatch;
+}
+
+// ---- counting scorers: overlap_probability for up to 4 candidates at once (algo_simple_bayes.c:33-66) ----
 // The three counts come from whole words of the 2-bit code streams and special-base maps.  A candidate
 // owns ROWS 16-lane DPP rows (one when both reads fit 256 bases, else two); lane c of it owns the 16
 // overlap positions i in [16c, 16c + 16): forward bases fi = flen - ov + i ascending, reverse bases
@@ -272,7 +309,7 @@ __device__ int primer_offset(const PamdKernelParams &P, const double *ltab, cons
 // A C G T "(f.nt & r.nt) != 0" is equality of the codes; N on either side is an unknown.  Any other nt
 // inside the compared range (IUPAC ambiguity codes, 0) is reported through `odd` and the caller scores
 // that step base by base instead.
-template <int ROWS>
+template <int ALGO, int ROWS>
 __device__ __forceinline__ double score_sb_codes(const PamdKernelParams &P, const WaveLds &L, int flen, int rlen, int ov, bool active, int lane, bool &odd) {
 	const int c = lane & (16 * ROWS - 1);
 	const int i0 = 16 * c;
@@ -315,14 +352,7 @@ __device__ __forceinline__ double score_sb_codes(const PamdKernelParams &P, cons
 		packed += (unsigned) __builtin_amdgcn_ds_swizzle((int) packed, 0x401F);	// the other row of the pair (lane ^ 16)
 	const int unknowns = (int) (packed & 1023u), matches = (int) (packed >> 10);
 	const int walked = hi_i > lo_i ? hi_i - lo_i : 0;
-	const int mismatches = walked - unknowns - matches;
-	// size_t arithmetic inside the parenthesis (algo_simple_bayes.c:61-65), wrap included
-	// flen + rlen - 2*ov + unknowns in size_t arithmetic: when it is negative the reference's unsigned
-	// value is 2^64 - |x|, whose conversion to double we reproduce through the 64-bit path; otherwise a
-	// single 32-bit conversion is exact
-	const int fbases = (ov >= flen && ov >= rlen) ? unknowns : flen + rlen - 2 * ov + unknowns;
-	const double free_bases = fbases >= 0 ? (double) (unsigned) fbases : (double) (u64) (long long) fbases;
-	return P.qual_nn * free_bases + (double) matches * P.sb_pmatch + (double) mismatches * P.sb_pmismatch;
+	return count_score<ALGO>(P, flen, rlen, ov, unknowns, matches, walked);
 }
 
 // ---- pear / rdp_mle: the per-base terms of one candidate, in L.ps[0..ov) ---------------------------
@@ -401,8 +431,8 @@ __device__ __forceinline__ double sum_terms_fast(const WaveLds &L, int ov, int l
 // ---- overlap_probability, one candidate ------------------------------------------------------
 template <int ALGO>
 __device__ __forceinline__ double score_overlap(const PamdKernelParams &P, const double *ltab, const WaveLds &L, int flen, int rlen, int ov, int lane) {
-	if (ALGO == PAMD_ALGO_SIMPLE_BAYES) {
-		// algo_simple_bayes.c:33-66: three integer counts, then a closed form
+	if (counting_algo<ALGO>()) {
+		// algo_simple_bayes.c:33-66 and the other counting scorers: three integer counts, then a closed form
 		int unknowns = 0, matches = 0, mismatches = 0;
 		for (int i0 = 0; i0 < ov; i0 += 128) {	// two overlap positions per lane: four LDS reads in flight
 			const int ia = i0 + lane, ib = i0 + 64 + lane;
@@ -418,10 +448,7 @@ __device__ __forceinline__ double score_overlap(const PamdKernelParams &P, const
 			matches += __popcll(__ballot(ina && !n0 && m0)) + __popcll(__ballot(inb && !n1 && m1));
 			mismatches += __popcll(__ballot(ina && !n0 && !m0)) + __popcll(__ballot(inb && !n1 && !m1));
 		}
-		// size_t arithmetic inside the parenthesis (algo_simple_bayes.c:61-65), wrap included
-		const int fb = (ov >= flen && ov >= rlen) ? unknowns : flen + rlen - 2 * ov + unknowns;
-		const double free_bases = fb >= 0 ? (double) (unsigned) fb : (double) (u64) (long long) fb;
-		return P.qual_nn * free_bases + (double) matches * P.sb_pmatch + (double) mismatches * P.sb_pmismatch;
+		return count_score<ALGO>(P, flen, rlen, ov, unknowns, matches, unknowns + matches + mismatches);
 	} else {
 		// algo_pear.c:32-59 / algo_rdp_mle.c:43-74: a sequential f64 sum over i = 0..ov-1.
 		// Lanes produce the terms, lane 0 adds them in order.
@@ -514,7 +541,7 @@ static_assert(sizeof(PendRec) == 80, "PendRec is sized by pamd_api.cpp");
 
 template <int ALGO>
 __device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsigned *lctr, const PendRec *pend, int npend, unsigned wave_gid, int lane) {
-	constexpr int NCH = ALGO == PAMD_ALGO_SIMPLE_BAYES ? 3 : 4;	// chains per pair
+	constexpr int NCH = counting_algo<ALGO>() ? 3 : 4;	// chains per pair
 	// all of this wave's row stores must have reached L2 before they are read back
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	wave_sync();
@@ -826,7 +853,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		int examined = 0;
 		int score_parked = 0;	// pear / rdp_mle: the winner's terms sit in L.ps and must be parked
 		int ncand = 0;
-		if (ALGO != PAMD_ALGO_SIMPLE_BAYES) {
+		if (!counting_algo<ALGO>()) {
 			u64 nz = __ballot(mybits != 0);
 			while (nz != 0 && ncand <= 4) {	// only "more than four?" matters
 				const int w = __builtin_ctzll(nz);
@@ -834,7 +861,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				ncand += __popc((unsigned) __builtin_amdgcn_readlane((int) mybits, w));
 			}
 		}
-		if (ALGO == PAMD_ALGO_SIMPLE_BAYES) {
+		if (counting_algo<ALGO>()) {
 			// Candidates are scored PER_STEP at a time from the packed code streams, one candidate per
 			// DPP row (pair of rows for long reads), and judged in ascending order.
 			constexpr int ROWS = BPL == 4 ? 1 : 2;
@@ -856,7 +883,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 					pending++;
 					if (pending == PER_STEP || (lastword && m == 0)) {
 						bool odd;
-						const double sc = score_sb_codes<ROWS>(P, L, flen, rlen, myov, row < pending, lane, odd);
+						const double sc = score_sb_codes<ALGO, ROWS>(P, L, flen, rlen, myov, row < pending, lane, odd);
 						const bool slowstep = __ballot(odd) != 0;	// an nt that is neither A C G T nor N: base by base
 						for (int r = 0; r < pending; r++) {
 							const int ovr = __builtin_amdgcn_readlane(myov, 16 * ROWS * r);
@@ -871,7 +898,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 					}
 				}
 			}
-		} else if (ALGO != PAMD_ALGO_SIMPLE_BAYES && ncand > 4) {
+		} else if (!counting_algo<ALGO>() && ncand > 4) {
 			// Many candidates: list them in ascending order (u16 overlaps in the staging area), then
 			// 64 at a time, one per lane, each lane summing its own candidate in reference order.
 			uint16_t *cand = reinterpret_cast<uint16_t *>(L.ps);
@@ -1117,6 +1144,18 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 					q = ltab[PAMD_LT_SCORE + clampq(rq)];
 				} else if (rmask) {
 					q = ltab[PAMD_LT_SCORE + clampq(fq)];
+				} else if (ALGO == PAMD_ALGO_EA_UTIL) {	// algo_ea_util.c:58-67
+					q = ltab[PAMD_LT_SCORE + (fq > rq ? clampq(fq) : clampq(rq))];
+				} else if (ALGO == PAMD_ALGO_FLASH) {	// algo_flash.c:63-80
+					int sc;
+					if (match) {
+						sc = fq > rq ? clampq(fq) : clampq(rq);
+					} else {
+						sc = clampq(fq) - clampq(rq);
+						sc = sc < 0 ? -sc : sc;
+						sc = sc < 2 ? 2 : sc;
+					}
+					q = ltab[PAMD_LT_SCORE + sc];
 				} else if (ALGO == PAMD_ALGO_RDP_MLE) {	// algo_rdp_mle.c:29-41
 					if (match) {
 						const int mx = fq >= rq ? fq : rq;
@@ -1124,7 +1163,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 					} else {
 						q = ltab[PAMD_LT_C + clampq(fq) * PAMD_NQ + clampq(rq)];
 					}
-				} else {	// algo_simple_bayes.c:68-75, algo_pear.c:61-68
+				} else {	// algo_simple_bayes.c:68-75, algo_pear.c:61-68, algo_uparse.c:68-75, algo_stitch.c:59-67
 					q = ltab[(match ? PAMD_LT_A : PAMD_LT_B) + clampq(fq) * PAMD_NQ + clampq(rq)];
 				}
 				nt = match ? (a & b) : (fq < rq ? b : a);	// assembler.c:212-220
@@ -1486,6 +1525,18 @@ int pamd_launch_assemble(const PamdKernelParams &p, int workgroups, int waves_pe
 		break;
 	case PAMD_ALGO_RDP_MLE:
 		kern = PAMD_PICK(PAMD_ALGO_RDP_MLE);
+		break;
+	case PAMD_ALGO_UPARSE:
+		kern = PAMD_PICK(PAMD_ALGO_UPARSE);
+		break;
+	case PAMD_ALGO_FLASH:
+		kern = PAMD_PICK(PAMD_ALGO_FLASH);
+		break;
+	case PAMD_ALGO_EA_UTIL:
+		kern = PAMD_PICK(PAMD_ALGO_EA_UTIL);
+		break;
+	case PAMD_ALGO_STITCH:
+		kern = PAMD_PICK(PAMD_ALGO_STITCH);
 		break;
 	default:
 		pamd_set_error("unknown algorithm %d", p.algo);

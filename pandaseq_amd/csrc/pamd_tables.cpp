@@ -50,6 +50,16 @@ double pr_mismatch_rdp_assembled(double x, double y) {	// mktable.c:94-104
 	return (v == 0) ? DBL_MIN : v;
 }
 
+double pr_match_uparse(double x, double y) {	// mktable.c:106-117
+	const double v = 1 - x * y / (1 - x - y + 4 * x * y / 3);
+	return (v <= 0) ? DBL_MIN : v;
+}
+
+double pr_mismatch_uparse(double x, double y) {	// mktable.c:119-130
+	const double v = 1 - (x + y / 3) / (x + y - 4 * x * y / 3);
+	return (v <= 0) ? DBL_MIN : v;
+}
+
 }	// namespace
 
 void pamd_build_tables(PamdTables *t) {
@@ -67,6 +77,8 @@ void pamd_build_tables(PamdTables *t) {
 			t->mismatch_pear[at] = through_text(std::log(pr_mismatch_pear(x, y)));
 			t->mismatch_rdp[at] = through_text(std::log(pr_mismatch(x, y)));
 			t->mismatch_rdp_asm[at] = through_text(std::log(pr_mismatch_rdp_assembled(x, y)));
+			t->match_uparse[at] = through_text(std::log(pr_match_uparse(x, y)));
+			t->mismatch_uparse[at] = through_text(std::log(pr_mismatch_uparse(x, y)));
 		}
 	}
 }

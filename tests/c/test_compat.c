@@ -130,6 +130,14 @@ int main(int argc, char **argv) {
 		algo = panda_algorithm_pear_new();
 	else if (strcmp(argv[3], "rdp_mle") == 0)
 		algo = panda_algorithm_rdp_mle_new();
+	else if (strcmp(argv[3], "uparse") == 0)
+		algo = panda_algorithm_uparse_new();
+	else if (strcmp(argv[3], "flash") == 0)
+		algo = panda_algorithm_flash_new();
+	else if (strcmp(argv[3], "ea_util") == 0)
+		algo = panda_algorithm_ea_util_new();
+	else if (strcmp(argv[3], "stitch") == 0)
+		algo = panda_algorithm_stitch_new();
 	else
 		algo = panda_algorithm_simple_bayes_new();
 	panda_assembler_set_algorithm(a, algo);

@@ -20,7 +20,8 @@ def po(built):
 
 # ---------------------------------------------------------------- tables: pinned on the reference's own generator
 
-TABLE_NAMES = ("score", "score_err", "match_sb", "mismatch_sb", "match_pear", "mismatch_pear", "mismatch_rdp", "mismatch_rdp_asm")
+TABLE_NAMES = ("score", "score_err", "match_sb", "mismatch_sb", "match_pear", "mismatch_pear", "mismatch_rdp", "mismatch_rdp_asm",
+               "match_uparse", "mismatch_uparse")
 
 
 def test_oracle_tables_equal_reference_mktable(po):
@@ -53,8 +54,9 @@ def test_table_known_values(po):
     assert t["score"][0] == -2.0                       # mktable.c:69-71
     assert t["mismatch_rdp_asm"][0][0] == -708.396     # DBL_MIN branch, mktable.c:103
     assert t["match_sb"][0][46] == -11.6905
-    for k in TABLE_NAMES[2:]:
+    for k in TABLE_NAMES[2:-1]:
         assert np.array_equal(t[k], t[k].T), f"{k} is expected to be symmetric"
+    assert not np.array_equal(t["mismatch_uparse"], t["mismatch_uparse"].T)  # the one asymmetric table
     assert np.array_equal(t["mismatch_rdp"], t["mismatch_sb"])
 
 
