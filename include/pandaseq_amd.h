@@ -38,7 +38,7 @@ enum {
 	PAMD_EINVAL = -1,	/* bad argument / value outside the device domain */
 	PAMD_ENODEVICE = -2,	/* no HIP device, or HIP runtime error */
 	PAMD_ENOMEM = -3,
-	PAMD_EUNSUPPORTED = -4	/* e.g. num_kmers != 2, primers_after: not on the device path */
+	PAMD_EUNSUPPORTED = -4	/* e.g. num_kmers != 2: not on the device path */
 };
 
 /* One base.  Byte-identical to panda_qual (pandaseq-common.h:210-219): nt is the one-hot
@@ -151,6 +151,10 @@ int pamd_set_reverse_primer(pamd_assembler *a, const uint8_t *nt, size_t length)
 int pamd_set_forward_trim(pamd_assembler *a, size_t trim);
 int pamd_set_reverse_trim(pamd_assembler *a, size_t trim);
 int pamd_set_primer_penalty(pamd_assembler *a, double penalty);
+/* `-a` (panda_assembler_set_primers_after, assembler_support.c:355-359): look for the primers in the merged
+ * sequence and cut them off it (assembler.c:300-333, panda_compute_offset_result offset.c:114-133) instead
+ * of in the reads before assembly */
+int pamd_set_primers_after(pamd_assembler *a, int after);
 /* the two in-scope check modules, fused into the kernel, in the order added
  * (replaces panda_assembler_add_module of plugin_min_phred.c / plugin_min_overlapbits.c) */
 int pamd_add_module_min_phred(pamd_assembler *a, int phred);

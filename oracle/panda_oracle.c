@@ -365,6 +365,39 @@ size_t po_compute_offset_qual(const po_tables *t, double threshold, double penal
 	return best;
 }
 
+/* panda_log1mexp (offset.c:35-38): log(1 - exp(p)) for a log-probability p.  Restated as written, including
+ * its test `p > M_LN2`, which for p <= 0 always takes the second form. */
+double po_log1mexp(double p) {
+	return (p > 0.69314718055994530942) ? log1p(-exp(-p)) : log(-expm1(-p));
+}
+
+/* computeoffset() with result_base_score (offset.c:46-89,114-133): the same circular-bucket scan over the
+ * merged bases; a base that agrees with the primer adds its log-probability, one that does not adds
+ * log(1 - exp(p)).  reverse walks the sequence from its last base. */
+size_t po_compute_offset_result(double threshold, double penalty, int reverse, const uint8_t *nt, const double *p, size_t len, const uint8_t *primer, size_t plen) {
+	double pr[PO_MAX_LEN];
+	double bestpr = exp(plen * threshold);
+	size_t best = 0;
+	if (plen > len || plen == 0)
+		return 0;
+	for (size_t i = 0; i < plen; i++)
+		pr[i] = -INFINITY;
+	for (size_t index = 0; index < len; index++) {
+		double last = exp(pr[index % plen] / (index + 1)) - index * penalty;
+		if (last > bestpr) {
+			bestpr = last;
+			best = index + 1;
+		}
+		pr[index % plen] = 0;
+		const size_t at = reverse ? len - index - 1 : index;
+		for (ptrdiff_t x = (ptrdiff_t) (plen > index ? index : plen - 1); x >= 0; x--) {
+			if (primer[x] != NT_N)
+				pr[(index - (size_t) x) % plen] += ((nt[at] & primer[x]) != 0) ? p[at] : po_log1mexp(p[at]);
+		}
+	}
+	return best;
+}
+
 /* ------------------------------------------------------------------ phred of an output base (nt.c:126-150) */
 
 int po_result_phred(const po_tables *t, double p) {
@@ -591,7 +624,9 @@ int po_assemble(const po_config *c, const po_tables *t, po_scratch *sc, const po
 	}
 	/* :259 precheck modules: neither in-scope module has one */
 	size_t fo, ro;
-	if (c->fprimer_len > 0) {	/* :263-273 */
+	if (c->post_primers) {	/* :285-288 */
+		fo = ro = 0;
+	} else if (c->fprimer_len > 0) {	/* :263-273 */
 		fo = po_compute_offset_qual(t, c->threshold, c->primer_penalty, F, flen, c->fprimer, (size_t) c->fprimer_len);
 		if (fo == 0) {
 			ctr->nofp++;
@@ -602,7 +637,8 @@ int po_assemble(const po_config *c, const po_tables *t, po_scratch *sc, const po
 		fo = (size_t) c->ftrim;
 	}
 	res->fwd_offset = (int32_t) fo;
-	if (c->rprimer_len > 0) {	/* :274-284 */
+	if (c->post_primers) {
+	} else if (c->rprimer_len > 0) {	/* :274-284 */
 		ro = po_compute_offset_qual(t, c->threshold, c->primer_penalty, R, rlen, c->rprimer, (size_t) c->rprimer_len);
 		if (ro == 0) {
 			ctr->norp++;
@@ -624,6 +660,41 @@ int po_assemble(const po_config *c, const po_tables *t, po_scratch *sc, const po
 		ctr->noalgn++;
 		res->seq_len = 0;
 		return res->status = PO_NOALGN;
+	}
+	if (c->post_primers) {	/* :300-333: the primers are looked for in the merged sequence and cut off it */
+		const size_t len = (size_t) res->seq_len;
+		if (c->fprimer_len > 0) {
+			fo = po_compute_offset_result(c->threshold, c->primer_penalty, 0, S_nt, S_p, len, c->fprimer, (size_t) c->fprimer_len);
+			if (fo == 0) {
+				ctr->nofp++;
+				res->seq_len = 0;
+				return res->status = PO_NOFP;
+			}
+			fo--;
+		} else {
+			fo = (size_t) c->ftrim;
+		}
+		res->fwd_offset = (int32_t) fo;
+		if (c->rprimer_len > 0) {
+			ro = po_compute_offset_result(c->threshold, c->primer_penalty, 1, S_nt, S_p, len, c->rprimer, (size_t) c->rprimer_len);
+			if (ro == 0) {
+				ctr->norp++;
+				res->seq_len = 0;
+				return res->status = PO_NORP;
+			}
+			ro--;
+		} else {
+			ro = (size_t) c->rtrim;
+		}
+		res->rev_offset = (int32_t) ro;
+		if (len <= fo + ro) {	/* :323-327: counted as a missing forward primer */
+			ctr->nofp++;
+			res->seq_len = 0;
+			return res->status = PO_NOFP;
+		}
+		res->seq_len = (int32_t) (len - fo - ro);
+		memmove(S_nt, S_nt + fo, (size_t) res->seq_len);
+		memmove(S_p, S_p + fo, (size_t) res->seq_len * sizeof(double));
 	}
 	if (res->quality < c->threshold) {	/* :334-338 */
 		ctr->lowq++;

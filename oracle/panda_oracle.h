@@ -13,7 +13,7 @@
  *   - align(): seed, scan, argmax, merge (assembler.c:48-250)
  *   - the three scoring algorithms       (algo_simple_bayes.c:33-75, algo_pear.c:32-68, algo_rdp_mle.c:29-74)
  *   - the four remaining scorers         (algo_uparse.c:33-75, algo_flash.c:30-80, algo_ea_util.c:29-67, algo_stitch.c:28-67)
- *   - the primer offset scan             (offset.c:47-112)
+ *   - the primer offset scan             (offset.c:47-112), also over the merged sequence (`-a`, offset.c:35-38,114-133, assembler.c:300-333)
  *   - assemble_seq() control + counters  (assembler.c:252-348)
  *   - panda_result_phred + min_phred / min_overlapbits (nt.c:126-150, plugin_min_phred.c:8-22, plugin_min_overlapbits.c:17-23)
  *
@@ -109,6 +109,7 @@ typedef struct {
 	int n_modules;
 	po_module modules[PO_MAX_MODULES];
 	double up_q, up_pmatch, up_pmismatch;	/* algo_uparse.c:126-135 */
+	int post_primers;			/* `-a`: look for the primers in the merged sequence (assembler.c:300-333) */
 } po_config;
 
 typedef struct {
@@ -148,6 +149,9 @@ double po_overlap_probability(const po_config *c, const po_tables *t, const po_q
 double po_match_probability(const po_config *c, const po_tables *t, int match, int8_t a, int8_t b);
 size_t po_compute_offset_qual(const po_tables *t, double threshold, double penalty, const po_qual *seq, size_t len, const uint8_t *primer, size_t plen);
 int po_result_phred(const po_tables *t, double p);
+double po_log1mexp(double p);	/* panda_log1mexp, offset.c:35-38 */
+/* panda_compute_offset_result (offset.c:114-133): the primer scan over merged bases; reverse = from the 3' end */
+size_t po_compute_offset_result(double threshold, double penalty, int reverse, const uint8_t *nt, const double *p, size_t len, const uint8_t *primer, size_t plen);
 size_t po_kmers_forward(const po_qual *s, size_t len, uint16_t *kmer, uint16_t *posn);
 size_t po_kmers_reverse(const po_qual *s, size_t len, uint16_t *kmer, uint16_t *posn);
 

@@ -37,6 +37,7 @@ class Config(C.Structure):
         ("n_modules", C.c_int),
         ("modules", Module * MAX_MODULES),
         ("up_q", C.c_double), ("up_pmatch", C.c_double), ("up_pmismatch", C.c_double),
+        ("post_primers", C.c_int),
     ]
 
 
@@ -133,7 +134,7 @@ def tables_np():
 
 
 def make_config(algo="simple_bayesian", q=None, pear_random_base_log=None, threshold=None, minoverlap=None,
-                maxoverlap=None, fprimer=None, rprimer=None, ftrim=0, rtrim=0, primer_penalty=0.0, modules=()):
+                maxoverlap=None, fprimer=None, rprimer=None, ftrim=0, rtrim=0, primer_penalty=0.0, modules=(), primers_after=False):
     """Mirror of the flag -> setter mapping of args_assembler.c:26-368 for the in-scope knobs.
     fprimer / rprimer are sequences of nt codes as the assembler stores them (the -q primer is
     already complemented, args_assembler.c:222)."""
@@ -167,6 +168,7 @@ def make_config(algo="simple_bayesian", q=None, pear_random_base_log=None, thres
         c.rtrim = 0
     if 0 <= primer_penalty < 1:
         c.primer_penalty = primer_penalty
+    c.post_primers = 1 if primers_after else 0  # `-a`, args_assembler.c
     c.n_modules = len(modules)
     for i, (kind, val) in enumerate(modules):
         if kind == "min_phred":

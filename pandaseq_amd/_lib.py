@@ -66,7 +66,7 @@ SYMBOLS = [
     "pamd_last_error", "pamd_device_count", "pamd_assembler_create", "pamd_assembler_destroy",
     "pamd_set_algorithm", "pamd_set_threshold", "pamd_set_minimum_overlap", "pamd_set_maximum_overlap",
     "pamd_set_forward_primer", "pamd_set_reverse_primer", "pamd_set_forward_trim", "pamd_set_reverse_trim",
-    "pamd_set_primer_penalty", "pamd_add_module_min_phred", "pamd_add_module_min_overlapbits",
+    "pamd_set_primer_penalty", "pamd_set_primers_after", "pamd_add_module_min_phred", "pamd_add_module_min_overlapbits",
     "pamd_clear_modules", "pamd_set_exact_sums", "pamd_tables_get", "pamd_assemble_device", "pamd_assemble_host",
     "pamd_last_kernel_ms", "pamd_last_launch_info", "pamd_synth_generate", "pamd_debug_phase_cycles",
 ]
@@ -104,6 +104,7 @@ def lib():
     L.pamd_set_forward_trim.argtypes = [C.c_void_p, C.c_size_t]
     L.pamd_set_reverse_trim.argtypes = [C.c_void_p, C.c_size_t]
     L.pamd_set_primer_penalty.argtypes = [C.c_void_p, C.c_double]
+    L.pamd_set_primers_after.argtypes = [C.c_void_p, C.c_int]
     L.pamd_add_module_min_phred.argtypes = [C.c_void_p, C.c_int]
     L.pamd_add_module_min_overlapbits.argtypes = [C.c_void_p, C.c_double]
     L.pamd_clear_modules.argtypes = [C.c_void_p]

@@ -152,6 +152,10 @@ class Assembler:
     def set_primer_penalty(self, p: float):
         check(lib().pamd_set_primer_penalty(self._h, float(p)))
 
+    def set_primers_after(self, after: bool):
+        """`-a`: strip the primers after assembly instead of before (assembler_support.c:355-359)."""
+        check(lib().pamd_set_primers_after(self._h, 1 if after else 0))
+
     def add_module(self, spec: str):
         """`-C name:args` for the two fused check modules (module.c:244-247 splits name from args)."""
         name, _, args = spec.partition(":")

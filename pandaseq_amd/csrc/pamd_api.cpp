@@ -62,6 +62,8 @@ struct pamd_assembler {
 	int n_modules = 0;
 	PamdModule modules[PAMD_MAX_MODULES];
 	int exact_sums = 1;
+	int post_primers = 0;
+	double *d_notp = nullptr;
 	// tables
 	PamdTables tabs;
 	double *d_tables = nullptr;	// image for the current algorithm
@@ -160,7 +162,7 @@ pamd_assembler *pamd_assembler_create(int device) {
 	a->pear_random_base = std::log(0.25);	// algo_pear.c:106
 	a->threshold = std::log(0.6);	// assembler_support.c:76
 	memset(a->primers, 0, sizeof a->primers);
-	if (hipMalloc(&a->d_tables, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_primers, sizeof a->primers) != hipSuccess || hipMalloc(&a->d_error, sizeof(unsigned long long)) != hipSuccess || hipMalloc(&a->d_phase, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_phase, 0, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_error, 0, sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&a->ev_start) != hipSuccess || hipEventCreate(&a->ev_stop) != hipSuccess) {
+	if (hipMalloc(&a->d_tables, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_notp, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_primers, sizeof a->primers) != hipSuccess || hipMalloc(&a->d_error, sizeof(unsigned long long)) != hipSuccess || hipMalloc(&a->d_phase, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_phase, 0, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_error, 0, sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&a->ev_start) != hipSuccess || hipEventCreate(&a->ev_stop) != hipSuccess) {
 		pamd_set_error("device allocation failed on device %d", device);
 		pamd_assembler_destroy(a);
 		return nullptr;
@@ -174,6 +176,8 @@ void pamd_assembler_destroy(pamd_assembler *a) {
 	(void) hipSetDevice(a->device);
 	if (a->d_tables)
 		(void) hipFree(a->d_tables);
+	if (a->d_notp)
+		(void) hipFree(a->d_notp);
 	if (a->d_primers)
 		(void) hipFree(a->d_primers);
 	if (a->d_error)
@@ -260,6 +264,13 @@ int pamd_set_reverse_trim(pamd_assembler *a, size_t trim) {	// assembler_support
 	return PAMD_OK;
 }
 
+int pamd_set_primers_after(pamd_assembler *a, int after) {	// assembler_support.c:355-359
+	if (a == nullptr)
+		return PAMD_EINVAL;
+	a->post_primers = after ? 1 : 0;
+	return PAMD_OK;
+}
+
 int pamd_set_primer_penalty(pamd_assembler *a, double penalty) {	// assembler_support.c:404-410
 	if (penalty >= 0 && penalty < 1)
 		a->primer_penalty = penalty;
@@ -326,12 +337,19 @@ static int upload_tables(pamd_assembler *a, hipStream_t st) {
 			B = a->tabs.mismatch_sb;
 			break;
 		}
+		img[PAMD_LT_SCORE + 47] = a->tabs.qual_nn;	// the spare slot of the score block: what `-a` calls entry 47
 		memcpy(&img[PAMD_LT_A], A, sizeof(double) * PAMD_TAB);
 		memcpy(&img[PAMD_LT_B], B, sizeof(double) * PAMD_TAB);
 		if (C)
 			memcpy(&img[PAMD_LT_C], C, sizeof(double) * PAMD_TAB);
 		// synchronous on purpose: `img` is a stack-lifetime host buffer
 		HIP_TRY(hipMemcpy(a->d_tables, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
+		// panda_log1mexp (offset.c:35-38) of every entry, with the host's libm as the reference uses it: what a
+		// merged base that disagrees with a primer adds in the `-a` scan (offset.c:114-122)
+		std::vector<double> notp(img.size());
+		for (size_t i = 0; i < img.size(); i++)
+			notp[i] = (img[i] > M_LN2) ? std::log1p(-std::exp(-img[i])) : std::log(-std::expm1(-img[i]));
+		HIP_TRY(hipMemcpy(a->d_notp, notp.data(), sizeof(double) * notp.size(), hipMemcpyHostToDevice));
 		a->d_tables_algo = a->algo;
 	}
 	if (a->primers_dirty) {
@@ -389,6 +407,8 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.error_flag = a->d_error;
 	p.phase_cycles = a->d_phase;
 	p.tables = a->d_tables;
+	p.notp = a->d_notp;
+	p.post_primers = a->post_primers;
 	p.primers = a->d_primers;
 	p.n_pairs = b->n_pairs;
 	p.seq_stride = b->seq_stride;
@@ -448,6 +468,9 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	o += mmax;
 	p.w_p = o;
 	o += (mmax * 8u > 2048u ? mmax * 8u : 2048u);
+	p.w_pidx = o;
+	if (a->post_primers)
+		o += mmax * 2u;
 	p.lds_wave_bytes = up16(o);
 	{
 		const uint32_t region = (mmax * 8u > 2048u ? mmax * 8u : 2048u);

@@ -354,10 +354,6 @@ namespace {
 int push_config(PandaAssembler a) {
 	if (!a->dev_dirty)
 		return PAMD_OK;
-	if (a->post_primers) {
-		pamd_set_error("primers_after (-a) is not implemented on the device path");
-		return PAMD_EUNSUPPORTED;
-	}
 	int algo;
 	double param = NAN;
 	if (panda_algorithm_is_a(a->algo, &panda_algorithm_simple_bayes_class)) {
@@ -383,6 +379,7 @@ int push_config(PandaAssembler a) {
 	}
 	pamd_assembler *d = a->dev;
 	pamd_set_algorithm(d, algo, param);
+	pamd_set_primers_after(d, a->post_primers ? 1 : 0);
 	pamd_set_threshold(d, std::exp(a->threshold));
 	pamd_set_minimum_overlap(d, a->minoverlap);
 	pamd_set_maximum_overlap(d, a->maxoverlap);

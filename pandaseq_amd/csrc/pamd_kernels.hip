@@ -119,6 +119,7 @@ struct WaveLds {
 	uint32_t *bits;	// candidate overlaps (BITS_INIT, assembler.c:41,84)
 	uint8_t *nts;	// merged nt staging
 	double *ps;	// merged log-p staging; the k-mer table lives here while seeding
+	uint16_t *pidx;	// `-a` only: which table entry each merged log-p came from (index into the table image)
 	uint32_t *hash;
 };
 
@@ -251,6 +252,52 @@ __device__ int primer_offset(const PamdKernelParams &P, const double *ltab, cons
 		}
 	}
 	// first-maximum across lanes: larger value wins, equal values -> smaller index
+	for (int off = 32; off > 0; off >>= 1) {
+		const double ob = __shfl_xor(best, off);
+		const int oi = __shfl_xor(besti, off);
+		const bool take = (oi != 0) && (besti == 0 || ob > best || (ob == best && oi < besti));
+		if (take) {
+			best = ob;
+			besti = oi;
+		}
+	}
+	return uni(besti);
+}
+
+// ---- primer offset in the MERGED sequence (`-a`: panda_compute_offset_result, offset.c:114-133) --------
+// The same scan as primer_offset() over the merged bases staged in LDS: a base that agrees with the primer
+// adds its log-probability p, one that does not adds log(1 - exp(p)) (panda_log1mexp, offset.c:35-38).
+// Every p is an entry of the probability tables, so that second value is read from a table the HOST
+// computed with its libm for each entry (P.notp, same layout as the table image) -- no device log/exp
+// enters the ordered sums.  reverse: the sequence is walked from its last base (offset.c:80).
+__device__ int primer_offset_result(const PamdKernelParams &P, const WaveLds &L, int len, const uint8_t *primer, int plen, bool reverse, int lane) {
+	if (plen > len)
+		return 0;
+	const bool logdomain = P.primer_penalty == 0.0;
+	double best = logdomain ? (double) plen * P.threshold : exp((double) plen * P.threshold);
+	int besti = 0;
+	for (int base = 0; base + plen <= len - 1; base += 64) {
+		const int s = base + lane;
+		const int index = s + plen;
+		if (index <= len - 1) {
+			double acc = 0.0;
+			for (int x = 0; x < plen; x++) {	// the order offset.c:79-87 fills bucket s in
+				const unsigned pn = primer[x];
+				if (pn != NT_N) {
+					const int at = reverse ? len - 1 - (s + x) : s + x;
+					const unsigned nt = L.nts[at];
+					acc += ((nt & pn) != 0) ? L.ps[at] : P.notp[L.pidx[at]];
+				}
+			}
+			double v = acc / (double) (index + 1);
+			if (!logdomain)
+				v = exp(v) - (double) index * P.primer_penalty;
+			if (v > best) {	// strict: the earliest index wins ties (offset.c:74)
+				best = v;
+				besti = index + 1;
+			}
+		}
+	}
 	for (int off = 32; off > 0; off >>= 1) {
 		const double ob = __shfl_xor(best, off);
 		const int oi = __shfl_xor(besti, off);
@@ -731,8 +778,11 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		PH_MARK(0);
 
 		// ---- primer offsets / trims (assembler.c:262-288) ----
+		const bool post = P.post_primers != 0;	// `-a`: primers are looked for in the merged sequence instead
 		int fo, ro;
-		if (P.fprimer_len > 0) {
+		if (post) {
+			fo = 0;
+		} else if (P.fprimer_len > 0) {
 			const int r = primer_offset(P, ltab, L.F, flen, lprimers, P.fprimer_len, lane);
 			if (r == 0) {
 				status = PAMD_ST_NOFP;
@@ -743,7 +793,9 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			fo = P.ftrim;
 		}
 		rec.fo = fo;
-		if (P.rprimer_len > 0) {
+		if (post) {
+			ro = 0;
+		} else if (P.rprimer_len > 0) {
 			const int r = primer_offset(P, ltab, L.R, rlen, lprimers + 456, P.rprimer_len, lane);
 			if (r == 0) {
 				status = PAMD_ST_NORP;
@@ -978,13 +1030,14 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 					} else {
 						// fast sums: `best` (any-order, |error| < 1e-9) is what gets reported; the one
 						// decision that still depends on it is min_overlapbits, re-done exactly if close
+						bool redo = post && P.exact_sums != 0;	// `-a` has no group finish: exact sums are made here
 						for (int mi = 0; mi < P.n_modules; mi++) {
 							const PamdModule md = P.modules[mi];
-							if (md.kind == 2 && fabs(md.nats - best) <= 1e-6) {
-								score_terms<ALGO>(P, ltab, L, flen, rlen, bo, lane);
-								best = sum_terms_exact(L, bo, lane);
-								break;
-							}
+							redo |= md.kind == 2 && fabs(md.nats - best) <= 1e-6;
+						}
+						if (redo) {
+							score_terms<ALGO>(P, ltab, L, flen, rlen, bo, lane);
+							best = sum_terms_exact(L, bo, lane);
 						}
 					}
 				}
@@ -1111,6 +1164,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const double q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
 				L.nts[j] = (uint8_t) nt;
 				L.ps[j] = q;
+				if (post)
+					L.pidx[j] = (uint16_t) (PAMD_LT_SCORE + clampq(qual_of(e)));
 				if (!EXACT)
 					qacc += q;
 				// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
@@ -1169,6 +1224,28 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				nt = match ? (a & b) : (fq < rq ? b : a);	// assembler.c:212-220
 				L.nts[A + i] = (uint8_t) nt;
 				L.ps[A + i] = q;
+				if (post) {	// the table entry q was read from (slot 47 of the score block stands for qual_nn)
+					int qi;
+					if (fmask && rmask) {
+						qi = PAMD_LT_SCORE + 47;
+					} else if (fmask) {
+						qi = PAMD_LT_SCORE + clampq(rq);
+					} else if (rmask) {
+						qi = PAMD_LT_SCORE + clampq(fq);
+					} else if (ALGO == PAMD_ALGO_EA_UTIL) {
+						qi = PAMD_LT_SCORE + (fq > rq ? clampq(fq) : clampq(rq));
+					} else if (ALGO == PAMD_ALGO_FLASH) {
+						int sc = clampq(fq) - clampq(rq);
+						sc = sc < 0 ? -sc : sc;
+						sc = sc < 2 ? 2 : sc;
+						qi = PAMD_LT_SCORE + (match ? (fq > rq ? clampq(fq) : clampq(rq)) : sc);
+					} else if (ALGO == PAMD_ALGO_RDP_MLE) {
+						qi = match ? PAMD_LT_SCORE + clampq(fq >= rq ? fq : rq) : PAMD_LT_C + clampq(fq) * PAMD_NQ + clampq(rq);
+					} else {
+						qi = (match ? PAMD_LT_A : PAMD_LT_B) + clampq(fq) * PAMD_NQ + clampq(rq);
+					}
+					L.pidx[A + i] = (uint16_t) qi;
+				}
 				if (!EXACT)
 					qacc += q;
 				// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
@@ -1191,6 +1268,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const double q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
 				L.nts[A + novl + i] = (uint8_t) nt;
 				L.ps[A + novl + i] = q;
+				if (post)
+					L.pidx[A + novl + i] = (uint16_t) (PAMD_LT_SCORE + clampq(qual_of(e)));
 				if (!EXACT)
 					qacc += q;
 				// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
@@ -1201,37 +1280,15 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			}
 			degen += __popcll(__ballot(in && __popc(nt) != 1));
 		}
-		// the row leaves LDS in full 16-byte stores (16 nt or 2 log-p per lane); rows are 16-base aligned
 		wave_sync();
-		if (store) {
-			if (lane * 16 < seqlen)
-				reinterpret_cast<uint4 *>(row_nt)[lane] = reinterpret_cast<const uint4 *>(L.nts)[lane];
-			for (int j0 = 0; j0 < seqlen; j0 += 128) {
-				const int j = j0 + lane * 2;
-				if (j < seqlen)
-					reinterpret_cast<double2 *>(row_p)[j >> 1] = reinterpret_cast<const double2 *>(L.ps)[j >> 1];
-			}
-		}
-		if (want_phred) {
-			for (int o = 32; o > 0; o >>= 1) {
-				const double other = __shfl_xor(pmin, o);
-				pmin = other < pmin ? other : pmin;
-			}
-			phmin = result_phred(ltab + PAMD_LT_SCORE, uni_f64(pmin));
-			if (__ballot(low_p) != 0 && phmin > 1)
-				phmin = 1;
-			rec.phmin = seqlen > 0 ? phmin : 127;	// an empty row passes any threshold
-		}
-		rec.mism = mism;
-		rec.degen = degen;
-		row_need = P.seq_stride == 0 && store ? need : 0;
-		if (!EXACT) {
-			// quality from the any-order sum (|error| ~1e-12); the LOWQ verdict is the only consumer that
-			// could notice, so within 1e-9 of the threshold the three sums are redone in reference order
+		// quality from the any-order sum (|error| ~1e-12); the LOWQ verdict is the only consumer that could
+		// notice, so within 1e-9 of the threshold (or always, for `-a` in exact-sums mode, which has no
+		// group finish) the three sums are redone in reference order from the staged row
+		auto fast_quality = [&](bool always_exact) {
 			for (int o = 32; o > 0; o >>= 1)
 				qacc += __shfl_xor(qacc, o);
-			quality_fast = uni_f64(qacc) / (double) len;
-			if (fabs(quality_fast - P.threshold) <= 1e-9) {
+			double quality = uni_f64(qacc) / (double) len;
+			if (always_exact || fabs(quality - P.threshold) <= 1e-9) {
 				wave_sync();
 				double acc = 0.0;
 				int lo = 0, hi = 0;
@@ -1247,9 +1304,93 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				for (int j = lo; j < hi; j++)
 					acc += L.ps[j];
 				const double fq = lane_f64(acc, 0), rq = lane_f64(acc, 1), oq = lane_f64(acc, 2);
-				quality_fast = (fq + rq + oq) / (double) len;	// assembler.c:244
+				quality = (fq + rq + oq) / (double) len;	// assembler.c:244
+			}
+			return quality;
+		};
+		int out_len = seqlen;	// bases the row keeps
+		if (post) {
+			// ---- `-a`: find the primers in the merged sequence and cut them off it (assembler.c:300-333) ----
+			if (!EXACT)
+				quality_fast = fast_quality(P.exact_sums != 0);	// needs the whole row: before it is cut
+			int pfo = P.ftrim, pro = P.rtrim;
+			if (P.fprimer_len > 0) {
+				const int r = primer_offset_result(P, L, seqlen, lprimers, P.fprimer_len, false, lane);
+				if (r == 0) {
+					status = PAMD_ST_NOFP;
+					break;
+				}
+				pfo = r - 1;
+			}
+			rec.fo = pfo;
+			if (P.rprimer_len > 0) {
+				const int r = primer_offset_result(P, L, seqlen, lprimers + 456, P.rprimer_len, true, lane);
+				if (r == 0) {
+					status = PAMD_ST_NORP;
+					break;
+				}
+				pro = r - 1;
+			}
+			rec.ro = pro;
+			if (seqlen <= pfo + pro) {	// assembler.c:323-327: counted as a missing forward primer
+				status = PAMD_ST_NOFP;
+				break;
+			}
+			out_len = seqlen - pfo - pro;
+			rec.seqlen = out_len;
+			// move the kept bases to the front of the staged row, 64 at a time, reads before writes
+			if (pfo > 0) {
+				for (int j0 = 0; j0 < out_len; j0 += 64) {
+					const int j = j0 + lane;
+					unsigned nt = 0;
+					double q = 0.0;
+					if (j < out_len) {
+						nt = L.nts[j + pfo];
+						q = L.ps[j + pfo];
+					}
+					wave_sync();
+					if (j < out_len) {
+						L.nts[j] = (uint8_t) nt;
+						L.ps[j] = q;
+					}
+				}
+			}
+			wave_sync();
+			if (want_phred) {	// the smallest phred of the KEPT bases
+				low_p = false;
+				pmin = 0.0;
+				for (int j = lane; j < out_len; j += 64) {
+					const double q = L.ps[j];
+					low_p |= q <= qs0;
+					pmin = (q > qs0 && q < pmin) ? q : pmin;
+				}
 			}
 		}
+		// the row leaves LDS in full 16-byte stores (16 nt or 2 log-p per lane); rows are 16-base aligned
+		if (store) {
+			if (lane * 16 < out_len)
+				reinterpret_cast<uint4 *>(row_nt)[lane] = reinterpret_cast<const uint4 *>(L.nts)[lane];
+			for (int j0 = 0; j0 < out_len; j0 += 128) {
+				const int j = j0 + lane * 2;
+				if (j < out_len)
+					reinterpret_cast<double2 *>(row_p)[j >> 1] = reinterpret_cast<const double2 *>(L.ps)[j >> 1];
+			}
+		}
+		if (want_phred) {
+			for (int o = 32; o > 0; o >>= 1) {
+				const double other = __shfl_xor(pmin, o);
+				pmin = other < pmin ? other : pmin;
+			}
+			phmin = result_phred(ltab + PAMD_LT_SCORE, uni_f64(pmin));
+			if (__ballot(low_p) != 0 && phmin > 1)
+				phmin = 1;
+			rec.phmin = out_len > 0 ? phmin : 127;	// an empty row passes any threshold
+		}
+		rec.mism = mism;
+		rec.degen = degen;
+		row_need = P.seq_stride == 0 && store ? need : 0;
+		if (!EXACT && !post)
+			quality_fast = fast_quality(false);
 	} while (0);
 	if (!rotated) {
 		cur = nxt;
@@ -1346,6 +1487,7 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	L.nts = wb + P.w_nt;
 	L.ps = reinterpret_cast<double *>(wb + P.w_p);
 	L.hash = reinterpret_cast<uint32_t *>(wb + P.w_p);
+	L.pidx = reinterpret_cast<uint16_t *>(wb + P.w_pidx);
 	PendRec *pend = reinterpret_cast<PendRec *>(wb + P.w_pend);
 
 	WaveArena arena;
@@ -1514,7 +1656,9 @@ int pamd_launch_assemble(const PamdKernelParams &p, int workgroups, int waves_pe
 	void (*kern)(const PamdKernelParams) = nullptr;
 	const bool ph = p.has_min_phred != 0;
 	const bool narrow = p.smax <= 256;	// 4 bases per lane while staging
-#define PAMD_PICK3(A, PH, B) (p.exact_sums ? pamd_assemble_kernel<A, PH, B, true> : pamd_assemble_kernel<A, PH, B, false>)
+// `-a` always runs the instantiation without the deferred group finish (the finish re-reads rows by the
+	// ranges of the untrimmed merge); with exact sums asked for it makes them in the wave instead
+#define PAMD_PICK3(A, PH, B) ((p.exact_sums && !p.post_primers) ? pamd_assemble_kernel<A, PH, B, true> : pamd_assemble_kernel<A, PH, B, false>)
 #define PAMD_PICK(A) (ph ? (narrow ? PAMD_PICK3(A, true, 4) : PAMD_PICK3(A, true, 8)) : (narrow ? PAMD_PICK3(A, false, 4) : PAMD_PICK3(A, false, 8)))
 	switch (p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
