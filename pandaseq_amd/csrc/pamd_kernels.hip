@@ -718,6 +718,34 @@ __device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsi
 	wave_sync();
 }
 
+// quality from the any-order sum (|error| ~1e-12); the LOWQ verdict is the only consumer that could notice,
+// so within 1e-9 of the threshold (or always, for `-a` in exact-sums mode, which has no group finish) the
+// three sums are redone in reference order from the staged row (assembler.c:171,226,236,244)
+__device__ __forceinline__ double fast_quality(const WaveLds &L, double qacc, double threshold, int len, int seqlen, int A, int novl, bool always_exact, int lane) {
+	for (int o = 32; o > 0; o >>= 1)
+		qacc += __shfl_xor(qacc, o);
+	double quality = uni_f64(qacc) / (double) len;
+	if (always_exact || fabs(quality - threshold) <= 1e-9) {
+		wave_sync();
+		double acc = 0.0;
+		int lo = 0, hi = 0;
+		if (lane == 0) {
+			hi = A;
+		} else if (lane == 1) {
+			lo = A + novl;
+			hi = seqlen;
+		} else if (lane == 2) {
+			lo = A;
+			hi = A + novl;
+		}
+		for (int j = lo; j < hi; j++)
+			acc += L.ps[j];
+		const double fq = lane_f64(acc, 0), rq = lane_f64(acc, 1), oq = lane_f64(acc, 2);
+		quality = (fq + rq + oq) / (double) len;	// assembler.c:244
+	}
+	return quality;
+}
+
 // the registers a wave carries from one pair to the next (software prefetch)
 struct Carry {
 	int flen_v, rlen_v;
@@ -725,7 +753,7 @@ struct Carry {
 };
 
 // ---- one pair: everything up to its parked record ----------------------------------------------
-template <int ALGO, bool PHRED, int BPL, bool EXACT>
+template <int ALGO, bool PHRED, int BPL, bool EXACT, bool POST>
 __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, unsigned *lctr, const WaveLds &L, WaveArena &arena, PendRec *slot_rec, int slot_idx, unsigned wave_gid, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt
 #ifdef PAMD_PHASE_TIMING
 	, u64 *ph_acc
@@ -778,7 +806,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		PH_MARK(0);
 
 		// ---- primer offsets / trims (assembler.c:262-288) ----
-		const bool post = P.post_primers != 0;	// `-a`: primers are looked for in the merged sequence instead
+		constexpr bool post = POST;	// `-a`: primers are looked for in the merged sequence instead (own kernel instantiation)
 		int fo, ro;
 		if (post) {
 			fo = 0;
@@ -1281,38 +1309,11 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			degen += __popcll(__ballot(in && __popc(nt) != 1));
 		}
 		wave_sync();
-		// quality from the any-order sum (|error| ~1e-12); the LOWQ verdict is the only consumer that could
-		// notice, so within 1e-9 of the threshold (or always, for `-a` in exact-sums mode, which has no
-		// group finish) the three sums are redone in reference order from the staged row
-		auto fast_quality = [&](bool always_exact) {
-			for (int o = 32; o > 0; o >>= 1)
-				qacc += __shfl_xor(qacc, o);
-			double quality = uni_f64(qacc) / (double) len;
-			if (always_exact || fabs(quality - P.threshold) <= 1e-9) {
-				wave_sync();
-				double acc = 0.0;
-				int lo = 0, hi = 0;
-				if (lane == 0) {
-					hi = A;
-				} else if (lane == 1) {
-					lo = A + novl;
-					hi = seqlen;
-				} else if (lane == 2) {
-					lo = A;
-					hi = A + novl;
-				}
-				for (int j = lo; j < hi; j++)
-					acc += L.ps[j];
-				const double fq = lane_f64(acc, 0), rq = lane_f64(acc, 1), oq = lane_f64(acc, 2);
-				quality = (fq + rq + oq) / (double) len;	// assembler.c:244
-			}
-			return quality;
-		};
 		int out_len = seqlen;	// bases the row keeps
 		if (post) {
 			// ---- `-a`: find the primers in the merged sequence and cut them off it (assembler.c:300-333) ----
 			if (!EXACT)
-				quality_fast = fast_quality(P.exact_sums != 0);	// needs the whole row: before it is cut
+				quality_fast = fast_quality(L, qacc, P.threshold, len, seqlen, A, novl, P.exact_sums != 0, lane);	// needs the whole row: before it is cut
 			int pfo = P.ftrim, pro = P.rtrim;
 			if (P.fprimer_len > 0) {
 				const int r = primer_offset_result(P, L, seqlen, lprimers, P.fprimer_len, false, lane);
@@ -1390,7 +1391,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		rec.degen = degen;
 		row_need = P.seq_stride == 0 && store ? need : 0;
 		if (!EXACT && !post)
-			quality_fast = fast_quality(false);
+			quality_fast = fast_quality(L, qacc, P.threshold, len, seqlen, A, novl, false, lane);
 	} while (0);
 	if (!rotated) {
 		cur = nxt;
@@ -1455,7 +1456,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 	}
 }
 
-template <int ALGO, bool PHRED, int BPL, bool EXACT>
+template <int ALGO, bool PHRED, int BPL, bool EXACT, bool POST>
 __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	double *ltab = reinterpret_cast<double *>(lds);
@@ -1524,9 +1525,9 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		nxt.r = load_read<BPL>(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
 #ifdef PAMD_PHASE_TIMING
-		assemble_pair<ALGO, PHRED, BPL, EXACT>(P, ltab, lprimers, lctr, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt, ph_acc);
+		assemble_pair<ALGO, PHRED, BPL, EXACT, POST>(P, ltab, lprimers, lctr, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt, ph_acc);
 #else
-		assemble_pair<ALGO, PHRED, BPL, EXACT>(P, ltab, lprimers, lctr, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt);
+		assemble_pair<ALGO, PHRED, BPL, EXACT, POST>(P, ltab, lprimers, lctr, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt);
 #endif
 		if (EXACT)
 			npend++;
@@ -1658,7 +1659,7 @@ int pamd_launch_assemble(const PamdKernelParams &p, int workgroups, int waves_pe
 	const bool narrow = p.smax <= 256;	// 4 bases per lane while staging
 // `-a` always runs the instantiation without the deferred group finish (the finish re-reads rows by the
 	// ranges of the untrimmed merge); with exact sums asked for it makes them in the wave instead
-#define PAMD_PICK3(A, PH, B) ((p.exact_sums && !p.post_primers) ? pamd_assemble_kernel<A, PH, B, true> : pamd_assemble_kernel<A, PH, B, false>)
+#define PAMD_PICK3(A, PH, B) (p.post_primers ? pamd_assemble_kernel<A, PH, B, false, true> : (p.exact_sums ? pamd_assemble_kernel<A, PH, B, true, false> : pamd_assemble_kernel<A, PH, B, false, false>))
 #define PAMD_PICK(A) (ph ? (narrow ? PAMD_PICK3(A, true, 4) : PAMD_PICK3(A, true, 8)) : (narrow ? PAMD_PICK3(A, false, 4) : PAMD_PICK3(A, false, 8)))
 	switch (p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
