@@ -321,7 +321,7 @@ __device__ __forceinline__ constexpr bool counting_algo() {
 
 // walked = bases present on both reads (the reference's real_overlap)
 template <int ALGO>
-__device__ __forceinline__ double count_score(const PamdKernelParams &P, int flen, int rlen, int ov, int unknowns, int matches, int walked) {
+__device__ __forceinline__ double count_score(double qual_nn, double pmatch, double pmismatch, int flen, int rlen, int ov, int unknowns, int matches, int walked) {
 	const int mismatches = walked - unknowns - matches;
 	if (ALGO == PAMD_ALGO_FLASH) {
 		// log(mismatches / real_overlap) with an INTEGER quotient (sic): 1 when nothing matches, else 0;
@@ -344,7 +344,7 @@ __device__ __forceinline__ double count_score(const PamdKernelParams &P, int fle
 	// 2^64 - |x|, whose conversion to double goes through the 64-bit path; otherwise one 32-bit conversion is exact
 	const int fbases = (ov >= flen && ov >= rlen) ? unknowns : flen + rlen - 2 * ov + unknowns;
 	const double free_bases = fbases >= 0 ? (double) (unsigned) fbases : (double) (u64) (long long) fbases;
-	return P.qual_nn * free_bases + (double) matches * P.sb_pmatch + (double) mismatches * P.sb_pmismatch;
+	return qual_nn * free_bases + (double) matches * pmatch + (double) mismatches * pmismatch;
 }
 
 // ---- counting scorers: overlap_probability for up to 4 candidates at once (algo_simple_bayes.c:33-66) ----
@@ -356,10 +356,8 @@ __device__ __forceinline__ double count_score(const PamdKernelParams &P, int fle
 // A C G T "(f.nt & r.nt) != 0" is equality of the codes; N on either side is an unknown.  Any other nt
 // inside the compared range (IUPAC ambiguity codes, 0) is reported through `odd` and the caller scores
 // that step base by base instead.
-template <int ALGO, int ROWS>
-__device__ __forceinline__ double score_sb_codes(const PamdKernelParams &P, const WaveLds &L, int flen, int rlen, int ov, bool active, int lane, bool &odd) {
-	const int c = lane & (16 * ROWS - 1);
-	const int i0 = 16 * c;
+// counts of the 16 overlap positions i0 .. i0+15 of candidate `ov`: unknowns in bits 0..9, matches in bits 10..
+__device__ __forceinline__ unsigned code_word_counts(const WaveLds &L, int flen, int rlen, int ov, int i0, bool active, bool &odd) {
 	// positions that exist on both reads: max(0, ov - flen) <= i < min(ov, rlen)
 	int lo_i = ov - flen;
 	lo_i = lo_i < 0 ? 0 : lo_i;
@@ -389,7 +387,13 @@ __device__ __forceinline__ double score_sb_codes(const PamdKernelParams &P, cons
 	const unsigned sp = fsp | rsp;			// bit 2k: a base that is not plain A C G T; bit 2k+1: an N
 	const unsigned isn = sp >> 1;
 	odd = (valid & sp & ~isn) != 0;
-	unsigned packed = (unsigned) __popc(valid & isn) | ((unsigned) __popc(valid & same & ~isn) << 10);	// each count <= 450 < 1024
+	return (unsigned) __popc(valid & isn) | ((unsigned) __popc(valid & same & ~isn) << 10);	// each count <= 450 < 1024
+}
+
+template <int ALGO, int ROWS>
+__device__ __forceinline__ double score_sb_codes(const PamdKernelParams &P, const WaveLds &L, int flen, int rlen, int ov, bool active, int lane, bool &odd) {
+	const int c = lane & (16 * ROWS - 1);
+	unsigned packed = code_word_counts(L, flen, rlen, ov, 16 * c, active, odd);
 	// sum over the 16 lanes of the row (rotate-and-add inside the DPP row)
 	packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x128, 0xF, 0xF, false);	// row_ror:8
 	packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x124, 0xF, 0xF, false);	// row_ror:4
@@ -398,8 +402,93 @@ __device__ __forceinline__ double score_sb_codes(const PamdKernelParams &P, cons
 	if (ROWS == 2)
 		packed += (unsigned) __builtin_amdgcn_ds_swizzle((int) packed, 0x401F);	// the other row of the pair (lane ^ 16)
 	const int unknowns = (int) (packed & 1023u), matches = (int) (packed >> 10);
+	int lo_i = ov - flen;
+	lo_i = lo_i < 0 ? 0 : lo_i;
+	const int hi_i = ov < rlen ? ov : rlen;
 	const int walked = hi_i > lo_i ? hi_i - lo_i : 0;
-	return count_score<ALGO>(P, flen, rlen, ov, unknowns, matches, walked);
+	return count_score<ALGO>(P.qual_nn, P.sb_pmatch, P.sb_pmismatch, flen, rlen, ov, unknowns, matches, walked);
+}
+
+// ---- counting scorers with many candidates: one candidate per LANE -------------------------------------
+// Pairs that scan dozens to hundreds of overlaps (tandem repeats, unseeded pairs: 1.5 % of config 1, 249
+// candidates each) are scored 64 candidates at a time: every lane walks ITS candidate's overlap 16 positions
+// per step with the same whole-word arithmetic, so no cross-lane reduction is needed and a step costs what
+// one 4-candidate step costs above.
+struct ManyScan {
+	double best;
+	int bo, examined, done;
+};
+
+// Kept out of line on purpose: inlined into the pair loop it pushed the whole kernel over its register budget
+// (spills on the common path); as a call it only costs the 1.5 % of pairs that take it.
+template <int ALGO>
+__device__ __attribute__((noinline, cold)) ManyScan scan_many_counting(const uint32_t *fc, const uint32_t *rc, const uint32_t *fn, const uint32_t *rn, uint16_t *cand, unsigned mybits, int minov, int flen, int rlen, double qual_nn, double pmatch, double pmismatch, double best, int lane) {
+	WaveLds L;
+	L.fc = const_cast<uint32_t *>(fc);
+	L.rc = const_cast<uint32_t *>(rc);
+	L.fn = const_cast<uint32_t *>(fn);
+	L.rn = const_cast<uint32_t *>(rn);
+	ManyScan out;
+	out.bo = -1;
+	out.done = 1;
+	// the candidates in ascending order, u16 each
+	int total = 0;
+	u64 words = __ballot(mybits != 0);
+	while (words != 0) {
+		const int w = __builtin_ctzll(words);
+		words &= words - 1;
+		const unsigned m = (unsigned) __builtin_amdgcn_readlane((int) mybits, w);
+		if (lane < 32 && ((m >> lane) & 1u))
+			cand[total + __popc(m & ((1u << lane) - 1u))] = (uint16_t) (w * 32 + lane + minov);
+		total += __popc(m);
+	}
+	wave_sync();
+	for (int c0 = 0; c0 < total; c0 += 64) {
+		const bool have = c0 + lane < total;
+		const int last = total - c0 > 64 ? 63 : total - c0 - 1;	// the lane that holds the batch's largest overlap
+		const int ov = (int) cand[have ? c0 + lane : c0 + last];
+		int lo_i = ov - flen;
+		lo_i = lo_i < 0 ? 0 : lo_i;
+		const int hi_i = ov < rlen ? ov : rlen;
+		const int first_i = __builtin_amdgcn_readfirstlane(lo_i) & ~15;	// candidates ascend: lane 0 starts lowest
+		const int end_i = __builtin_amdgcn_readlane(hi_i, last);
+		unsigned packed = 0;
+		bool any_odd = false;
+		for (int i0 = first_i; i0 < end_i; i0 += 16) {
+			bool o;
+			packed += code_word_counts(L, flen, rlen, ov, i0, have, o);
+			any_odd |= o;
+		}
+		if (__ballot(any_odd && have) != 0) {
+			out.done = 0;	// an IUPAC ambiguity code in a compared range: the caller scans this pair step by step
+			break;
+		}
+		const int unknowns = (int) (packed & 1023u), matches = (int) (packed >> 10);
+		const int walked = hi_i > lo_i ? hi_i - lo_i : 0;
+		double pr = count_score<ALGO>(qual_nn, pmatch, pmismatch, flen, rlen, ov, unknowns, matches, walked);
+		// first maximum of this batch: larger score wins, equal scores -> smaller overlap
+		int bov = have ? ov : 0x7FFFFFFF;
+		if (!have)
+			pr = -__builtin_inf();
+		for (int o = 32; o > 0; o >>= 1) {
+			const double opr = __shfl_xor(pr, o);
+			const int oov = __shfl_xor(bov, o);
+			if (opr > pr || (opr == pr && oov < bov)) {
+				pr = opr;
+				bov = oov;
+			}
+		}
+		pr = uni_f64(pr);
+		bov = uni(bov);
+		if (pr > best) {	// batches are in ascending overlap order, strict > keeps the earlier one
+			best = pr;
+			out.bo = bov;
+		}
+	}
+	wave_sync();
+	out.best = best;
+	out.examined = total;
+	return out;
 }
 
 // ---- pear / rdp_mle: the per-base terms of one candidate, in L.ps[0..ov) ---------------------------
@@ -495,7 +584,7 @@ __device__ __forceinline__ double score_overlap(const PamdKernelParams &P, const
 			matches += __popcll(__ballot(ina && !n0 && m0)) + __popcll(__ballot(inb && !n1 && m1));
 			mismatches += __popcll(__ballot(ina && !n0 && !m0)) + __popcll(__ballot(inb && !n1 && !m1));
 		}
-		return count_score<ALGO>(P, flen, rlen, ov, unknowns, matches, unknowns + matches + mismatches);
+		return count_score<ALGO>(P.qual_nn, P.sb_pmatch, P.sb_pmismatch, flen, rlen, ov, unknowns, matches, unknowns + matches + mismatches);
 	} else {
 		// algo_pear.c:32-59 / algo_rdp_mle.c:43-74: a sequential f64 sum over i = 0..ov-1.
 		// Lanes produce the terms, lane 0 adds them in order.
@@ -718,13 +807,148 @@ __device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsi
 	wave_sync();
 }
 
+// ---- fast-sums finish, 64 pairs at a time -----------------------------------------------------------
+// What is left to do for a pair once its row is written -- the f64 division of the quality sum, LOWQ,
+// the check modules, the 48-byte record, the counters -- is wave-uniform work: done per pair it occupies a
+// whole wave for a few hundred instructions with one useful lane.  Instead the pair's scalars are dropped
+// into lane `slot` of twelve registers (one v_cndmask each), and every 64 pairs all lanes finish their
+// pair at once.  Rows of pairs that turn out LOWQ / rejected stay in the arena as holes, as in exact mode.
+struct Pend64 {
+	unsigned off_lo, off_hi;	// row offset in seq_nt / seq_p (~0 = none)
+	unsigned q_lo, q_hi;		// the any-order quality SUM (or, flagged, the finished quality)
+	unsigned b_lo, b_hi;		// estimated_overlap_probability
+	unsigned len_bo;		// seq_len | overlap << 16
+	unsigned ex_mm;			// examined | mismatches << 16
+	unsigned dg_fo;			// degenerates | forward offset << 16
+	unsigned ro_st;			// reverse offset | status << 16 | slow << 24 | "q is final" << 25
+	unsigned div_ph;		// the divisor len (assembler.c:244) | smallest phred << 16
+	unsigned a_novl;		// forward-only bases | overlap bases << 16 (for the exact redo of the three sums)
+};
+
+__device__ __forceinline__ unsigned put_lane(unsigned reg, unsigned value, bool mine) {
+	return mine ? value : reg;	// one v_cndmask: the compare is shared by the twelve fields
+}
+
+__device__ __forceinline__ void park64(Pend64 &pd, int slot_idx, const PendRec &rec, int status, double q, bool q_final) {
+	const bool slot = (int) (threadIdx.x & 63u) == slot_idx;
+	union {
+		double d;
+		unsigned u[2];
+	} qq, bb;
+	qq.d = q;
+	bb.d = rec.best;
+	pd.off_lo = put_lane(pd.off_lo, (unsigned) rec.off, slot);
+	pd.off_hi = put_lane(pd.off_hi, (unsigned) (rec.off >> 32), slot);
+	pd.q_lo = put_lane(pd.q_lo, qq.u[0], slot);
+	pd.q_hi = put_lane(pd.q_hi, qq.u[1], slot);
+	pd.b_lo = put_lane(pd.b_lo, bb.u[0], slot);
+	pd.b_hi = put_lane(pd.b_hi, bb.u[1], slot);
+	pd.len_bo = put_lane(pd.len_bo, (unsigned) rec.seqlen | ((unsigned) rec.bo << 16), slot);
+	pd.ex_mm = put_lane(pd.ex_mm, (unsigned) rec.examined | ((unsigned) rec.mism << 16), slot);
+	pd.dg_fo = put_lane(pd.dg_fo, (unsigned) rec.degen | ((unsigned) rec.fo << 16), slot);
+	pd.ro_st = put_lane(pd.ro_st, (unsigned) rec.ro | ((unsigned) status << 16) | ((unsigned) (rec.slow != 0) << 24) | ((unsigned) q_final << 25), slot);
+	pd.div_ph = put_lane(pd.div_ph, (unsigned) rec.len | ((unsigned) rec.phmin << 16), slot);
+	pd.a_novl = put_lane(pd.a_novl, (unsigned) rec.A | ((unsigned) rec.novl << 16), slot);
+}
+
+// lane s finishes the wave's s-th parked pair: pair index first_pair + s * pair_step
+__device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64 &pd, int npend, u64 first_pair, u64 pair_step, int lane) {
+	int status = -1, reject = -1;
+	bool slow = false;
+	if (lane < npend) {
+		const u64 pair = first_pair + (u64) lane * pair_step;
+		const u64 row = (u64) pd.off_lo | ((u64) pd.off_hi << 32);
+		union {
+			double d;
+			unsigned u[2];
+		} q, e;
+		q.u[0] = pd.q_lo;
+		q.u[1] = pd.q_hi;
+		e.u[0] = pd.b_lo;
+		e.u[1] = pd.b_hi;
+		status = (int) ((pd.ro_st >> 16) & 0xFFu);
+		slow = ((pd.ro_st >> 24) & 1u) != 0;
+		const bool q_final = ((pd.ro_st >> 25) & 1u) != 0;
+		const int seqlen = (int) (pd.len_bo & 0xFFFFu), bo = (int) (pd.len_bo >> 16);
+		double quality = 0.0;
+		u64 off = ~0ull;
+		if (status == PAMD_ST_OK) {
+			if (row == ~0ull)
+				atomicAdd(P.error_flag, 1ull);	// the output arena was too small for this row
+			const double len = (double) (pd.div_ph & 0xFFFFu);
+			quality = q_final ? q.d : q.d / len;	// assembler.c:244
+			if (!q_final && fabs(quality - P.threshold) <= 1e-9 && row != ~0ull) {
+				// too close to the LOWQ threshold for an any-order sum: the three sums again, in the
+				// reference's order, from the row (this wave wrote it; its stores are retired first)
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				const int A = (int) (pd.a_novl & 0xFFFFu), novl = (int) (pd.a_novl >> 16);
+				const double *p = P.seq_p + row;
+				double f = 0.0, r = 0.0, o = 0.0;
+				for (int j = 0; j < A; j++)
+					f += p[j];
+				for (int j = A + novl; j < seqlen; j++)
+					r += p[j];
+				for (int j = A; j < A + novl; j++)
+					o += p[j];
+				quality = (f + r + o) / len;
+			}
+			if (quality < P.threshold) {	// assembler.c:334-338
+				status = PAMD_ST_LOWQ;
+			} else {
+				const int phmin = (int) (pd.div_ph >> 16);
+				for (int mi = 0; mi < P.n_modules && reject < 0; mi++) {	// module.c:124-136
+					const PamdModule md = P.modules[mi];
+					if (md.kind == 1) {	// plugin_min_phred.c:8-22
+						if (phmin < md.phred)
+							reject = mi;
+					} else if (md.kind == 2) {	// plugin_min_overlapbits.c:17-23
+						if (!(md.nats <= e.d))
+							reject = mi;
+					}
+				}
+				if (reject >= 0)
+					status = PAMD_ST_REJECT;
+				else
+					off = row;
+			}
+		}
+		q.d = quality;
+		uint4 *dst = reinterpret_cast<uint4 *>(&P.results[pair]);
+		dst[0] = make_uint4(q.u[0], q.u[1], e.u[0], e.u[1]);
+		dst[1] = make_uint4((unsigned) off, (unsigned) (off >> 32), pd.len_bo, pd.ex_mm);
+		dst[2] = make_uint4(pd.dg_fo, (pd.ro_st & 0xFFFFu) | ((unsigned) status << 16) | (((unsigned) reject & 0xFFu) << 24), slow ? 1u : 0u, 0u);
+		if (status == PAMD_ST_OK)
+			atomicAdd(&lctr[PAMD_CTR_OVERLAP0 + bo], 1u);
+		else if (status == PAMD_ST_REJECT)
+			atomicAdd(&lctr[PAMD_CTR_REJECTED0 + reject], 1u);
+	}
+	// workgroup-local counters (assembler.h:59-67,75): one LDS atomic per status per group
+	const int ctr_of[6] = { PAMD_CTR_OK, PAMD_CTR_BADR, PAMD_CTR_NOFP, PAMD_CTR_NORP, PAMD_CTR_NOALGN, PAMD_CTR_LOWQ };
+#pragma unroll
+	for (int st = 0; st < 6; st++) {
+		const int c = __popcll(__ballot(status == st));
+		if (c != 0 && lane == 0)
+			atomicAdd(&lctr[ctr_of[st]], (unsigned) c);
+	}
+	const int nslow = __popcll(__ballot(slow));
+	if (lane == 0) {
+		atomicAdd(&lctr[PAMD_CTR_COUNT], (unsigned) npend);
+		if (nslow)
+			atomicAdd(&lctr[PAMD_CTR_SLOW], (unsigned) nslow);
+	}
+}
+
 // quality from the any-order sum (|error| ~1e-12); the LOWQ verdict is the only consumer that could notice,
 // so within 1e-9 of the threshold (or always, for `-a` in exact-sums mode, which has no group finish) the
 // three sums are redone in reference order from the staged row (assembler.c:171,226,236,244)
-__device__ __forceinline__ double fast_quality(const WaveLds &L, double qacc, double threshold, int len, int seqlen, int A, int novl, bool always_exact, int lane) {
+__device__ __forceinline__ double quality_sum(double qacc) {	// the any-order sum over the wave
 	for (int o = 32; o > 0; o >>= 1)
 		qacc += __shfl_xor(qacc, o);
-	double quality = uni_f64(qacc) / (double) len;
+	return uni_f64(qacc);
+}
+
+__device__ __forceinline__ double fast_quality(const WaveLds &L, double qacc, double threshold, int len, int seqlen, int A, int novl, bool always_exact, int lane) {
+	double quality = quality_sum(qacc) / (double) len;
 	if (always_exact || fabs(quality - threshold) <= 1e-9) {
 		wave_sync();
 		double acc = 0.0;
@@ -754,7 +978,7 @@ struct Carry {
 
 // ---- one pair: everything up to its parked record ----------------------------------------------
 template <int ALGO, bool PHRED, int BPL, bool EXACT, bool POST>
-__device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, unsigned *lctr, const WaveLds &L, WaveArena &arena, PendRec *slot_rec, int slot_idx, unsigned wave_gid, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt
+__device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, unsigned *lctr, const WaveLds &L, WaveArena &arena, PendRec *slot_rec, Pend64 &pd, int slot_idx, unsigned wave_gid, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt
 #ifdef PAMD_PHASE_TIMING
 	, u64 *ph_acc
 #endif
@@ -763,7 +987,6 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 	PH_DECL;
 	bool rotated = false;
 	double quality_fast = 0.0;
-	u64 row_need = 0;	// arena bases taken by this pair's row (compact mode), given back if it is rejected
 	const int minov = P.minoverlap;
 	const unsigned hmask = P.hash_slots - 1u;
 	const unsigned hshift = P.hash_shift;
@@ -933,15 +1156,28 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		int examined = 0;
 		int score_parked = 0;	// pear / rdp_mle: the winner's terms sit in L.ps and must be parked
 		int ncand = 0;
-		if (!counting_algo<ALGO>()) {
+		constexpr int MANY = counting_algo<ALGO>() ? 24 : 4;	// from here on a candidate per lane pays
+		{
 			u64 nz = __ballot(mybits != 0);
-			while (nz != 0 && ncand <= 4) {	// only "more than four?" matters
+			while (nz != 0 && ncand <= MANY) {	// only "more than MANY?" matters
 				const int w = __builtin_ctzll(nz);
 				nz &= nz - 1;
 				ncand += __popc((unsigned) __builtin_amdgcn_readlane((int) mybits, w));
 			}
 		}
-		if (counting_algo<ALGO>()) {
+		bool per_lane_done = false;
+		if (counting_algo<ALGO>() && ncand > MANY) {
+			// Many candidates: 64 at a time, one per lane (scan_many_counting).  An IUPAC ambiguity code inside
+			// a compared range abandons that path: the pair is then scanned by the step path below.
+			const ManyScan ms = scan_many_counting<ALGO>(L.fc, L.rc, L.fn, L.rn, reinterpret_cast<uint16_t *>(L.ps), mybits, minov, flen, rlen, P.qual_nn, P.sb_pmatch, P.sb_pmismatch, best, lane);
+			if (ms.done) {
+				per_lane_done = true;
+				best = ms.best;
+				bo = ms.bo;
+				examined = ms.examined;
+			}
+		}
+		if (counting_algo<ALGO>() && !per_lane_done) {
 			// Candidates are scored PER_STEP at a time from the packed code streams, one candidate per
 			// DPP row (pair of rows for long reads), and judged in ascending order.
 			constexpr int ROWS = BPL == 4 ? 1 : 2;
@@ -1020,7 +1256,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			}
 			examined = total;
 			wave_sync();
-		} else {
+		} else if (!counting_algo<ALGO>()) {
 			// Few candidates.  simple_bayesian scores are exact integers-in-a-formula.  pear / rdp_mle
 			// scores are ordered f64 chains, ~150 dependent adds each: the winner is DECIDED from
 			// any-order sums (error < 1e-9) whenever every comparison is clearer than 1e-6, and its exact
@@ -1389,9 +1625,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		}
 		rec.mism = mism;
 		rec.degen = degen;
-		row_need = P.seq_stride == 0 && store ? need : 0;
 		if (!EXACT && !post)
-			quality_fast = fast_quality(L, qacc, P.threshold, len, seqlen, A, novl, false, lane);
+			quality_fast = quality_sum(qacc);	// divided by len in finish64()
 	} while (0);
 	if (!rotated) {
 		cur = nxt;
@@ -1404,56 +1639,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			*slot_rec = rec;	// park it; finish_group() does the rest
 		return;
 	}
-	// fast sums: nothing is pending, finish the pair here (same steps as finish_group's tail)
-	int reject = -1;
-	u64 off = ~0ull;
-	if (status == PAMD_ST_OK) {
-		if (rec.off == ~0ull && lane == 0)
-			atomicAdd(P.error_flag, 1ull);
-		if (quality_fast < P.threshold) {	// assembler.c:334-338
-			status = PAMD_ST_LOWQ;
-		} else {
-			for (int mi = 0; mi < P.n_modules && reject < 0; mi++) {	// module.c:124-136
-				const PamdModule md = P.modules[mi];
-				if (md.kind == 1) {
-					if (rec.phmin < md.phred)
-						reject = mi;
-				} else if (md.kind == 2) {
-					if (!(md.nats <= rec.best))
-						reject = mi;
-				}
-			}
-			if (reject >= 0)
-				status = PAMD_ST_REJECT;
-			else
-				off = rec.off;
-		}
-		if (status != PAMD_ST_OK)
-			arena.cur -= row_need;	// the row of a rejected pair is the arena's newest piece: hand it back
-	}
-	if (lane == 0) {
-		union {
-			double d;
-			unsigned u[2];
-		} q, e;
-		q.d = quality_fast;
-		e.d = rec.best;
-		uint4 *dst = reinterpret_cast<uint4 *>(&P.results[pair]);
-		dst[0] = make_uint4(q.u[0], q.u[1], e.u[0], e.u[1]);
-		dst[1] = make_uint4((unsigned) off, (unsigned) (off >> 32), (unsigned) rec.seqlen | ((unsigned) rec.bo << 16), (unsigned) rec.examined | ((unsigned) rec.mism << 16));
-		dst[2] = make_uint4((unsigned) rec.degen | ((unsigned) rec.fo << 16), (unsigned) rec.ro | ((unsigned) status << 16) | (((unsigned) reject & 0xFFu) << 24), (unsigned) rec.slow, 0u);
-		atomicAdd(&lctr[PAMD_CTR_COUNT], 1u);
-		if (rec.slow)
-			atomicAdd(&lctr[PAMD_CTR_SLOW], 1u);
-		const int ctr_of[6] = { PAMD_CTR_OK, PAMD_CTR_BADR, PAMD_CTR_NOFP, PAMD_CTR_NORP, PAMD_CTR_NOALGN, PAMD_CTR_LOWQ };
-		if (status == PAMD_ST_REJECT) {
-			atomicAdd(&lctr[PAMD_CTR_REJECTED0 + reject], 1u);
-		} else {
-			atomicAdd(&lctr[ctr_of[status]], 1u);
-			if (status == PAMD_ST_OK)
-				atomicAdd(&lctr[PAMD_CTR_OVERLAP0 + rec.bo], 1u);
-		}
-	}
+	// fast sums: the pair's scalars wait in lane `slot_idx` of the wave's pending registers (finish64)
+	park64(pd, slot_idx, rec, status, quality_fast, POST);
 }
 
 template <int ALGO, bool PHRED, int BPL, bool EXACT, bool POST>
@@ -1515,6 +1702,8 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	// are known-ready on both incoming edges
 	asm volatile("" : "+v"(cur.flen_v), "+v"(cur.rlen_v), "+v"(cur.f.x), "+v"(cur.f.y), "+v"(cur.f.z), "+v"(cur.f.w), "+v"(cur.r.x), "+v"(cur.r.y), "+v"(cur.r.z), "+v"(cur.r.w));
 	int npend = 0;
+	Pend64 pd = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+	u64 group_first = pair;	// fast sums: the pair parked in lane 0 of the pending registers
 	while (pair < P.n_pairs) {
 		const u64 next = pair + total_waves;
 		q = next < P.n_pairs ? next : last;
@@ -1525,12 +1714,16 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		nxt.r = load_read<BPL>(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
 #ifdef PAMD_PHASE_TIMING
-		assemble_pair<ALGO, PHRED, BPL, EXACT, POST>(P, ltab, lprimers, lctr, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt, ph_acc);
+		assemble_pair<ALGO, PHRED, BPL, EXACT, POST>(P, ltab, lprimers, lctr, L, arena, &pend[EXACT ? npend : 0], pd, npend, wave_gid, pair, lane, flen, rlen, cur, nxt, ph_acc);
 #else
-		assemble_pair<ALGO, PHRED, BPL, EXACT, POST>(P, ltab, lprimers, lctr, L, arena, &pend[npend], npend, wave_gid, pair, lane, flen, rlen, cur, nxt);
+		assemble_pair<ALGO, PHRED, BPL, EXACT, POST>(P, ltab, lprimers, lctr, L, arena, &pend[EXACT ? npend : 0], pd, npend, wave_gid, pair, lane, flen, rlen, cur, nxt);
 #endif
-		if (EXACT)
-			npend++;
+		npend++;
+		if (!EXACT && npend == 64) {
+			finish64(P, lctr, pd, npend, group_first, total_waves, lane);
+			npend = 0;
+			group_first = next;
+		}
 		if (EXACT && npend == GROUP) {
 #ifdef PAMD_PHASE_TIMING
 			const u64 t0 = __builtin_amdgcn_s_memtime();
@@ -1543,8 +1736,10 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		}
 		pair = next;
 	}
-	if (npend > 0)
+	if (EXACT && npend > 0)
 		finish_group<ALGO>(P, ltab, lctr, pend, npend, wave_gid, lane);
+	if (!EXACT && npend > 0)
+		finish64(P, lctr, pd, npend, group_first, total_waves, lane);
 #ifdef PAMD_PHASE_TIMING
 	ph_acc[9] = __builtin_amdgcn_s_memtime() - ph_begin;
 	if (lane == 0 && P.phase_cycles != nullptr)
