@@ -1166,7 +1166,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			}
 		}
 		bool per_lane_done = false;
-		if (counting_algo<ALGO>() && ncand > MANY) {
+		if (counting_algo<ALGO>() && !EXACT && ncand > MANY) {
 			// Many candidates: 64 at a time, one per lane (scan_many_counting).  An IUPAC ambiguity code inside
 			// a compared range abandons that path: the pair is then scanned by the step path below.
 			const ManyScan ms = scan_many_counting<ALGO>(L.fc, L.rc, L.fn, L.rn, reinterpret_cast<uint16_t *>(L.ps), mybits, minov, flen, rlen, P.qual_nn, P.sb_pmatch, P.sb_pmismatch, best, lane);
@@ -1408,10 +1408,6 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		uint8_t *row_nt = P.seq_nt + (store ? off : 0);
 		double *row_p = P.seq_p + (store ? off : 0);
 		constexpr bool want_phred = PHRED;	// a min_phred module is loaded (separate kernel instantiation)
-		// a register copy: selecting between "load from the kernel arguments" and "load from LDS"
-		// makes the compiler emit one FLAT load, whose wait also waits for every store in flight
-		double qual_nn = P.qual_nn;
-		asm volatile("" : "+v"(qual_nn));
 		int mism = 0, degen = 0, phmin = 127;
 		double qacc = 0.0;	// fast sums: this lane's share of the quality sum, any order
 		bool low_p = false;
@@ -1456,60 +1452,29 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const bool match = (a & b) != 0;
 				ismm = !match;
 				const bool fmask = fi >= uf, rmask = ri >= ur;	// B-cliff
-				double q;
-				if (fmask && rmask) {
-					q = qual_nn;
-				} else if (fmask) {
-					q = ltab[PAMD_LT_SCORE + clampq(rq)];
-				} else if (rmask) {
-					q = ltab[PAMD_LT_SCORE + clampq(fq)];
-				} else if (ALGO == PAMD_ALGO_EA_UTIL) {	// algo_ea_util.c:58-67
-					q = ltab[PAMD_LT_SCORE + (fq > rq ? clampq(fq) : clampq(rq))];
+				// one table read, its index chosen without a branch (slot 47 of the score block holds qual_nn)
+				const int cf = clampq(fq), cr = clampq(rq);
+				int qi;
+				if (ALGO == PAMD_ALGO_EA_UTIL) {	// algo_ea_util.c:58-67
+					qi = PAMD_LT_SCORE + (fq > rq ? cf : cr);
 				} else if (ALGO == PAMD_ALGO_FLASH) {	// algo_flash.c:63-80
-					int sc;
-					if (match) {
-						sc = fq > rq ? clampq(fq) : clampq(rq);
-					} else {
-						sc = clampq(fq) - clampq(rq);
-						sc = sc < 0 ? -sc : sc;
-						sc = sc < 2 ? 2 : sc;
-					}
-					q = ltab[PAMD_LT_SCORE + sc];
+					int sc = cf - cr;
+					sc = sc < 0 ? -sc : sc;
+					sc = sc < 2 ? 2 : sc;
+					qi = PAMD_LT_SCORE + (match ? (fq > rq ? cf : cr) : sc);
 				} else if (ALGO == PAMD_ALGO_RDP_MLE) {	// algo_rdp_mle.c:29-41
-					if (match) {
-						const int mx = fq >= rq ? fq : rq;
-						q = ltab[PAMD_LT_SCORE + clampq(mx)];
-					} else {
-						q = ltab[PAMD_LT_C + clampq(fq) * PAMD_NQ + clampq(rq)];
-					}
+					qi = match ? PAMD_LT_SCORE + clampq(fq >= rq ? fq : rq) : PAMD_LT_C + cf * PAMD_NQ + cr;
 				} else {	// algo_simple_bayes.c:68-75, algo_pear.c:61-68, algo_uparse.c:68-75, algo_stitch.c:59-67
-					q = ltab[(match ? PAMD_LT_A : PAMD_LT_B) + clampq(fq) * PAMD_NQ + clampq(rq)];
+					qi = (match ? PAMD_LT_A : PAMD_LT_B) + cf * PAMD_NQ + cr;
 				}
+				qi = rmask ? PAMD_LT_SCORE + cf : qi;	// B-cliff (assembler.c:192-207)
+				qi = fmask ? PAMD_LT_SCORE + (rmask ? 47 : cr) : qi;
+				const double q = ltab[qi];
 				nt = match ? (a & b) : (fq < rq ? b : a);	// assembler.c:212-220
 				L.nts[A + i] = (uint8_t) nt;
 				L.ps[A + i] = q;
-				if (post) {	// the table entry q was read from (slot 47 of the score block stands for qual_nn)
-					int qi;
-					if (fmask && rmask) {
-						qi = PAMD_LT_SCORE + 47;
-					} else if (fmask) {
-						qi = PAMD_LT_SCORE + clampq(rq);
-					} else if (rmask) {
-						qi = PAMD_LT_SCORE + clampq(fq);
-					} else if (ALGO == PAMD_ALGO_EA_UTIL) {
-						qi = PAMD_LT_SCORE + (fq > rq ? clampq(fq) : clampq(rq));
-					} else if (ALGO == PAMD_ALGO_FLASH) {
-						int sc = clampq(fq) - clampq(rq);
-						sc = sc < 0 ? -sc : sc;
-						sc = sc < 2 ? 2 : sc;
-						qi = PAMD_LT_SCORE + (match ? (fq > rq ? clampq(fq) : clampq(rq)) : sc);
-					} else if (ALGO == PAMD_ALGO_RDP_MLE) {
-						qi = match ? PAMD_LT_SCORE + clampq(fq >= rq ? fq : rq) : PAMD_LT_C + clampq(fq) * PAMD_NQ + clampq(rq);
-					} else {
-						qi = (match ? PAMD_LT_A : PAMD_LT_B) + clampq(fq) * PAMD_NQ + clampq(rq);
-					}
+				if (post)
 					L.pidx[A + i] = (uint16_t) qi;
-				}
 				if (!EXACT)
 					qacc += q;
 				// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
