@@ -142,3 +142,20 @@ def test_io_product_has_no_cpu_fallback():
         textio.FastqParser(0)
     with pytest.raises(_lib.PamdError):
         textio.Formatter(0)
+
+
+def test_io_oracle_matches_golden_fixture():
+    """tests/golden/io/mixed.npz (committed with its generator): the I/O oracle still produces the same
+    rows, header fields and FASTA / FASTQ bytes from the same text."""
+    g = np.load(os.path.join(GOLDEN, "io", "mixed.npz"))
+    ft, rt = g["fwd_text"].tobytes(), g["rev_text"].tobytes()
+    pf, pr, pfl, prl, ids, st = po.fastq_read(ft, rt, stride=456)
+    assert [st.n_pairs, st.n_records, st.n_dropped, st.stop_code, st.seen_under_64] == g["status"].tolist()
+    assert np.array_equal(pf, g["fwd"]) and np.array_equal(pr, g["rev"])
+    assert np.array_equal(pfl, g["flen"]) and np.array_equal(prl, g["rlen"])
+    assert [po.seqid_str(ids[i]) for i in range(st.n_pairs)] == [bytes(x) for x in g["names"]]
+    res, nt, p, _ = po.assemble_batch(po.make_config("simple_bayesian"), pf, pr, pfl, prl)
+    assert np.array_equal(res["status"] == 0, g["ok"])
+    fasta = b"".join(po.output_fasta(ids[i], float(res["quality"][i]), nt[i, :int(res["seq_len"][i])])
+                     for i in range(st.n_pairs) if res["status"][i] == 0)
+    assert fasta == g["fasta"].tobytes()

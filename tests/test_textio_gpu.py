@@ -83,40 +83,9 @@ def test_parse_edge_cases(io, case):
     check_parse(textio, ft, rt, qualmin=qualmin, policy=policy)
 
 
-def _random_fastq(n, seed):
-    """Ragged reads, every header format, IUPAC letters, odd qualities; one text pair."""
-    rng = np.random.default_rng(seed)
-    letters = np.frombuffer(b"ACGTACGTACGTACGTNRYKMSWBDHVUXacgtn", dtype=np.uint8)
-    fo, ro = [], []
-    for i in range(n):
-        kind = i % 5
-        x, y = int(rng.integers(0, 99999)), int(rng.integers(0, 99999))
-        tag = "".join(rng.choice(list("ACGT"), size=int(rng.integers(0, 9))))
-        if kind == 0:
-            hf, hr = f"@M0{i % 7}:{i % 90}:FC-{i % 13}:{1 + i % 8}:{1101 + i % 50}:{x}:{y} 1:N:0:{tag}", None
-            hr = hf.replace(" 1:N", " 2:Y")
-        elif kind == 1:
-            hf = f"@HWUSI-EAS100R:{1 + i % 8}:{i % 120}:{x}:{y}#{tag}/1"
-            hr = hf[:-1] + "2"
-        elif kind == 2:
-            hf = f"@MS{i % 3}:18:000-A1{i % 9}:{1 + i % 8}:{1101 + i % 50}:{x}:{y}#{tag}/1"
-            hr = hf[:-1] + "2"
-        elif kind == 3:
-            hf = hr = f"@SRR{i % 1000:06d}.{i} some comment {x}"
-        else:
-            hf = hr = f"@ERR{i % 1000}.{i} {y}/1"
-        lf, lr = (0 if i % 97 == 5 else int(rng.integers(1, 451))), int(rng.integers(0, 451))
-        for h, ln, dst in ((hf, lf, fo), (hr, lr, ro)):
-            seq = letters[rng.integers(0, len(letters), size=ln)].tobytes()
-            qual = rng.integers(33, 127, size=ln).astype(np.uint8).tobytes()
-            eol = b"\r\n" if i % 11 == 0 else b"\n"
-            dst.append(h.encode() + eol + seq + eol + b"+" + (h[1:].encode() if i % 4 == 0 else b"") + eol + qual + eol)
-    return b"".join(fo), b"".join(ro)
-
-
 def test_parse_mixed_formats_ragged(io):
     pa, textio, parser, _ = io
-    ft, rt = _random_fastq(6000, 5)
+    ft, rt = util.random_fastq(6000, 5)
     out, st = check_parse(textio, ft, rt, parser=parser)
     assert st.n_good == 6000 and st.n_dropped > 0
 
@@ -124,7 +93,7 @@ def test_parse_mixed_formats_ragged(io):
 def test_parse_in_chunks(io):
     """Cutting the texts anywhere and resuming at fwd_consumed / rev_consumed gives the same rows."""
     pa, textio, parser, _ = io
-    ft, rt = _random_fastq(3000, 9)
+    ft, rt = util.random_fastq(3000, 9)
     whole, wst = check_parse(textio, ft, rt, parser=parser)
     rows_f, rows_r, lens = [], [], []
     fpos = rpos = 0
@@ -182,7 +151,7 @@ def test_format_matches_oracle(io, fmt, source):
         ft, rt = synth.render_fastq(f, r, fl, rl, tag="ACGT")
         stride = spec.row_stride()
     else:
-        ft, rt = _random_fastq(3000, 21)
+        ft, rt = util.random_fastq(3000, 21)
         stride = 456
     ftd = textio.text_to_device(ft)
     rows, st = parser.parse(ftd, textio.text_to_device(rt), ft.count(b"\n") // 4 + 1, stride)
@@ -230,3 +199,30 @@ def test_format_with_rejections_and_fastq_phred_range(io):
                     for i in range(3000) if ores["status"][i] == 0)
     assert (ores["status"] == 6).sum() > 0
     assert bytes(text) == want
+
+
+def test_io_golden_fixture(io):
+    """The committed fixture tests/golden/io/mixed.npz: text -> rows -> assembly -> FASTA / FASTQ on the device
+    against the stored bytes."""
+    import os
+    pa, textio, parser, formatter = io
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "io", "mixed.npz"))
+    ft, rt = g["fwd_text"].tobytes(), g["rev_text"].tobytes()
+    ftd = textio.text_to_device(ft)
+    rows, st = parser.parse(ftd, textio.text_to_device(rt), 400, 456)
+    n_pairs, n_records, n_dropped, stop, under64 = g["status"].tolist()
+    assert (int(st.n_good), int(st.n_dropped), int(st.stop_code), int(st.seen_under_64)) == (n_records, n_dropped, stop, under64)
+    ids = rows["ids"].cpu().numpy().view(textio.SEQID_DTYPE).reshape(-1)[:n_records]
+    keep = np.nonzero(ids["flag"] == 0)[0]
+    assert np.array_equal(rows["fwd"].cpu().numpy()[:n_records][keep], g["fwd"])
+    assert np.array_equal(rows["rev"].cpu().numpy()[:n_records][keep], g["rev"])
+    assert np.array_equal(rows["flen"].cpu().numpy().view(np.uint16)[:n_records][keep], g["flen"])
+    for j, k in enumerate(keep):
+        f = textio.seqid_fields(ids[k], ft)
+        assert ("%s:%s:%s:%d:%d:%d:%d:%s" % f).encode("latin1") == bytes(g["names"][j])
+    asm, b = _assemble(pa, rows, n_records)
+    for which, key in ((textio.OUT_FASTA, "fasta"), (textio.OUT_FASTQ, "fastq")):
+        out, nbytes, fixups = formatter.format(b, rows["ids"], ftd, which)
+        text = bytearray(out[:nbytes].cpu().numpy().tobytes())
+        textio.apply_fixups(text, fixups, b.results_numpy()["quality"])
+        assert bytes(text) == g[key].tobytes(), key

@@ -201,3 +201,34 @@ def fastq_cases():
     add("rev_shorter", good[0] + good[0], b"", "END")
     add("unterminated_last_line", _rec(ok17[0], s, q)[:-1], _rec(ok17[1], s, q)[:-1], "EOF")
     return cases
+
+
+def random_fastq(n, seed):
+    """Ragged reads, every header format, IUPAC letters, odd qualities; one text pair."""
+    rng = np.random.default_rng(seed)
+    letters = np.frombuffer(b"ACGTACGTACGTACGTNRYKMSWBDHVUXacgtn", dtype=np.uint8)
+    fo, ro = [], []
+    for i in range(n):
+        kind = i % 5
+        x, y = int(rng.integers(0, 99999)), int(rng.integers(0, 99999))
+        tag = "".join(rng.choice(list("ACGT"), size=int(rng.integers(0, 9))))
+        if kind == 0:
+            hf, hr = f"@M0{i % 7}:{i % 90}:FC-{i % 13}:{1 + i % 8}:{1101 + i % 50}:{x}:{y} 1:N:0:{tag}", None
+            hr = hf.replace(" 1:N", " 2:Y")
+        elif kind == 1:
+            hf = f"@HWUSI-EAS100R:{1 + i % 8}:{i % 120}:{x}:{y}#{tag}/1"
+            hr = hf[:-1] + "2"
+        elif kind == 2:
+            hf = f"@MS{i % 3}:18:000-A1{i % 9}:{1 + i % 8}:{1101 + i % 50}:{x}:{y}#{tag}/1"
+            hr = hf[:-1] + "2"
+        elif kind == 3:
+            hf = hr = f"@SRR{i % 1000:06d}.{i} some comment {x}"
+        else:
+            hf = hr = f"@ERR{i % 1000}.{i} {y}/1"
+        lf, lr = (0 if i % 97 == 5 else int(rng.integers(1, 451))), int(rng.integers(0, 451))
+        for h, ln, dst in ((hf, lf, fo), (hr, lr, ro)):
+            seq = letters[rng.integers(0, len(letters), size=ln)].tobytes()
+            qual = rng.integers(33, 127, size=ln).astype(np.uint8).tobytes()
+            eol = b"\r\n" if i % 11 == 0 else b"\n"
+            dst.append(h.encode() + eol + seq + eol + b"+" + (h[1:].encode() if i % 4 == 0 else b"") + eol + qual + eol)
+    return b"".join(fo), b"".join(ro)
