@@ -46,15 +46,19 @@ def parse():
                          "(statuses, overlaps, merged bases, per-base log-p bit-identical; the two f64 scalars within 1e-9); "
                          "exact: the reference's summation order, every output bit-identical")
     ap.add_argument("--traffic-bytes", type=float, default=None, help="PMC-measured HBM bytes per launch (from profiles/)")
+    ap.add_argument("--algo", default=None, help="override the config's scorer (simple_bayesian, pear, rdp_mle, uparse, flash, ea_util, stitch): "
+                                                 "not a BASELINE.json configuration, for the per-scorer table of DESIGN.md")
+    ap.add_argument("--primers-after", action="store_true", help="`-a`: strip primers after assembly (config 2 has primers)")
     return ap.parse_args()
 
 
-def setup_assembler(pa, synth, cfg_index, device_index, exact_sums=True):
+def setup_assembler(pa, synth, cfg_index, device_index, exact_sums=True, algo=None, primers_after=False):
     asm = pa.Assembler(device_index)
     asm.set_exact_sums(exact_sums)
     spec = synth.config_spec(cfg_index)
     c = CONFIGS[cfg_index]
-    asm.set_algorithm(c["algo"])
+    asm.set_algorithm(algo or c["algo"])
+    asm.set_primers_after(primers_after)
     if cfg_index == 2:
         asm.set_forward_primer(synth.nt_codes(spec.fprimer))
         asm.set_reverse_primer(synth.nt_codes(spec.rprimer, complement=True))
@@ -64,14 +68,14 @@ def setup_assembler(pa, synth, cfg_index, device_index, exact_sums=True):
     return asm, spec
 
 
-def oracle_config(po, synth, cfg_index):
+def oracle_config(po, synth, cfg_index, algo=None, primers_after=False):
     spec = synth.config_spec(cfg_index)
     kw = {}
     if cfg_index == 2:
         kw = dict(fprimer=synth.nt_codes(spec.fprimer), rprimer=synth.nt_codes(spec.rprimer, complement=True))
     if cfg_index == 3:
         kw = dict(modules=[("min_phred", 2), ("min_overlapbits", 15)])
-    return po.make_config(CONFIGS[cfg_index]["algo"], **kw)
+    return po.make_config(algo or CONFIGS[cfg_index]["algo"], primers_after=primers_after, **kw)
 
 
 def main():
@@ -107,7 +111,7 @@ def main():
 
     cfg_index = args.config
     n = args.pairs or CONFIGS[cfg_index]["pairs"]
-    asm, spec = setup_assembler(pa, synth, cfg_index, local, exact_sums=args.sums == "exact")
+    asm, spec = setup_assembler(pa, synth, cfg_index, local, exact_sums=args.sums == "exact", algo=args.algo, primers_after=args.primers_after)
     L = spec.read_len
 
     # ---- calibrate the arena on the first pairs, then build the full shard in HBM ----
@@ -215,11 +219,12 @@ def main():
         "dtype": "u8+f64",
         "data": "synthetic",
         "config": {
-            "workload": CONFIGS[cfg_index]["name"],
+            "workload": CONFIGS[cfg_index]["name"] + (f" [scorer overridden: {args.algo}]" if args.algo else "") + (" [-a]" if args.primers_after else ""),
             "config_index": cfg_index,
             "pairs_per_gpu": n,
             "read_len": L,
-            "algorithm": CONFIGS[cfg_index]["algo"],
+            "algorithm": args.algo or CONFIGS[cfg_index]["algo"],
+            "primers_after": bool(args.primers_after),
             "sharding": f"{world} contiguous shard(s), one RCCL all-reduce of STAT counters per step" if world > 1 else "single GPU",
             "output": "compact arena, nt u8 + log-p f64 per merged base",
             "sums": ("reference order (all outputs bit-identical)" if args.sums == "exact" else
@@ -248,7 +253,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import pyoracle as po
         threads = len(os.sched_getaffinity(0))
-        ocfg = oracle_config(po, synth, cfg_index)
+        ocfg = oracle_config(po, synth, cfg_index, args.algo, args.primers_after)
         probe = 20000
         hf = batch.fwd[:probe].cpu().numpy()
         hr = batch.rev[:probe].cpu().numpy()
