@@ -1177,6 +1177,25 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				examined = ms.examined;
 			}
 		}
+		if (counting_algo<ALGO>() && ncand == 1) {
+			// The usual case, one seeded overlap: scored by one DPP row (pair of rows for long reads) without
+			// the candidate bookkeeping below.  An IUPAC ambiguity code in range falls through to it.
+			constexpr int ROWS1 = BPL == 4 ? 1 : 2;
+			const int w = __builtin_ctzll(__ballot(mybits != 0));
+			const unsigned m = (unsigned) __builtin_amdgcn_readlane((int) mybits, w);
+			const int ov = w * 32 + __builtin_ctz(m) + minov;
+			bool odd;
+			const double sc = score_sb_codes<ALGO, ROWS1>(P, L, flen, rlen, ov, lane < 16 * ROWS1, lane, odd);
+			if (__ballot(odd) == 0) {
+				const double pr = lane_f64(sc, 0);
+				if (pr > best) {
+					best = pr;
+					bo = ov;
+				}
+				examined = 1;
+				per_lane_done = true;
+			}
+		}
 		if (counting_algo<ALGO>() && !per_lane_done) {
 			// Candidates are scored PER_STEP at a time from the packed code streams, one candidate per
 			// DPP row (pair of rows for long reads), and judged in ascending order.
