@@ -281,7 +281,26 @@ __device__ int primer_offset_result(const PamdKernelParams &P, const WaveLds &L,
 		const int index = s + plen;
 		if (index <= len - 1) {
 			double acc = 0.0;
-			for (int x = 0; x < plen; x++) {	// the order offset.c:79-87 fills bucket s in
+			// the order offset.c:79-87 fills bucket s in (x ascending); the reads of eight steps -- the LDS
+			// ones and the table read of log(1 - exp(p)) -- are issued together, then added in order
+			int x = 0;
+			for (; x + 8 <= plen; x += 8) {
+				unsigned nt[8], pn[8];
+				double pp[8], np[8];
+#pragma unroll
+				for (int u = 0; u < 8; u++) {
+					const int at = reverse ? len - 1 - (s + x + u) : s + x + u;
+					nt[u] = L.nts[at];
+					pp[u] = L.ps[at];
+					np[u] = P.notp[L.pidx[at]];
+					pn[u] = primer[x + u];
+				}
+#pragma unroll
+				for (int u = 0; u < 8; u++)
+					if (pn[u] != NT_N)
+						acc += ((nt[u] & pn[u]) != 0) ? pp[u] : np[u];
+			}
+			for (; x < plen; x++) {
 				const unsigned pn = primer[x];
 				if (pn != NT_N) {
 					const int at = reverse ? len - 1 - (s + x) : s + x;
