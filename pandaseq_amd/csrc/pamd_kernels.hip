@@ -209,46 +209,66 @@ __device__ int primer_offset(const PamdKernelParams &P, const double *ltab, cons
 	// and exp is monotone, so we compare x (see DESIGN.md "exp in the primer scan").
 	double best = logdomain ? (double) plen * P.threshold : exp((double) plen * P.threshold);
 	int besti = 0;
+	// Pruning (zero penalty only): every term is a log-probability <= 0, so an alignment's partial sum only
+	// falls; once it is clearly below bound * (index + 1), where bound is the best value any lane has found,
+	// its final value cannot exceed bound and it can stop.  The wave leaves a block of 64 starts as soon as
+	// no lane can still win -- after the real primer has been seen (normally in the first block) that is
+	// after the first mismatching base or two instead of all `plen`.
+	double bound = best;
 	for (int base = 0; base + plen <= len - 1; base += 64) {
 		const int s = base + lane;
 		const int index = s + plen;
-		if (index <= len - 1) {
-			double acc = 0.0;
-			// same order as offset.c:79-87 (x ascending); the loads of eight steps are issued together
-			int x = 0;
-			for (; x + 8 <= plen; x += 8) {
-				unsigned e[8], pn[8];
-				double t[8];
+		const bool have = index <= len - 1;
+		const int ss = have ? s : 0;	// lanes past the end walk the first alignment and are ignored
+		const double floor_acc = bound * (double) (index + 1) - 1e-6;
+		double acc = 0.0;
+		// same order as offset.c:79-87 (x ascending); the loads of eight steps are issued together
+		int x = 0;
+		bool live = true;
+		for (; x + 8 <= plen && live; x += 8) {
+			unsigned e[8], pn[8];
+			double t[8];
 #pragma unroll
-				for (int u = 0; u < 8; u++) {
-					e[u] = S[s + x + u];
-					pn[u] = primer[x + u];
-				}
+			for (int u = 0; u < 8; u++) {
+				e[u] = S[ss + x + u];
+				pn[u] = primer[x + u];
+			}
 #pragma unroll
-				for (int u = 0; u < 8; u++) {
-					const int q = clampq(qual_of(e[u]));
-					t[u] = ltab[(((nt_of(e[u]) & pn[u]) != 0) ? PAMD_LT_SCORE : PAMD_LT_ERR) + q];
-				}
+			for (int u = 0; u < 8; u++) {
+				const int q = clampq(qual_of(e[u]));
+				t[u] = ltab[(((nt_of(e[u]) & pn[u]) != 0) ? PAMD_LT_SCORE : PAMD_LT_ERR) + q];
+			}
 #pragma unroll
-				for (int u = 0; u < 8; u++)
-					if (pn[u] != NT_N)
-						acc += t[u];
+			for (int u = 0; u < 8; u++)
+				if (pn[u] != NT_N)
+					acc += t[u];
+			live = !logdomain || __ballot(have && !(acc < floor_acc)) != 0;
+		}
+		if (!live)
+			continue;	// no start of this block can beat what has been found
+		for (; x < plen; x++) {
+			const unsigned pn = primer[x];
+			if (pn != NT_N) {
+				const unsigned e = S[ss + x];
+				const int q = clampq(qual_of(e));
+				acc += ((nt_of(e) & pn) != 0) ? ltab[PAMD_LT_SCORE + q] : ltab[PAMD_LT_ERR + q];
 			}
-			for (; x < plen; x++) {
-				const unsigned pn = primer[x];
-				if (pn != NT_N) {
-					const unsigned e = S[s + x];
-					const int q = clampq(qual_of(e));
-					acc += ((nt_of(e) & pn) != 0) ? ltab[PAMD_LT_SCORE + q] : ltab[PAMD_LT_ERR + q];
-				}
+		}
+		double v = acc / (double) (index + 1);
+		if (!logdomain)
+			v = exp(v) - (double) index * P.primer_penalty;
+		const bool better = have && v > best;	// strict: the earliest index wins ties (offset.c:74)
+		if (better) {
+			best = v;
+			besti = index + 1;
+		}
+		if (logdomain && __ballot(better) != 0) {
+			double m = besti != 0 ? best : bound;
+			for (int off = 32; off > 0; off >>= 1) {
+				const double o = __shfl_xor(m, off);
+				m = o > m ? o : m;
 			}
-			double v = acc / (double) (index + 1);
-			if (!logdomain)
-				v = exp(v) - (double) index * P.primer_penalty;
-			if (v > best) {	// strict: the earliest index wins ties (offset.c:74)
-				best = v;
-				besti = index + 1;
-			}
+			bound = uni_f64(m);
 		}
 	}
 	// first-maximum across lanes: larger value wins, equal values -> smaller index
