@@ -226,3 +226,46 @@ def test_io_golden_fixture(io):
         text = bytearray(out[:nbytes].cpu().numpy().tobytes())
         textio.apply_fixups(text, fixups, b.results_numpy()["quality"])
         assert bytes(text) == g[key].tobytes(), key
+
+
+def test_parse_max_pairs_and_resume(io):
+    """max_pairs smaller than the records present: exactly that many are parsed and fwd/rev_consumed point
+    at the next record, so a second call continues where the first stopped."""
+    pa, textio, parser, _ = io
+    ft, rt = util.random_fastq(500, 3)
+    whole, wst = check_parse(textio, ft, rt, parser=parser)
+    out1, st1 = parser.parse(textio.text_to_device(ft), textio.text_to_device(rt), 123, 456)
+    assert (int(st1.n_records), int(st1.n_good), int(st1.stop_code)) == (123, 123, 0)
+    out2, st2 = parser.parse(textio.text_to_device(ft[int(st1.fwd_consumed):]), textio.text_to_device(rt[int(st1.rev_consumed):]), 1000, 456)
+    assert int(st2.n_good) == 500 - 123
+    both = np.concatenate([out1["fwd"].cpu().numpy()[:123], out2["fwd"].cpu().numpy()[:377]])
+    assert np.array_equal(both, whole["fwd"].cpu().numpy()[:500])
+    assert int(st1.n_dropped) + int(st2.n_dropped) == int(wst.n_dropped)
+
+
+def test_format_capacity_and_empty(io):
+    pa, textio, parser, formatter = io
+    spec = synth.config_spec(1)
+    f, r, fl, rl = synth.generate_numpy(spec, 0, 512)
+    ft, rt = synth.render_fastq(f, r, fl, rl)
+    ftd = textio.text_to_device(ft)
+    rows, st = parser.parse(ftd, textio.text_to_device(rt), 512, spec.row_stride())
+    asm, b = _assemble(pa, rows, 512)
+    out, nbytes, _ = formatter.format(b, rows["ids"], ftd, textio.OUT_FASTA)
+    assert nbytes > 0
+    # a buffer one byte too small is refused, with the size that is needed in the message
+    with pytest.raises(pa.PamdError, match=str(nbytes)):
+        formatter.format(b, rows["ids"], ftd, textio.OUT_FASTA, capacity=nbytes - 1)
+    out2, nbytes2, _ = formatter.format(b, rows["ids"], ftd, textio.OUT_FASTA, capacity=nbytes)
+    assert nbytes2 == nbytes and bytes(out2[:nbytes].cpu().numpy().tobytes()) == bytes(out[:nbytes].cpu().numpy().tobytes())
+    # nothing accepted -> no text: an impossible quality threshold turns every pair into LOWQ
+    asm2 = pa.Assembler(0)
+    asm2.set_threshold(0.999999)
+    outs = pa.alloc_outputs(512, 512 * 912 + 16384 * 4096, "cuda:0")
+    b2 = pa.DeviceBatch(n=512, fwd=rows["fwd"], rev=rows["rev"], flen=rows["flen"], rlen=rows["rlen"], **outs)
+    asm2.assemble_device(b2)
+    import torch
+    torch.cuda.synchronize()
+    assert (b2.results_numpy()["status"] != 0).all()
+    _, nb, _ = formatter.format(b2, rows["ids"], ftd, textio.OUT_FASTQ)
+    assert nb == 0
