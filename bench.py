@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--algo", default=None, help="override the config's scorer (simple_bayesian, pear, rdp_mle, uparse, flash, ea_util, stitch): "
                                                  "not a BASELINE.json configuration, for the per-scorer table of DESIGN.md")
     ap.add_argument("--primers-after", action="store_true", help="`-a`: strip primers after assembly (config 2 has primers)")
+    ap.add_argument("--io", action="store_true", help="N=1 only: also time the data-format rows either side of the path (FASTQ ingest, FASTA / "
+                                                      "FASTQ formatting, tools/bench_io.py) with their own CPU baseline; reported under \"io\"")
+    ap.add_argument("--io-pairs", type=int, default=4_000_000)
     return ap.parse_args()
 
 
@@ -283,6 +286,37 @@ def main():
             "single_thread_pairs_per_s": rate1,
             "matches_gpu_on_sample": same,
         }
+    # ---- optional: the data-format rows either side of the path, with the oracle's reader / formatter as CPU baseline ----
+    if rank == 0 and world == 1 and args.io:
+        del batch
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_io
+        io_args = argparse.Namespace(pairs=args.io_pairs, config=cfg_index, steps=3, out=None)
+        io_out, ctx = bench_io.run(io_args)
+        if not args.no_cpu:
+            from oracle import pyoracle as po
+            m = min(200_000, ctx["base_n"])
+            ft, rt = ctx["ft"], ctx["rt"]
+            cut_f, cut_r = ft[:len(ft) // ctx["base_n"] * m], rt[:len(rt) // ctx["base_n"] * m]
+            c0 = time.perf_counter()
+            pf, pr, pfl, prl, oids, ost = po.fastq_read(cut_f, cut_r, stride=ctx["stride"], max_pairs=m)
+            cpu_parse = time.perf_counter() - c0
+            same = bool(ost.n_pairs == m and np.array_equal(pf, ctx["rows"]["fwd"][:m].cpu().numpy()) and np.array_equal(pr, ctx["rows"]["rev"][:m].cpu().numpy()))
+            res_io, okm = ctx["res"], ctx["okm"]
+            k = 0
+            c0 = time.perf_counter()
+            for i in range(min(m, 50_000)):
+                if okm[i]:
+                    po.output_fasta(oids[i], float(res_io["quality"][i]), np.ones(int(res_io["seq_len"][i]), dtype=np.uint8))
+                    k += 1
+            cpu_fmt = time.perf_counter() - c0
+            io_out["cpu_baseline"] = {
+                "ingest_pairs_per_s": m / cpu_parse, "format_fasta_pairs_per_s": k / cpu_fmt if cpu_fmt > 0 else None, "cores": 1, "kind": "port",
+                "sample": f"first {m} pairs of the same text through the oracle's reader (one thread, in memory); {k} results through its FASTA formatter (ctypes call per pair)",
+                "matches_gpu_on_sample": same,
+            }
+        out["io"] = io_out
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -6,7 +6,8 @@ FASTQ text -> batch rows, and accepted pairs -> FASTA / FASTQ text, with the tex
 
 One JSON object: per stage the pairs/s, the kernels' HIP-event time, the algorithmic bytes per pair
 and the fraction of the 8 TB/s HBM roofline they amount to; the end-to-end text -> text rate of the
-three stages back to back; and the oracle's single-thread CPU rate on a bounded sample of the same text.
+three stages back to back.  `python bench.py --io` runs the same legs and adds the CPU baseline (the
+oracle's reader and formatter on a bounded sample of the same text).
 
 Algorithmic bytes (the minimum a pass must move):
   ingest   both texts once + one row of 2 bytes/base per read + lengths (4 B) + the parsed header (48 B)
@@ -24,15 +25,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0
 
 
-def main():
-    ap = argparse.ArgumentParser()
+def add_args(ap):
     ap.add_argument("--pairs", type=int, default=4_000_000, help="pairs per text chunk (a chunk must stay below 4 GiB)")
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--cpu-pairs", type=int, default=200_000)
     ap.add_argument("--out", default=None)
-    args = ap.parse_args()
-    import numpy as np
+
+
+def run(args):
+    """The GPU legs.  Returns (result dict, context for a CPU baseline leg: bench.py --io adds that one, because
+    only bench.py's cpu_baseline leg and tests/ may call the oracle)."""
     import torch
 
     import bench
@@ -133,31 +135,15 @@ def main():
         },
         "text_to_text": {"pairs_per_s": n / e2e, "ms": e2e * 1e3, "stages": "FASTQ parse -> assemble (fast sums) -> FASTA format, host wall clock, text resident in HBM"},
     }
-    # CPU baseline: the oracle's reader + formatter, one thread, on a bounded sample of the same text
-    from oracle import pyoracle as po
-    m = min(args.cpu_pairs, base_n)
-    cut_f = ft[:len(ft) // base_n * m]
-    cut_r = rt[:len(rt) // base_n * m]
-    t0 = time.perf_counter()
-    pf, pr, pfl, prl, oids, ost = po.fastq_read(cut_f, cut_r, stride=stride, max_pairs=m)
-    cpu_parse = time.perf_counter() - t0
-    assert ost.n_pairs == m
-    same = bool(np.array_equal(pf, rows["fwd"][:m].cpu().numpy()) and np.array_equal(pr, rows["rev"][:m].cpu().numpy()))
-    seq_nt = b.seq_nt.cpu().numpy() if n <= 1_000_000 else None
-    t0 = time.perf_counter()
-    k = 0
-    for i in range(min(m, 50_000)):
-        if okm[i]:
-            ln = int(res["seq_len"][i])
-            nt = seq_nt[int(res["seq_offset"][i]):int(res["seq_offset"][i]) + ln] if seq_nt is not None else np.ones(ln, dtype=np.uint8)
-            po.output_fasta(oids[i], float(res["quality"][i]), nt)
-            k += 1
-    cpu_fmt = time.perf_counter() - t0
-    out["cpu_baseline"] = {
-        "ingest_pairs_per_s": m / cpu_parse, "format_fasta_pairs_per_s": k / cpu_fmt if cpu_fmt > 0 else None, "cores": 1, "kind": "port",
-        "sample": f"first {m} pairs of the same text through the oracle's reader (one thread, in memory); {k} results through its FASTA formatter (ctypes call per pair)",
-        "matches_gpu_on_sample": same,
-    }
+    ctx = dict(ft=ft, rt=rt, base_n=base_n, stride=stride, rows=rows, res=res, okm=okm, batch=b, n=n)
+    return out, ctx
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    add_args(ap)
+    args = ap.parse_args()
+    out, _ = run(args)
     s = json.dumps(out)
     print(s)
     if args.out:
