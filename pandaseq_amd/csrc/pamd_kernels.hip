@@ -850,7 +850,7 @@ __device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsi
 // What is left to do for a pair once its row is written -- the f64 division of the quality sum, LOWQ,
 // the check modules, the 48-byte record, the counters -- is wave-uniform work: done per pair it occupies a
 // whole wave for a few hundred instructions with one useful lane.  Instead the pair's scalars are dropped
-// into lane `slot` of twelve registers (one v_cndmask each), and every 64 pairs all lanes finish their
+// into lane `slot` of ten registers (one v_cndmask each), and every 64 pairs all lanes finish their
 // pair at once.  Rows of pairs that turn out LOWQ / rejected stay in the arena as holes, as in exact mode.
 struct Pend64 {
 	unsigned off_lo, off_hi;	// row offset in seq_nt / seq_p (~0 = none)
@@ -859,9 +859,7 @@ struct Pend64 {
 	unsigned len_bo;		// seq_len | overlap << 16
 	unsigned ex_mm;			// examined | mismatches << 16
 	unsigned dg_fo;			// degenerates | forward offset << 16
-	unsigned ro_st;			// reverse offset | status << 16 | slow << 24 | "q is final" << 25
-	unsigned div_ph;		// the divisor len (assembler.c:244) | smallest phred << 16
-	unsigned a_novl;		// forward-only bases | overlap bases << 16 (for the exact redo of the three sums)
+	unsigned ro_st;			// reverse offset | status << 16 | slow << 24 | "q is final" << 25 | smallest phred (63 = none) << 26
 };
 
 __device__ __forceinline__ unsigned put_lane(unsigned reg, unsigned value, bool mine) {
@@ -885,9 +883,7 @@ __device__ __forceinline__ void park64(Pend64 &pd, int slot_idx, const PendRec &
 	pd.len_bo = put_lane(pd.len_bo, (unsigned) rec.seqlen | ((unsigned) rec.bo << 16), slot);
 	pd.ex_mm = put_lane(pd.ex_mm, (unsigned) rec.examined | ((unsigned) rec.mism << 16), slot);
 	pd.dg_fo = put_lane(pd.dg_fo, (unsigned) rec.degen | ((unsigned) rec.fo << 16), slot);
-	pd.ro_st = put_lane(pd.ro_st, (unsigned) rec.ro | ((unsigned) status << 16) | ((unsigned) (rec.slow != 0) << 24) | ((unsigned) q_final << 25), slot);
-	pd.div_ph = put_lane(pd.div_ph, (unsigned) rec.len | ((unsigned) rec.phmin << 16), slot);
-	pd.a_novl = put_lane(pd.a_novl, (unsigned) rec.A | ((unsigned) rec.novl << 16), slot);
+	pd.ro_st = put_lane(pd.ro_st, (unsigned) rec.ro | ((unsigned) status << 16) | ((unsigned) (rec.slow != 0) << 24) | ((unsigned) q_final << 25) | ((unsigned) (rec.phmin > 63 ? 63 : rec.phmin) << 26), slot);
 }
 
 // lane s finishes the wave's s-th parked pair: pair index first_pair + s * pair_step
@@ -914,27 +910,13 @@ __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64
 		if (status == PAMD_ST_OK) {
 			if (row == ~0ull)
 				atomicAdd(P.error_flag, 1ull);	// the output arena was too small for this row
-			const double len = (double) (pd.div_ph & 0xFFFFu);
-			quality = q_final ? q.d : q.d / len;	// assembler.c:244
-			if (!q_final && fabs(quality - P.threshold) <= 1e-9 && row != ~0ull) {
-				// too close to the LOWQ threshold for an any-order sum: the three sums again, in the
-				// reference's order, from the row (this wave wrote it; its stores are retired first)
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				const int A = (int) (pd.a_novl & 0xFFFFu), novl = (int) (pd.a_novl >> 16);
-				const double *p = P.seq_p + row;
-				double f = 0.0, r = 0.0, o = 0.0;
-				for (int j = 0; j < A; j++)
-					f += p[j];
-				for (int j = A + novl; j < seqlen; j++)
-					r += p[j];
-				for (int j = A; j < A + novl; j++)
-					o += p[j];
-				quality = (f + r + o) / len;
-			}
+			// assembler.c:244: the divisor is the sequence length + 1.  A sum that lands within 1e-9 of the LOWQ
+			// threshold was already redone in reference order when the pair was parked (flagged final).
+			quality = q_final ? q.d : q.d / (double) (seqlen + 1);
 			if (quality < P.threshold) {	// assembler.c:334-338
 				status = PAMD_ST_LOWQ;
 			} else {
-				const int phmin = (int) (pd.div_ph >> 16);
+				const int ph6 = (int) (pd.ro_st >> 26), phmin = ph6 == 63 ? 127 : ph6;
 				for (int mi = 0; mi < P.n_modules && reject < 0; mi++) {	// module.c:124-136
 					const PamdModule md = P.modules[mi];
 					if (md.kind == 1) {	// plugin_min_phred.c:8-22
@@ -1026,6 +1008,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 	PH_DECL;
 	bool rotated = false;
 	double quality_fast = 0.0;
+	bool quality_final_flag = POST;	// quality_fast is the finished quality, not the sum still to be divided
 	const int minov = P.minoverlap;
 	const unsigned hmask = P.hash_slots - 1u;
 	const unsigned hshift = P.hash_shift;
@@ -1648,8 +1631,15 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		}
 		rec.mism = mism;
 		rec.degen = degen;
-		if (!EXACT && !post)
-			quality_fast = quality_sum(qacc);	// divided by len in finish64()
+		if (!EXACT && !post) {
+			quality_fast = quality_sum(qacc);	// divided by len in finish64() ...
+			// ... unless the quotient would land within 1e-9 of the LOWQ threshold (tested without dividing):
+			// then the three sums are redone here, in reference order, from the staged row
+			if (fabs(quality_fast - P.threshold * (double) len) <= 1e-9 * (double) len) {
+				quality_fast = fast_quality(L, qacc, P.threshold, len, seqlen, A, novl, true, lane);
+				quality_final_flag = true;
+			}
+		}
 	} while (0);
 	if (!rotated) {
 		cur = nxt;
@@ -1663,7 +1653,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		return;
 	}
 	// fast sums: the pair's scalars wait in lane `slot_idx` of the wave's pending registers (finish64)
-	park64(pd, slot_idx, rec, status, quality_fast, POST);
+	park64(pd, slot_idx, rec, status, quality_fast, quality_final_flag);
 }
 
 template <int ALGO, bool PHRED, int BPL, bool EXACT, bool POST>
@@ -1725,7 +1715,7 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	// are known-ready on both incoming edges
 	asm volatile("" : "+v"(cur.flen_v), "+v"(cur.rlen_v), "+v"(cur.f.x), "+v"(cur.f.y), "+v"(cur.f.z), "+v"(cur.f.w), "+v"(cur.r.x), "+v"(cur.r.y), "+v"(cur.r.z), "+v"(cur.r.w));
 	int npend = 0;
-	Pend64 pd = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+	Pend64 pd = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
 	u64 group_first = pair;	// fast sums: the pair parked in lane 0 of the pending registers
 	while (pair < P.n_pairs) {
 		const u64 next = pair + total_waves;
