@@ -138,7 +138,21 @@ __device__ __forceinline__ uint4 load_read(const uint8_t *row, unsigned row_byte
 	return make_uint4(v.x, v.y, 0u, 0u);
 }
 
-template <bool FORWARD, int BPL>
+// word w (0..3) of the 16-entry byte table nt -> (2-bit k-mer code | special-base map entry << 2) of one read
+// direction (see stage_read); entries 4w .. 4w+3, lowest nt in the low byte
+template <bool FORWARD>
+__device__ __forceinline__ constexpr unsigned lut_word(int w) {
+	unsigned v = 0;
+	for (int k = 0; k < 4; k++) {
+		const int nt = 4 * w + k;
+		const unsigned code = ((FORWARD ? 0x00030210u : 0x00030120u) >> (2 * nt)) & 3u;
+		const unsigned special = ((FORWARD ? 0xD5545441u : 0xEAA8A882u) >> (2 * nt)) & 3u;
+		v |= (code | (special << 2)) << (8 * k);
+	}
+	return v;
+}
+
+template <bool FORWARD, int BPL, bool BYTEWISE>
 __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint16_t *dst, uint32_t *codes, uint32_t *nmap) {
 	if (lane * BPL < len) {
 		if (BPL == 8)
@@ -146,7 +160,6 @@ __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint
 		else
 			reinterpret_cast<uint2 *>(dst)[lane] = make_uint2(v.x, v.y);
 	}
-	const unsigned w[4] = { v.x, v.y, v.z, v.w };
 	// Branch-free on purpose (straight-line bit arithmetic; ?: chains here compile to exec-mask
 	// branches per base).  nt is 0..15 in the device domain.
 	//   2-bit code (misc.h:41: T=3 G=2 C=1, anything else 0) = two bits of a constant indexed by nt
@@ -157,14 +170,37 @@ __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint
 	// special-base map entry by nt: 3 for N (15), 0 for A C G T (1 2 4 8), 1 for everything else; the
 	// reverse read stores 2 instead of 1 (entries are bit-swapped like its codes)
 	constexpr unsigned SPECIAL_F = 0xD5545441u, SPECIAL_R = 0xEAA8A882u;	// 16 two-bit entries, nt 0 in the low bits
+	constexpr unsigned CODE_OF = FORWARD ? 0x00030210u : 0x00030120u;
+	if (BPL == 4 && BYTEWISE) {
+		// four bases at once (used where it does not push the kernel over its register budget: DESIGN.md "the
+		// register cliff"): the nt and quality bytes are gathered into one word each, the two 2-bit
+		// maps come out of ONE 16-entry byte table (code | special << 2) read with v_perm_b32, and
+		// "quality == 2" is a zero-byte test
+		const unsigned n4 = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u) & 0x0F0F0F0Fu;
+		const unsigned q4 = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);
+		const unsigned sel = n4 & 0x07070707u;
+		const unsigned b3 = (n4 >> 3) & 0x01010101u, m3 = (b3 << 8) - b3;	// 0xFF where nt >= 8
+		const unsigned lo = __builtin_amdgcn_perm(lut_word<FORWARD>(1), lut_word<FORWARD>(0), sel);
+		const unsigned hi = __builtin_amdgcn_perm(lut_word<FORWARD>(3), lut_word<FORWARD>(2), sel);
+		const unsigned r4 = (hi & m3) | (lo & ~m3);
+		const unsigned c4 = r4 & 0x03030303u, s4 = (r4 >> 2) & 0x03030303u;
+		const unsigned cy = c4 | (c4 >> 6), sy = s4 | (s4 >> 6);
+		codes_k = (cy | (cy >> 12)) & 0xFFu;	// base k at bits 2k..2k+1
+		nbits = (sy | (sy >> 12)) & 0xFFu;
+		const unsigned x = q4 ^ 0x02020202u;
+		const unsigned t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);	// 0x80 where quality == 2
+		is2 = (((t >> 7) * 0x00204081u) >> 21) & 0xFu;
+	} else {
+		const unsigned w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-	for (int k = 0; k < BPL; k++) {
-		const unsigned e = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-		const unsigned nt2 = (e & 15u) * 2u;
-		const unsigned c = ((FORWARD ? 0x00030210u : 0x00030120u) >> nt2) & 3u;
-		codes_k |= c << (2 * k);
-		nbits |= (((FORWARD ? SPECIAL_F : SPECIAL_R) >> nt2) & 3u) << (2 * k);
-		is2 |= (((((e >> 8) ^ 2u) & 0xFFu) - 1u) >> 8 & 1u) << k;
+		for (int k = 0; k < BPL; k++) {
+			const unsigned e = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+			const unsigned nt2 = (e & 15u) * 2u;
+			const unsigned c = (CODE_OF >> nt2) & 3u;
+			codes_k |= c << (2 * k);
+			nbits |= (((FORWARD ? SPECIAL_F : SPECIAL_R) >> nt2) & 3u) << (2 * k);
+			is2 |= (((((e >> 8) ^ 2u) & 0xFFu) - 1u) >> 8 & 1u) << k;
+		}
 	}
 	// bases at or beyond the read length contribute nothing
 	int cnt = len - lane * BPL;
@@ -1040,8 +1076,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		}
 		// previous pair's readers are done with this wave's LDS
 		wave_sync();
-		const int uf = stage_read<true, BPL>(fregs, flen, lane, L.F, L.fc, L.fn);
-		const int ur = stage_read<false, BPL>(rregs, rlen, lane, L.R, L.rc, L.rn);
+		const int uf = stage_read<true, BPL, EXACT>(fregs, flen, lane, L.F, L.fc, L.fn);
+		const int ur = stage_read<false, BPL, EXACT>(rregs, rlen, lane, L.R, L.rc, L.rn);
 		// clear the k-mer table (aliases the log-p staging area) and the candidate bitmap
 		for (unsigned s4 = lane; s4 < P.hash_slots / 4; s4 += 64)
 			reinterpret_cast<uint4 *>(L.hash)[s4] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
