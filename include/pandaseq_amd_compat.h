@@ -103,6 +103,8 @@ struct panda_algorithm_class {	/* pandaseq-common.h:594-605 */
 };
 
 /* ---- constructors / lifetime (pandaseq-assembler.h:40-66,183-192) ---- */
+/* misc.c:38-41: what PANDA_MAX_LEN expands to (pandaseq-common.h:44); plugins call it */
+size_t panda_max_len(void);
 PandaAssembler panda_assembler_new(PandaNextSeq next, void *next_data, PandaDestroy next_destroy, PandaLogProxy logger);
 PandaAssembler panda_assembler_new_kmer(PandaNextSeq next, void *next_data, PandaDestroy next_destroy, PandaLogProxy logger, size_t num_kmers);
 PandaAssembler panda_assembler_ref(PandaAssembler assembler);

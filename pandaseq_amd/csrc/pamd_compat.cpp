@@ -629,6 +629,10 @@ void pamd_compat_set_batch_pairs(size_t pairs) {
 	g_batch_pairs = pairs ? pairs : 1;
 }
 
+size_t panda_max_len(void) {	// misc.c:38-41
+	return PAMD_MAX_LEN;
+}
+
 PandaAssembler panda_assembler_new(PandaNextSeq next, void *next_data, PandaDestroy next_destroy, PandaLogProxy logger) {
 	return panda_assembler_new_kmer(next, next_data, next_destroy, logger, PANDA_DEFAULT_NUM_KMERS);
 }

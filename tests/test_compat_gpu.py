@@ -103,6 +103,38 @@ def test_reference_plugin_binaries(built, tmp_path, algo, plugin, args):
         assert np.array_equal(g["nt"], o_nt[i, :g["seq_len"]]) and np.array_equal(g["p"], o_p[i, :g["seq_len"]])
 
 
+@pytest.mark.parametrize("plugin,args", [("completely_miss_the_point", "0"), ("completely_miss_the_point", "2"), ("empty", None)])
+def test_reference_host_plugins(built, tmp_path, plugin, args):
+    """Two more of the reference's own plugin binaries (plugin_completely_miss_the_point.c, plugin_empty.c), which
+    have no fused form: loaded the way module.c:227-298 loads them and run as host callbacks over the results of
+    the device path, in the client compiled against the reference's own pandaseq.h.  They read
+    overlap_mismatches and sequence_length through the reference's struct layout."""
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    from util import adversarial_pairs
+    client = os.path.join(REF_DIR, "refclient")
+    so = os.path.join(REF_DIR, plugin + ".so")
+    if not (os.path.exists(client) and os.path.exists(so)):
+        pytest.skip("oracle/_ref was not built (needs /root/reference at build time: make -C oracle ref)")
+    spec = synth.config_spec(1)
+    n = 2500
+    fwd, rev, flen, rlen = adversarial_pairs(spec, n, seed=35)
+    pin, out_host = tmp_path / "pairs.bin", tmp_path / "host.bin"
+    _write_pairs(pin, fwd, rev, flen, rlen)
+    subprocess.check_call([client, str(pin), str(out_host), "simple_bayesian", "2", so, plugin, "(null)" if args is None else args], timeout=300)
+    got, counters, _ = _parse_output(out_host.read_bytes())
+    o_res, o_nt, o_p, o_ctr = po.assemble_batch(po.make_config("simple_bayesian"), fwd, rev, flen, rlen)
+    ok = [i for i in range(n) if flen[i] >= 2 and rlen[i] >= 2 and o_res["status"][i] == 0]
+    if plugin == "completely_miss_the_point":
+        expected = [i for i in ok if o_res["mismatches"][i] <= int(args)]
+    else:
+        expected = [i for i in ok if o_res["seq_len"][i] > 0]
+    assert [g["index"] for g in got] == expected
+    assert counters[8] == len(ok) - len(expected)
+    if plugin == "completely_miss_the_point":
+        assert counters[8] > 0, "the filter must reject something for the test to mean anything"
+
+
 @pytest.mark.parametrize("algo,mode", [("simple_bayesian", 0), ("pear", 0), ("rdp_mle", 1), ("uparse", 0), ("flash", 0), ("ea_util", 0), ("stitch", 0)])
 def test_reference_api_client(built, tmp_path, algo, mode):
     from oracle import pyoracle as po
