@@ -82,6 +82,10 @@ typedef struct panda_log_proxy *PandaLogProxy;	/* pandaseq-common.h:93; opaque, 
 
 /* callback types, pandaseq-common.h:338-522 */
 typedef void (*PandaDestroy) (void *user_data);
+/* pandaseq-common.h:430-443: fill `buffer` with up to buffer_length bytes; *read = 0 at the end of the data */
+typedef bool (*PandaBufferRead) (char *buffer, size_t buffer_length, size_t *read, void *user_data);
+/* pandaseq-common.h:165-178 */
+typedef enum { PANDA_TAG_PRESENT, PANDA_TAG_ABSENT, PANDA_TAG_OPTIONAL } PandaTagging;
 typedef bool (*PandaNextSeq) (panda_seq_identifier *id, const panda_qual **forward, size_t *forward_length, const panda_qual **reverse, size_t *reverse_length, void *user_data);
 typedef void (*PandaFailAlign) (PandaAssembler assembler, const panda_seq_identifier *id, const panda_qual *forward, size_t forward_length, const panda_qual *reverse, size_t reverse_length, void *user_data);
 typedef bool (*PandaCheck) (PandaLogProxy logger, const panda_result_seq *sequence, void *user_data);
@@ -103,6 +107,19 @@ struct panda_algorithm_class {	/* pandaseq-common.h:594-605 */
 };
 
 /* ---- constructors / lifetime (pandaseq-assembler.h:40-66,183-192) ---- */
+/* ---- the FASTQ reader (pandaseq.h:111-127,238-264, pandaseq-assembler.h:77-101), parsing whole chunks of text on
+ * the device (pamd_compat_fastq.cpp).  Plain and gzip files; no bzip2, no separate index-read file (`index` must
+ * be NULL). ---- */
+PandaNextSeq panda_create_fastq_reader(PandaBufferRead forward, void *forward_data, PandaDestroy forward_destroy, PandaBufferRead reverse, void *reverse_data, PandaDestroy reverse_destroy, PandaLogProxy logger, unsigned char qualmin, PandaTagging policy, PandaBufferRead index, void *index_data, PandaDestroy index_destroy, void **user_data, PandaDestroy *destroy);
+PandaBufferRead panda_open_buffer(const char *file_name, PandaLogProxy logger, void **user_data, PandaDestroy *destroy);
+PandaNextSeq panda_open_fastq(const char *forward, const char *reverse, PandaLogProxy logger, unsigned char qualmin, PandaTagging policy, const char *index, void **user_data, PandaDestroy *destroy);
+PandaAssembler panda_assembler_new_fastq_reader(PandaBufferRead forward, void *forward_data, PandaDestroy forward_destroy, PandaBufferRead reverse, void *reverse_data, PandaDestroy reverse_destroy, PandaLogProxy logger, unsigned char qualmin, PandaTagging policy);
+PandaAssembler panda_assembler_open_fastq(const char *forward, const char *reverse, PandaLogProxy logger, unsigned char qualmin, PandaTagging policy);	/* fileio.c:139 */
+PandaAssembler panda_assembler_open(const char *forward, const char *reverse, PandaLogProxy logger, unsigned char qualmin, PandaTagging policy);	/* the name pandaseq-assembler.h:96 declares */
+/* which GPU the readers created from now on parse on (default 0), and the PAMD_FQ_* code (pandaseq_amd_io.h) the
+ * last reader on this thread stopped with -- the PandaCode the reference's reader would have logged */
+void pamd_compat_set_fastq_device(int device);
+int pamd_compat_last_fastq_stop(void);
 /* misc.c:38-41: what PANDA_MAX_LEN expands to (pandaseq-common.h:44); plugins call it */
 size_t panda_max_len(void);
 PandaAssembler panda_assembler_new(PandaNextSeq next, void *next_data, PandaDestroy next_destroy, PandaLogProxy logger);

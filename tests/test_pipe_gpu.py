@@ -95,3 +95,62 @@ def test_reader_stops_where_the_reference_stops(pipe, tmp_path):
     want, ctr, st2 = _oracle_text(bad, rt, "simple_bayesian", "fasta")
     assert po.FQ_STOP[st2.stop_code] in ("BADNT", "NOQUAL") and st2.n_records == 1100
     assert got == want and stop == (st2.stop_code, 1100)
+
+
+# ---- the reference's own file-level API: panda_assembler_open() + panda_assembler_next() ------------------
+@pytest.fixture(scope="module")
+def open_client(built, tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("open") / "test_open_fastq")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "test_open_fastq.c"), "-o", exe,
+                           "-L", os.path.join(ROOT, "pandaseq_amd"), "-lpandaseq_amd", "-lm",
+                           "-Wl,-rpath," + os.path.join(ROOT, "pandaseq_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def _run_open(exe, tmp_path, ft, rt, algo, gz=False):
+    import gzip
+    f, r, o = tmp_path / ("f.fastq.gz" if gz else "f.fastq"), tmp_path / ("r.fastq.gz" if gz else "r.fastq"), tmp_path / "out.fasta"
+    f.write_bytes(gzip.compress(ft, 1) if gz else ft)
+    r.write_bytes(gzip.compress(rt, 1) if gz else rt)
+    out = subprocess.check_output([exe, str(f), str(r), str(o), algo], timeout=600).decode()
+    stat = {line.split("\t")[1]: int(line.split("\t")[2]) for line in out.splitlines() if line.startswith("STAT")}
+    stop = int([line.split("\t")[1] for line in out.splitlines() if line.startswith("STOP")][0])
+    return o.read_bytes(), stat, stop
+
+
+@pytest.mark.parametrize("algo,gz", [("simple_bayesian", False), ("pear", True), ("uparse", False)])
+def test_reference_file_api(open_client, tmp_path, algo, gz):
+    """panda_assembler_open(forward, reverse, ...) on plain and gzip files, then the pool.c:76 loop: the FASTQ text is
+    parsed on the device a chunk at a time behind the per-pair PandaNextSeq contract, names included."""
+    ft, rt = util.random_fastq(3000, 47)
+    got, stat, stop = _run_open(open_client, tmp_path, ft, rt, algo, gz)
+    want, ctr, st = _oracle_text(ft, rt, algo, "fasta")
+    assert got == want
+    assert stat["READS"] == int(ctr["count"]) and stat["OK"] == int(ctr["ok"]) and stat["NOALGN"] == int(ctr["noalgn"])
+    assert stat["LOWQ"] == int(ctr["lowq"]) and stat["BADR"] == int(ctr["badr"]) and stop == 0
+
+
+def test_reference_file_api_many_chunks_and_stop(open_client, tmp_path):
+    """More pairs than one refill holds (65 536), and a record the reader must stop at."""
+    spec = synth.config_spec(0)
+    f, r, fl, rl = synth.generate_numpy(spec, 0, 150_000)
+    ft, rt = synth.render_fastq(f, r, fl, rl)
+    lines = rt.split(b"\n")
+    lines[4 * 140_000 + 3] = lines[4 * 140_000 + 3][:-1]  # one quality too few in the reverse read of record 140000
+    rt_bad = b"\n".join(lines)
+    got, stat, stop = _run_open(open_client, tmp_path, ft, rt_bad, "simple_bayesian")
+    want, ctr, st = _oracle_text(ft, rt_bad, "simple_bayesian", "fasta", stride=152)
+    assert st.n_records == 140_000 and po.FQ_STOP[st.stop_code] == "NOQUAL"
+    assert got == want and stat["READS"] == 140_000 and stop == st.stop_code
+
+
+def test_reference_file_api_with_reference_headers(built, tmp_path):
+    """The same client compiled against the reference's OWN pandaseq.h (oracle/_ref/refopen)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "refopen")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref was not built (needs /root/reference at build time: make -C oracle ref)")
+    ft, rt = util.random_fastq(1200, 49)
+    got, stat, stop = _run_open(exe, tmp_path, ft, rt, "rdp_mle")
+    want, ctr, st = _oracle_text(ft, rt, "rdp_mle", "fasta")
+    assert got == want and stat["OK"] == int(ctr["ok"])
