@@ -24,6 +24,10 @@
 #include <stdbool.h>
 #include <stddef.h>
 
+#ifndef PANDA_API
+#	define PANDA_API 3	/* pandaseq.h:61: the plugin ABI version panda_module_load() demands */
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -135,11 +139,19 @@ const panda_result_seq *panda_assembler_next(PandaAssembler assembler);	/* :175 
 /* ---- modules (pandaseq-assembler.h:112-167, pandaseq-module.h) ---- */
 PandaModule panda_module_new(const char *name, PandaCheck check, PandaPreCheck precheck, void *user_data, PandaDestroy cleanup);	/* module.c:300-321 */
 /* "min_phred:10" / "min_overlapbits:15" -> a module the kernel applies itself (replaces dlopen-ing
- * plugin_min_phred.c / plugin_min_overlapbits.c through module.c:227-298); anything else -> NULL */
+ * plugin_min_phred.c / plugin_min_overlapbits.c through module.c:227-298).  Any other "name[:args]" is a
+ * plugin file as module.c loads them: name, name.so, then $PANDASEQ_PLUGIN_DIR/name[.so]; its
+ * <module>_LTX_api must equal PANDA_API and its <module>_LTX_opener (pandaseq-plugin.h:33) supplies the
+ * precheck / check callbacks, which run on the host around the device batch like panda_module_new()'s. */
 PandaModule panda_module_load(PandaLogProxy logger, const char *path);
 PandaModule panda_module_ref(PandaModule module);
 void panda_module_unref(PandaModule module);
 const char *panda_module_get_name(PandaModule module);
+int panda_module_get_api(PandaModule module);	/* module.c:360-363 */
+const char *panda_module_get_args(PandaModule module);	/* pandaseq-module.h:94 (declared there, defined nowhere in the reference) */
+const char *panda_module_get_description(PandaModule module);	/* module.c:365-372 */
+const char *panda_module_get_usage(PandaModule module);	/* module.c:384-391 */
+const char *panda_module_get_version(PandaModule module);	/* module.c:379-382 */
 bool panda_assembler_add_module(PandaAssembler assembler, PandaModule module);
 size_t panda_assembler_add_modules(PandaAssembler assembler, PandaModule *modules, size_t modules_length);
 bool panda_assembler_foreach_module(PandaAssembler assembler, PandaModuleCallback callback, void *callback_data);
@@ -150,6 +162,12 @@ extern const struct panda_algorithm_class panda_algorithm_simple_bayes_class;
 extern const struct panda_algorithm_class panda_algorithm_pear_class;
 extern const struct panda_algorithm_class panda_algorithm_rdp_mle_class;
 PandaAlgorithm panda_algorithm_new(PandaAlgorithmClass clazz);
+/* the name-sorted registry the command line looks algorithms up in (algo.c:96-133); the seven classes above
+ * are registered when the library loads.  A class registered by the caller is listed, but an assembler only
+ * accepts the seven the kernel implements (panda_assembler_set_algorithm logs and keeps the old one otherwise). */
+extern PandaAlgorithmClass *panda_algorithms;
+extern size_t panda_algorithms_length;
+void panda_algorithm_register(PandaAlgorithmClass clazz);
 PandaAlgorithm panda_algorithm_ref(PandaAlgorithm algo);
 void panda_algorithm_unref(PandaAlgorithm algo);
 bool panda_algorithm_is_a(PandaAlgorithm algo, PandaAlgorithmClass clazz);

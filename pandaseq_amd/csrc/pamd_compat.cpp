@@ -3,6 +3,8 @@
 // per-pair callbacks and counters in source order (assembler.c:252-366), and the getters/setters of
 // assembler_support.c.  All assembly arithmetic happens in the HIP kernel; nothing here scores,
 // merges or sums anything.
+#include <dlfcn.h>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -208,6 +210,38 @@ PandaAlgorithm panda_algorithm_ea_util_new(void) {	// algo_ea_util.c:89-92
 PandaAlgorithm panda_algorithm_stitch_new(void) {	// algo_stitch.c:89-92
 	return panda_algorithm_new(&panda_algorithm_stitch_class);
 }
+
+// the registry (algo.c:96-133): a name-sorted array the front end's -A option searches
+PandaAlgorithmClass *panda_algorithms = nullptr;
+size_t panda_algorithms_length = 0;
+static size_t g_algorithms_size = 0;
+
+void panda_algorithm_register(PandaAlgorithmClass clazz) {
+	for (size_t it = 0; it < panda_algorithms_length; it++)
+		if (panda_algorithms[it] == clazz)
+			return;
+	if (panda_algorithms_length == g_algorithms_size) {
+		g_algorithms_size = g_algorithms_size ? 2 * g_algorithms_size : 16;
+		panda_algorithms = static_cast<PandaAlgorithmClass *>(realloc(panda_algorithms, g_algorithms_size * sizeof(PandaAlgorithmClass)));
+	}
+	// insertion keeps the array sorted by name
+	size_t at = panda_algorithms_length++;
+	while (at > 0 && strcmp(panda_algorithms[at - 1]->name, clazz->name) > 0) {
+		panda_algorithms[at] = panda_algorithms[at - 1];
+		at--;
+	}
+	panda_algorithms[at] = clazz;
+}
+
+__attribute__((constructor)) static void register_builtin_algorithms(void) {	// algo.c:123-133
+	panda_algorithm_register(&panda_algorithm_ea_util_class);
+	panda_algorithm_register(&panda_algorithm_flash_class);
+	panda_algorithm_register(&panda_algorithm_pear_class);
+	panda_algorithm_register(&panda_algorithm_rdp_mle_class);
+	panda_algorithm_register(&panda_algorithm_simple_bayes_class);
+	panda_algorithm_register(&panda_algorithm_stitch_class);
+	panda_algorithm_register(&panda_algorithm_uparse_class);
+}
 }	// extern "C"
 
 // ---------------------------------------------------------------- modules (module.c)
@@ -218,10 +252,99 @@ struct panda_module {
 	PandaDestroy destroy;
 	void *user_data;
 	char *name;
+	char *args;	// the text after ':' in panda_module_load's path (module.c:284), NULL when there was none
+	void *handle;	// dlopen handle of a plugin file; NULL for panda_module_new and the two fused modules
+	int api;
+	const char **version;
 	int fused_kind;	// 0 = host callbacks; 1 = min_phred, 2 = min_overlapbits (run inside the kernel)
 	int fused_phred;
 	double fused_bits;
 };
+
+// A plugin is a shared object exporting <module>_LTX_api, <module>_LTX_opener and optionally _LTX_desc / _LTX_usage /
+// _LTX_version (pandaseq-plugin.h:33-35).  module.c:227-298 finds it with libltdl's lt_dlopenext(); here it is
+// dlopen() on the name as given, then with ".so" appended, then under $PANDASEQ_PLUGIN_DIR.  libltdl looks a symbol up
+// as "<module>_LTX_<sym>" before "<sym>", with <module> the file's base name less "lib" and the extension.
+static void *plugin_symbol(void *handle, const std::string &module, const char *sym) {
+	void *p = dlsym(handle, (module + "_LTX_" + sym).c_str());
+	if (p == nullptr && module.compare(0, 3, "lib") == 0)
+		p = dlsym(handle, (module.substr(3) + "_LTX_" + sym).c_str());
+	return p != nullptr ? p : dlsym(handle, sym);
+}
+
+static std::string plugin_module_name(const std::string &path) {
+	size_t slash = path.rfind('/');
+	std::string base = slash == std::string::npos ? path : path.substr(slash + 1);
+	size_t dot = base.find('.');
+	if (dot != std::string::npos)
+		base.resize(dot);
+	for (char &c : base)
+		if (!isalnum((unsigned char) c))
+			c = '_';
+	return base;
+}
+
+typedef bool (*PluginOpen) (PandaLogProxy logger, const char *args, PandaPreCheck *precheck, PandaCheck *check, void **user_data, PandaDestroy *destroy);
+
+static bool load_plugin_file(PandaModule m, PandaLogProxy logger, const std::string &name, const char *args) {
+	std::vector<std::string> tries = { name, name + ".so" };
+	const char *dir = getenv("PANDASEQ_PLUGIN_DIR");
+	if (dir != nullptr && name.find('/') == std::string::npos) {
+		tries.push_back(std::string(dir) + "/" + name);
+		tries.push_back(std::string(dir) + "/" + name + ".so");
+	}
+	void *handle = nullptr;
+	std::string why;
+	for (const std::string &t : tries) {
+		// a bare name must not be searched for along the loader's default path: only files
+		if (t.find('/') == std::string::npos)
+			handle = dlopen(("./" + t).c_str(), RTLD_NOW | RTLD_LOCAL);
+		else
+			handle = dlopen(t.c_str(), RTLD_NOW | RTLD_LOCAL);
+		if (handle != nullptr)
+			break;
+		const char *e = dlerror();
+		if (why.empty() && e != nullptr)
+			why = e;
+	}
+	if (handle == nullptr) {
+		fprintf(stderr, "Could not open module %s: %s\n", name.c_str(), why.c_str());
+		pamd_set_error("could not open module %s: %s", name.c_str(), why.c_str());
+		return false;
+	}
+	const std::string module = plugin_module_name(name);
+	int *api = static_cast<int *>(plugin_symbol(handle, module, "api"));
+	if (api == nullptr || *api != PANDA_API) {	// module.c:263-270
+		fprintf(stderr, "Invalid API in %s (%d != %d). Are you sure this module was compiled for this version of PANDAseq?\n", name.c_str(), api == nullptr ? -1 : *api, PANDA_API);
+		pamd_set_error("invalid API in module %s", name.c_str());
+		dlclose(handle);
+		return false;
+	}
+	PluginOpen opener = reinterpret_cast<PluginOpen>(plugin_symbol(handle, module, "opener"));
+	if (opener == nullptr) {
+		fprintf(stderr, "Could not find opener function in %s\n", name.c_str());
+		pamd_set_error("could not find opener function in %s", name.c_str());
+		dlclose(handle);
+		return false;
+	}
+	PandaCheck check = nullptr;
+	PandaPreCheck precheck = nullptr;
+	void *user_data = nullptr;
+	PandaDestroy destroy = nullptr;
+	if (!opener(logger, args, &precheck, &check, &user_data, &destroy) || (precheck == nullptr && check == nullptr)) {	// module.c:284
+		pamd_set_error("module %s refused its arguments", name.c_str());
+		dlclose(handle);
+		return false;
+	}
+	m->handle = handle;
+	m->api = *api;
+	m->check = check;
+	m->precheck = precheck;
+	m->user_data = user_data;
+	m->destroy = destroy;
+	m->version = static_cast<const char **>(plugin_symbol(handle, module, "version"));
+	return true;
+}
 
 extern "C" {
 PandaModule panda_module_new(const char *name, PandaCheck check, PandaPreCheck precheck, void *user_data, PandaDestroy cleanup) {	// module.c:300-321
@@ -234,6 +357,7 @@ PandaModule panda_module_new(const char *name, PandaCheck check, PandaPreCheck p
 	m->destroy = cleanup;
 	m->user_data = user_data;
 	m->name = strdup(name);
+	m->api = PANDA_API;
 	return m;
 }
 
@@ -248,6 +372,8 @@ PandaModule panda_module_load(PandaLogProxy logger, const char *path) {
 	PandaModule m = static_cast<PandaModule>(calloc(1, sizeof(struct panda_module)));
 	m->refcnt = 1;
 	m->name = strdup(name.c_str());
+	m->args = args ? strdup(args) : nullptr;
+	m->api = PANDA_API;
 	if (name == "min_phred") {	// plugin_min_phred.c:24-44
 		char *end = nullptr;
 		long v = (args && *args) ? strtol(args, &end, 10) : -1;
@@ -269,8 +395,7 @@ PandaModule panda_module_load(PandaLogProxy logger, const char *path) {
 		}
 		m->fused_kind = 2;
 		m->fused_bits = bits;
-	} else {
-		pamd_set_error("module %s is not built into the device path; wrap its check function with panda_module_new()", name.c_str());
+	} else if (!load_plugin_file(m, logger, name, args)) {
 		panda_module_unref(m);
 		return nullptr;
 	}
@@ -295,12 +420,52 @@ void panda_module_unref(PandaModule m) {
 		if (m->destroy != nullptr && m->user_data != nullptr)
 			m->destroy(m->user_data);
 		free(m->name);
+		free(m->args);
+		if (m->handle != nullptr)
+			dlclose(m->handle);
 		free(m);
 	}
 }
 
 const char *panda_module_get_name(PandaModule m) {
 	return m->name;
+}
+
+int panda_module_get_api(PandaModule m) {	// module.c:360-363
+	return m->api;
+}
+
+const char *panda_module_get_args(PandaModule m) {	// pandaseq-module.h: the arguments the module was loaded with
+	return m->args;
+}
+
+static const char *module_string(PandaModule m, const char *sym) {
+	if (m->handle == nullptr)
+		return nullptr;
+	const char **v = static_cast<const char **>(plugin_symbol(m->handle, plugin_module_name(m->name), sym));
+	return v == nullptr ? nullptr : *v;
+}
+
+const char *panda_module_get_description(PandaModule m) {	// module.c:365-372
+	if (m->fused_kind == 1)
+		return "Require every base of the assembled sequence to reach a minimum PHRED score";
+	if (m->fused_kind == 2)
+		return "Require a minimum amount of information in the overlap";
+	return module_string(m, "desc");
+}
+
+const char *panda_module_get_usage(PandaModule m) {	// module.c:384-391
+	if (m->fused_kind == 1)
+		return "min_phred:value";
+	if (m->fused_kind == 2)
+		return "min_overlapbits:15";
+	return module_string(m, "usage");
+}
+
+const char *panda_module_get_version(PandaModule m) {	// module.c:379-382
+	if (m->fused_kind != 0)
+		return "1.0";	// VER_INFO of plugin_min_phred.c:6 / plugin_min_overlapbits.c:15
+	return m->version == nullptr ? nullptr : *m->version;
 }
 }	// extern "C"
 #endif	// PAMD_WITH_REFERENCE_OBJECTS

@@ -122,6 +122,10 @@ def test_reference_host_plugins(built, tmp_path, plugin, args):
     pin, out_host = tmp_path / "pairs.bin", tmp_path / "host.bin"
     _write_pairs(pin, fwd, rev, flen, rlen)
     subprocess.check_call([client, str(pin), str(out_host), "simple_bayesian", "2", so, plugin, "(null)" if args is None else args], timeout=300)
+    # and the same plugin file through panda_module_load("<file>:<args>"), the call main.c makes for -C
+    out_load = tmp_path / "load.bin"
+    subprocess.check_call([client, str(pin), str(out_load), "simple_bayesian", "3", so if args is None else so + ":" + args], timeout=300)
+    assert out_load.read_bytes() == out_host.read_bytes()
     got, counters, _ = _parse_output(out_host.read_bytes())
     o_res, o_nt, o_p, o_ctr = po.assemble_batch(po.make_config("simple_bayesian"), fwd, rev, flen, rlen)
     ok = [i for i in range(n) if flen[i] >= 2 and rlen[i] >= 2 and o_res["status"][i] == 0]
@@ -133,6 +137,37 @@ def test_reference_host_plugins(built, tmp_path, plugin, args):
     assert counters[8] == len(ok) - len(expected)
     if plugin == "completely_miss_the_point":
         assert counters[8] > 0, "the filter must reject something for the test to mean anything"
+
+
+def test_loaded_plugin_file(built, tmp_path):
+    """A plugin file written for this test (tests/c/plugin_short_overlap.c: a precheck and a check), found by
+    panda_module_load() the way module.c:227-298 finds plugins, run on the host around the device batch."""
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    from util import adversarial_pairs
+    so = str(tmp_path / "short_overlap.so")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "plugin_short_overlap.c"), "-o", so])
+    spec = synth.config_spec(1)
+    n = 2500
+    fwd, rev, flen, rlen = adversarial_pairs(spec, n, seed=37)
+    flen[5:40:7] = 2     # reach the precheck (forward_length >= 3) with reads the assembler itself accepts
+    pin, out = tmp_path / "pairs.bin", tmp_path / "out.bin"
+    _write_pairs(pin, fwd, rev, flen, rlen)
+    limit = 60
+    subprocess.check_call([_build_client(str(tmp_path)), str(pin), str(out), "simple_bayesian", "3", "%s:%d" % (so, limit)], timeout=300)
+    got, counters, _ = _parse_output(out.read_bytes())
+    keep = (flen >= 3) & (rlen >= 2)
+    o_res, o_nt, o_p, o_ctr = po.assemble_batch(po.make_config("simple_bayesian"), fwd, rev, np.where(keep, flen, 0), rlen)
+    ok = [i for i in range(n) if keep[i] and o_res["status"][i] == 0]
+    expected = [i for i in ok if o_res["overlap"][i] >= limit]
+    assert [g["index"] for g in got] == expected
+    pre_rejected = int(((flen == 2) & (rlen >= 2)).sum())
+    assert pre_rejected > 0 and len(ok) > len(expected) > 0
+    assert counters[8] == pre_rejected + len(ok) - len(expected)    # module.c:138-154 and :120-136 count into the same slot
+    for g in got[:100]:
+        i = g["index"]
+        assert g["quality"] == o_res["quality"][i] and np.array_equal(g["nt"], o_nt[i, :g["seq_len"]])
 
 
 @pytest.mark.parametrize("algo,mode", [("simple_bayesian", 0), ("pear", 0), ("rdp_mle", 1), ("uparse", 0), ("flash", 0), ("ea_util", 0), ("stitch", 0)])
