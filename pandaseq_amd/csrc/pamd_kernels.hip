@@ -1228,11 +1228,11 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			// Many candidates: 64 at a time, one per lane (scan_many_counting).  An IUPAC ambiguity code inside
 			// a compared range abandons that path: the pair is then scanned by the step path below.
 			const ManyScan ms = scan_many_counting<ALGO>(L.fc, L.rc, L.fn, L.rn, reinterpret_cast<uint16_t *>(L.ps), mybits, minov, flen, rlen, P.qual_nn, P.sb_pmatch, P.sb_pmismatch, best, lane);
-			if (ms.done) {
+			if (uni(ms.done)) {	// a function's results come back in vector registers: make them wave-uniform again
 				per_lane_done = true;
-				best = ms.best;
-				bo = ms.bo;
-				examined = ms.examined;
+				best = uni_f64(ms.best);
+				bo = uni(ms.bo);
+				examined = uni(ms.examined);
 			}
 		}
 		if (counting_algo<ALGO>() && ncand == 1) {
