@@ -464,13 +464,14 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	o += 128;
 	p.w_pend = o;
 	o += 8 * 80;	// GROUP parked records of 80 bytes
+	// the merge loops are branch-free: up to 63 lanes past the row's end write into slack (pamd_kernels.hip)
 	p.w_nt = o;
-	o += mmax;
+	o += mmax + 64u;
 	p.w_p = o;
-	o += (mmax * 8u > 2048u ? mmax * 8u : 2048u);
+	o += (mmax * 8u > 2048u ? mmax * 8u : 2048u) + 64u * 8u;
 	p.w_pidx = o;
 	if (a->post_primers)
-		o += mmax * 2u;
+		o += mmax * 2u + 64u * 2u;
 	p.lds_wave_bytes = up16(o);
 	{
 		const uint32_t region = (mmax * 8u > 2048u ? mmax * 8u : 2048u);

@@ -65,6 +65,14 @@ __device__ __forceinline__ void wave_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// __ballot() takes an int: a bool predicate is first turned into 0/1 in a vector register (v_cndmask) and compared with
+// zero again (v_cmp) -- two VALU instructions per ballot.  The builtin takes the predicate as it is when it is ONE
+// comparison; a conjunction is still materialised, so hot code writes ballot(a) & ballot(b) (two compares it needed
+// anyway and a scalar AND).
+__device__ __forceinline__ u64 ballot(bool pred) {
+	return __builtin_amdgcn_ballot_w64(pred);
+}
+
 __device__ __forceinline__ int uni(int v) {
 	return __builtin_amdgcn_readfirstlane(v);
 }
@@ -225,7 +233,7 @@ __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint
 		reinterpret_cast<uint8_t *>(nmap)[lane] = (uint8_t) nbits;
 	}
 	const int mine = not2 ? lane * BPL + (31 - __builtin_clz(not2)) + 1 : 0;
-	const u64 has = __ballot(not2 != 0);
+	const u64 has = ballot(not2 != 0);
 	if (has == 0)
 		return 0;
 	const int top = 63 - __builtin_clzll(has);
@@ -278,7 +286,7 @@ __device__ int primer_offset(const PamdKernelParams &P, const double *ltab, cons
 			for (int u = 0; u < 8; u++)
 				if (pn[u] != NT_N)
 					acc += t[u];
-			live = !logdomain || __ballot(have && !(acc < floor_acc)) != 0;
+			live = !logdomain || ballot(have && !(acc < floor_acc)) != 0;
 		}
 		if (!live)
 			continue;	// no start of this block can beat what has been found
@@ -298,7 +306,7 @@ __device__ int primer_offset(const PamdKernelParams &P, const double *ltab, cons
 			best = v;
 			besti = index + 1;
 		}
-		if (logdomain && __ballot(better) != 0) {
+		if (logdomain && ballot(better) != 0) {
 			double m = besti != 0 ? best : bound;
 			for (int off = 32; off > 0; off >>= 1) {
 				const double o = __shfl_xor(m, off);
@@ -508,7 +516,7 @@ __device__ __attribute__((noinline, cold)) ManyScan scan_many_counting(const uin
 	out.done = 1;
 	// the candidates in ascending order, u16 each
 	int total = 0;
-	u64 words = __ballot(mybits != 0);
+	u64 words = ballot(mybits != 0);
 	while (words != 0) {
 		const int w = __builtin_ctzll(words);
 		words &= words - 1;
@@ -534,7 +542,7 @@ __device__ __attribute__((noinline, cold)) ManyScan scan_many_counting(const uin
 			packed += code_word_counts(L, flen, rlen, ov, i0, have, o);
 			any_odd |= o;
 		}
-		if (__ballot(any_odd && have) != 0) {
+		if (ballot(any_odd && have) != 0) {
 			out.done = 0;	// an IUPAC ambiguity code in a compared range: the caller scans this pair step by step
 			break;
 		}
@@ -655,9 +663,9 @@ __device__ __forceinline__ double score_overlap(const PamdKernelParams &P, const
 			const unsigned a1 = L.F[inb ? fb : 0] & 0xFFu, b1 = L.R[inb ? rb : 0] & 0xFFu;
 			const bool n0 = a0 == NT_N || b0 == NT_N, n1 = a1 == NT_N || b1 == NT_N;
 			const bool m0 = (a0 & b0) != 0, m1 = (a1 & b1) != 0;
-			unknowns += __popcll(__ballot(ina && n0)) + __popcll(__ballot(inb && n1));
-			matches += __popcll(__ballot(ina && !n0 && m0)) + __popcll(__ballot(inb && !n1 && m1));
-			mismatches += __popcll(__ballot(ina && !n0 && !m0)) + __popcll(__ballot(inb && !n1 && !m1));
+			unknowns += __popcll(ballot(ina && n0)) + __popcll(ballot(inb && n1));
+			matches += __popcll(ballot(ina && !n0 && m0)) + __popcll(ballot(inb && !n1 && m1));
+			mismatches += __popcll(ballot(ina && !n0 && !m0)) + __popcll(ballot(inb && !n1 && !m1));
 		}
 		return count_score<ALGO>(P.qual_nn, P.sb_pmatch, P.sb_pmismatch, flen, rlen, ov, unknowns, matches, unknowns + matches + mismatches);
 	} else {
@@ -873,7 +881,7 @@ __device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsi
 	const int ctr_of[6] = { PAMD_CTR_OK, PAMD_CTR_BADR, PAMD_CTR_NOFP, PAMD_CTR_NORP, PAMD_CTR_NOALGN, PAMD_CTR_LOWQ };
 #pragma unroll
 	for (int st = 0; st < 6; st++) {
-		const int c = __popcll(__ballot(status == st));
+		const int c = __popcll(ballot(status == st));
 		if (c != 0 && lane == 0)
 			atomicAdd(&lctr[ctr_of[st]], (unsigned) c);
 	}
@@ -983,11 +991,11 @@ __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64
 	const int ctr_of[6] = { PAMD_CTR_OK, PAMD_CTR_BADR, PAMD_CTR_NOFP, PAMD_CTR_NORP, PAMD_CTR_NOALGN, PAMD_CTR_LOWQ };
 #pragma unroll
 	for (int st = 0; st < 6; st++) {
-		const int c = __popcll(__ballot(status == st));
+		const int c = __popcll(ballot(status == st));
 		if (c != 0 && lane == 0)
 			atomicAdd(&lctr[ctr_of[st]], (unsigned) c);
 	}
-	const int nslow = __popcll(__ballot(slow));
+	const int nslow = __popcll(ballot(slow));
 	if (lane == 0) {
 		atomicAdd(&lctr[PAMD_CTR_COUNT], (unsigned) npend);
 		if (nslow)
@@ -1205,7 +1213,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		const unsigned keep = lane < lastw ? 0xFFFFFFFFu : (lane == lastw ? ((1u << (size & 31)) - 1u) : 0u);
 		if (lane <= lastw && lane < 32)
 			mybits = L.bits[lane] & keep;
-		if (__ballot(mybits != 0) == 0)
+		if (ballot(mybits != 0) == 0)
 			mybits = keep;	// ALL_BITS_IF_NONE
 		wave_sync();	// the scan below reuses the staging area the k-mer table lived in
 
@@ -1216,7 +1224,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		int ncand = 0;
 		constexpr int MANY = counting_algo<ALGO>() ? 24 : 4;	// from here on a candidate per lane pays
 		{
-			u64 nz = __ballot(mybits != 0);
+			u64 nz = ballot(mybits != 0);
 			while (nz != 0 && ncand <= MANY) {	// only "more than MANY?" matters
 				const int w = __builtin_ctzll(nz);
 				nz &= nz - 1;
@@ -1239,12 +1247,12 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			// The usual case, one seeded overlap: scored by one DPP row (pair of rows for long reads) without
 			// the candidate bookkeeping below.  An IUPAC ambiguity code in range falls through to it.
 			constexpr int ROWS1 = BPL == 4 ? 1 : 2;
-			const int w = __builtin_ctzll(__ballot(mybits != 0));
+			const int w = __builtin_ctzll(ballot(mybits != 0));
 			const unsigned m = (unsigned) __builtin_amdgcn_readlane((int) mybits, w);
 			const int ov = w * 32 + __builtin_ctz(m) + minov;
 			bool odd;
 			const double sc = score_sb_codes<ALGO, ROWS1>(P, L, flen, rlen, ov, lane < 16 * ROWS1, lane, odd);
-			if (__ballot(odd) == 0) {
+			if (ballot(odd) == 0) {
 				const double pr = lane_f64(sc, 0);
 				if (pr > best) {
 					best = pr;
@@ -1262,7 +1270,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			const int row = lane / (16 * ROWS);
 			int myov = 0;	// this row's candidate
 			int pending = 0;
-			u64 words = __ballot(mybits != 0);	// non-empty 32-candidate words, ascending
+			u64 words = ballot(mybits != 0);	// non-empty 32-candidate words, ascending
 			while (words != 0) {
 				const int w = __builtin_ctzll(words);
 				words &= words - 1;
@@ -1277,7 +1285,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 					if (pending == PER_STEP || (lastword && m == 0)) {
 						bool odd;
 						const double sc = score_sb_codes<ALGO, ROWS>(P, L, flen, rlen, myov, row < pending, lane, odd);
-						const bool slowstep = __ballot(odd) != 0;	// an nt that is neither A C G T nor N: base by base
+						const bool slowstep = ballot(odd) != 0;	// an nt that is neither A C G T nor N: base by base
 						for (int r = 0; r < pending; r++) {
 							const int ovr = __builtin_amdgcn_readlane(myov, 16 * ROWS * r);
 							const double pr = slowstep ? score_overlap<ALGO>(P, ltab, L, flen, rlen, ovr, lane) : lane_f64(sc, 16 * ROWS * r);
@@ -1296,7 +1304,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			// 64 at a time, one per lane, each lane summing its own candidate in reference order.
 			uint16_t *cand = reinterpret_cast<uint16_t *>(L.ps);
 			int total = 0;
-			u64 words = __ballot(mybits != 0);
+			u64 words = ballot(mybits != 0);
 			while (words != 0) {
 				const int w = __builtin_ctzll(words);
 				words &= words - 1;
@@ -1342,7 +1350,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			bool ambiguous = EXACT && P.score_scratch == nullptr;
 			if (!ambiguous) {
 				int last_ov = -1;
-				u64 words = __ballot(mybits != 0);
+				u64 words = ballot(mybits != 0);
 				while (words != 0) {
 					const int w = __builtin_ctzll(words);
 					words &= words - 1;
@@ -1387,7 +1395,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				best = P.qual_nn * (double) (flen + rlen);
 				bo = -1;
 				examined = 0;
-				u64 words = __ballot(mybits != 0);	// non-empty 32-candidate words, ascending
+				u64 words = ballot(mybits != 0);	// non-empty 32-candidate words, ascending
 				while (words != 0) {
 					const int w = __builtin_ctzll(words);
 					words &= words - 1;
@@ -1490,101 +1498,101 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		bool low_p = false;
 		double pmin = 0.0;	// every log-p is <= 0
 		const double qs0 = want_phred ? ltab[PAMD_LT_SCORE] : 0.0;
+		// The three loops are branch-free: a lane past the end of its range reads staged bytes it ignores, takes its
+		// log-p from a table slot that holds 0.0 (PAMD_LT_ZERO) and writes where a later loop writes again or, past the
+		// row's end, into the 64 entries of slack each staging array has.  Without exec-masked blocks the compiler can
+		// overlap the LDS round trips of consecutive rounds, which is what these loops wait for.
 		// forward-only bases (assembler.c:162-173)
+#pragma unroll 2
 		for (int j0 = 0; j0 < A; j0 += 64) {
 			const int j = j0 + lane;
 			const bool in = j < A;
-			unsigned nt = 1;
-			if (in) {
-				const unsigned e = L.F[j + fo];
-				nt = e & 0xFFu;
-				const double q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
-				L.nts[j] = (uint8_t) nt;
-				L.ps[j] = q;
-				if (post)
-					L.pidx[j] = (uint16_t) (PAMD_LT_SCORE + clampq(qual_of(e)));
-				if (!EXACT)
-					qacc += q;
-				// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
-				// it (checked over every breakpoint in tests/test_oracle_cpu.py), so the smallest phred of
-				// the row follows from "any p at or below qual_score[0]" and the smallest p above it
+			const unsigned e = L.F[j + fo];
+			const unsigned nt = e & 0xFFu;
+			const int qi = in ? PAMD_LT_SCORE + clampq(qual_of(e)) : PAMD_LT_ZERO;
+			const double q = ltab[qi];
+			L.nts[j] = (uint8_t) nt;
+			L.ps[j] = q;
+			if (post)
+				L.pidx[j] = (uint16_t) qi;
+			if (!EXACT)
+				qacc += q;
+			// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
+			// it (checked over every breakpoint in tests/test_oracle_cpu.py), so the smallest phred of
+			// the row follows from "any p at or below qual_score[0]" and the smallest p above it
+			if (want_phred) {
 				low_p |= q <= qs0;
 				pmin = (q > qs0 && q < pmin) ? q : pmin;
 			}
-			degen += __popcll(__ballot(in && __popc(nt) != 1));	// PANDA_NT_IS_DEGN
+			degen += __popcll(ballot(in) & ballot(__popc(nt) != 1));	// PANDA_NT_IS_DEGN
 		}
 		// overlapping bases (assembler.c:181-228)
+#pragma unroll 2
 		for (int i0 = 0; i0 < novl; i0 += 64) {
 			const int i = i0 + lane;
 			const bool in = i < novl;
-			unsigned nt = 1;
-			bool ismm = false;
-			if (in) {
-				const int fi = fo + A + i;
-				const int ri = rlen - i - 1 + wdf;
-				const unsigned ef = L.F[fi];
-				const unsigned er = L.R[ri];
-				const unsigned a = ef & 0xFFu, b = er & 0xFFu;
-				const int fq = qual_of(ef), rq = qual_of(er);
-				const bool match = (a & b) != 0;
-				ismm = !match;
-				const bool fmask = fi >= uf, rmask = ri >= ur;	// B-cliff
-				// one table read, its index chosen without a branch (slot 47 of the score block holds qual_nn)
-				const int cf = clampq(fq), cr = clampq(rq);
-				int qi;
-				if (ALGO == PAMD_ALGO_EA_UTIL) {	// algo_ea_util.c:58-67
-					qi = PAMD_LT_SCORE + (fq > rq ? cf : cr);
-				} else if (ALGO == PAMD_ALGO_FLASH) {	// algo_flash.c:63-80
-					int sc = cf - cr;
-					sc = sc < 0 ? -sc : sc;
-					sc = sc < 2 ? 2 : sc;
-					qi = PAMD_LT_SCORE + (match ? (fq > rq ? cf : cr) : sc);
-				} else if (ALGO == PAMD_ALGO_RDP_MLE) {	// algo_rdp_mle.c:29-41
-					qi = match ? PAMD_LT_SCORE + clampq(fq >= rq ? fq : rq) : PAMD_LT_C + cf * PAMD_NQ + cr;
-				} else {	// algo_simple_bayes.c:68-75, algo_pear.c:61-68, algo_uparse.c:68-75, algo_stitch.c:59-67
-					qi = (match ? PAMD_LT_A : PAMD_LT_B) + cf * PAMD_NQ + cr;
-				}
-				qi = rmask ? PAMD_LT_SCORE + cf : qi;	// B-cliff (assembler.c:192-207)
-				qi = fmask ? PAMD_LT_SCORE + (rmask ? 47 : cr) : qi;
-				const double q = ltab[qi];
-				nt = match ? (a & b) : (fq < rq ? b : a);	// assembler.c:212-220
-				L.nts[A + i] = (uint8_t) nt;
-				L.ps[A + i] = q;
-				if (post)
-					L.pidx[A + i] = (uint16_t) qi;
-				if (!EXACT)
-					qacc += q;
-				// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
-				// it (checked over every breakpoint in tests/test_oracle_cpu.py), so the smallest phred of
-				// the row follows from "any p at or below qual_score[0]" and the smallest p above it
+			const int fi = fo + A + i;
+			const int ri = in ? rlen - i - 1 + wdf : 0;
+			const unsigned ef = L.F[fi];
+			const unsigned er = L.R[ri];
+			const unsigned a = ef & 0xFFu, b = er & 0xFFu;
+			const int fq = qual_of(ef), rq = qual_of(er);
+			const bool match = (a & b) != 0;
+			const unsigned nt = match ? (a & b) : (fq < rq ? b : a);	// assembler.c:212-220
+			const bool fmask = fi >= uf, rmask = ri >= ur;	// B-cliff
+			// one table read, its index chosen without a branch (slot 47 of the score block holds qual_nn)
+			const int cf = clampq(fq), cr = clampq(rq);
+			int qi;
+			if (ALGO == PAMD_ALGO_EA_UTIL) {	// algo_ea_util.c:58-67
+				qi = PAMD_LT_SCORE + (fq > rq ? cf : cr);
+			} else if (ALGO == PAMD_ALGO_FLASH) {	// algo_flash.c:63-80
+				int sc = cf - cr;
+				sc = sc < 0 ? -sc : sc;
+				sc = sc < 2 ? 2 : sc;
+				qi = PAMD_LT_SCORE + (match ? (fq > rq ? cf : cr) : sc);
+			} else if (ALGO == PAMD_ALGO_RDP_MLE) {	// algo_rdp_mle.c:29-41
+				qi = match ? PAMD_LT_SCORE + clampq(fq >= rq ? fq : rq) : PAMD_LT_C + cf * PAMD_NQ + cr;
+			} else {	// algo_simple_bayes.c:68-75, algo_pear.c:61-68, algo_uparse.c:68-75, algo_stitch.c:59-67
+				qi = (match ? PAMD_LT_A : PAMD_LT_B) + cf * PAMD_NQ + cr;
+			}
+			qi = rmask ? PAMD_LT_SCORE + cf : qi;	// B-cliff (assembler.c:192-207)
+			qi = fmask ? PAMD_LT_SCORE + (rmask ? 47 : cr) : qi;
+			qi = in ? qi : PAMD_LT_ZERO;
+			const double q = ltab[qi];
+			L.nts[A + i] = (uint8_t) nt;
+			L.ps[A + i] = q;
+			if (post)
+				L.pidx[A + i] = (uint16_t) qi;
+			if (!EXACT)
+				qacc += q;
+			if (want_phred) {
 				low_p |= q <= qs0;
 				pmin = (q > qs0 && q < pmin) ? q : pmin;
 			}
-			mism += __popcll(__ballot(in && ismm));
-			degen += __popcll(__ballot(in && __popc(nt) != 1));
+			const u64 inmask = ballot(in);
+			mism += __popcll(inmask & ballot((a & b) == 0));
+			degen += __popcll(inmask & ballot(__popc(nt) != 1));
 		}
 		// reverse-only bases (assembler.c:231-243)
+#pragma unroll 2
 		for (int i0 = 0; i0 < Bn; i0 += 64) {
 			const int i = i0 + lane;
 			const bool in = i < Bn;
-			unsigned nt = 1;
-			if (in) {
-				const unsigned e = L.R[rlen - bo - i - 1];
-				nt = e & 0xFFu;
-				const double q = ltab[PAMD_LT_SCORE + clampq(qual_of(e))];
-				L.nts[A + novl + i] = (uint8_t) nt;
-				L.ps[A + novl + i] = q;
-				if (post)
-					L.pidx[A + novl + i] = (uint16_t) (PAMD_LT_SCORE + clampq(qual_of(e)));
-				if (!EXACT)
-					qacc += q;
-				// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
-				// it (checked over every breakpoint in tests/test_oracle_cpu.py), so the smallest phred of
-				// the row follows from "any p at or below qual_score[0]" and the smallest p above it
+			const unsigned e = L.R[in ? rlen - bo - i - 1 : 0];
+			const unsigned nt = e & 0xFFu;
+			const int qi = in ? PAMD_LT_SCORE + clampq(qual_of(e)) : PAMD_LT_ZERO;
+			const double q = ltab[qi];
+			L.nts[A + novl + i] = (uint8_t) nt;
+			L.ps[A + novl + i] = q;
+			if (post)
+				L.pidx[A + novl + i] = (uint16_t) qi;
+			if (!EXACT)
+				qacc += q;
+			if (want_phred) {
 				low_p |= q <= qs0;
 				pmin = (q > qs0 && q < pmin) ? q : pmin;
 			}
-			degen += __popcll(__ballot(in && __popc(nt) != 1));
+			degen += __popcll(ballot(in) & ballot(__popc(nt) != 1));
 		}
 		wave_sync();
 		int out_len = seqlen;	// bases the row keeps
@@ -1661,7 +1669,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				pmin = other < pmin ? other : pmin;
 			}
 			phmin = result_phred(ltab + PAMD_LT_SCORE, uni_f64(pmin));
-			if (__ballot(low_p) != 0 && phmin > 1)
+			if (ballot(low_p) != 0 && phmin > 1)
 				phmin = 1;
 			rec.phmin = out_len > 0 ? phmin : 127;	// an empty row passes any threshold
 		}
