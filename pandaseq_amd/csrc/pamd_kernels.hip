@@ -1154,7 +1154,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			const int sn = inr ? p - 8 : 0;	// no N among the 9 positions ending at p (misc.h:41)
 			const int sc = inr ? p - 7 : 0;
 			const unsigned nwin = __builtin_amdgcn_alignbit(L.fn[(sn >> 4) + 1], L.fn[sn >> 4], 2u * ((unsigned) sn & 15u)) & 0x2AAAAu;	// N = high bit of an entry
-			const unsigned kmer = __builtin_amdgcn_alignbit(L.fc[(sc >> 4) + 1], L.fc[sc >> 4], 2u * ((unsigned) sc & 15u)) & 0xFFFFu;
+			unsigned kmer = __builtin_amdgcn_alignbit(L.fc[(sc >> 4) + 1], L.fc[sc >> 4], 2u * ((unsigned) sc & 15u)) & 0xFFFFu;
+			asm volatile("" : "+v"(kmer));	// pins the second window read above the branch (the compiler sinks it into it otherwise)
 			if (inr && nwin == 0) {
 				const unsigned word = (kmer << 16) | (unsigned) p;
 				unsigned slot = kmer_hash(kmer, hshift) & ~1u;	// chains start on a slot pair (see the probe)
@@ -1170,7 +1171,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			const bool inr = p + 8 < rlen;	// p <= rlen - 9
 			const int sp = inr ? p : 0;	// no N among positions p .. p+8
 			const unsigned nwin = __builtin_amdgcn_alignbit(L.rn[(sp >> 4) + 1], L.rn[sp >> 4], 2u * ((unsigned) sp & 15u)) & 0x15555u;	// reverse entries are bit-swapped
-			const unsigned x = __builtin_amdgcn_alignbit(L.rc[(sp >> 4) + 1], L.rc[sp >> 4], 2u * ((unsigned) sp & 15u)) & 0xFFFFu;
+			unsigned x = __builtin_amdgcn_alignbit(L.rc[(sp >> 4) + 1], L.rc[sp >> 4], 2u * ((unsigned) sp & 15u)) & 0xFFFFu;
+			asm volatile("" : "+v"(x));	// as above
 			if (inr && nwin == 0) {
 				const unsigned kmer = __builtin_bitreverse32(x) >> 16;
 				const unsigned kk = kmer << 16;
