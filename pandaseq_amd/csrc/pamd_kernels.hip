@@ -99,6 +99,31 @@ __device__ __forceinline__ double lane_f64(double v, int src) {
 	return x.d;
 }
 
+// ---- wave-wide f64 sum without the LDS -----------------------------------------------------------------
+// __shfl_xor() is a ds_bpermute: an LDS round trip the wave parks on, six in a row for a butterfly.  DPP moves
+// stay in the vector ALU: xor 1 and xor 2 inside quads, then the mirrored half-row and row, give every lane
+// its row's sum (16 lanes); the four row sums are read back as scalars.  The order differs from the butterfly's,
+// which only callers that accept any order use.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+	union {
+		double d;
+		int i[2];
+	} x, y;
+	x.d = v;
+	y.i[0] = __builtin_amdgcn_update_dpp(0, x.i[0], CTRL, 0xF, 0xF, true);
+	y.i[1] = __builtin_amdgcn_update_dpp(0, x.i[1], CTRL, 0xF, 0xF, true);
+	return y.d;
+}
+
+__device__ __forceinline__ double wave_sum_any_order(double v) {
+	v += dpp_f64<0xB1>(v);	// quad_perm:[1,0,3,2]
+	v += dpp_f64<0x4E>(v);	// quad_perm:[2,3,0,1]
+	v += dpp_f64<0x141>(v);	// row_half_mirror
+	v += dpp_f64<0x140>(v);	// row_mirror
+	return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
+}
+
 __device__ __forceinline__ int clampq(int q) {	// PHREDCLAMP, prob.h:23
 	return q > 46 ? 46 : (q < 0 ? 0 : q);
 }
@@ -641,10 +666,9 @@ __device__ __forceinline__ double sum_terms_fast(const WaveLds &L, int ov, int l
 	double acc = 0.0;
 	for (int i = lane; i < ov; i += 64)
 		acc += L.ps[i];
-	for (int o = 32; o > 0; o >>= 1)
-		acc += __shfl_xor(acc, o);
+	acc = wave_sum_any_order(acc);
 	wave_sync();
-	return uni_f64(acc);
+	return acc;
 }
 
 // ---- overlap_probability, one candidate ------------------------------------------------------
@@ -1007,9 +1031,7 @@ __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64
 // so within 1e-9 of the threshold (or always, for `-a` in exact-sums mode, which has no group finish) the
 // three sums are redone in reference order from the staged row (assembler.c:171,226,236,244)
 __device__ __forceinline__ double quality_sum(double qacc) {	// the any-order sum over the wave
-	for (int o = 32; o > 0; o >>= 1)
-		qacc += __shfl_xor(qacc, o);
-	return uni_f64(qacc);
+	return wave_sum_any_order(qacc);
 }
 
 __device__ __forceinline__ double fast_quality(const WaveLds &L, double qacc, double threshold, int len, int seqlen, int A, int novl, bool always_exact, int lane) {
