@@ -1679,12 +1679,20 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		}
 		// the row leaves LDS in full 16-byte stores (16 nt or 2 log-p per lane); rows are 16-base aligned
 		if (store) {
+			// the LDS reads are unconditional and come first, two rounds of log-p at a time, so that one wait covers
+			// them all; only the stores are predicated (a read past the row's end returns staged bytes nobody keeps)
+			const uint4 nt16 = reinterpret_cast<const uint4 *>(L.nts)[lane];
+			const double2 *src = reinterpret_cast<const double2 *>(L.ps);
+			double2 *dst = reinterpret_cast<double2 *>(row_p);
 			if (lane * 16 < out_len)
-				reinterpret_cast<uint4 *>(row_nt)[lane] = reinterpret_cast<const uint4 *>(L.nts)[lane];
-			for (int j0 = 0; j0 < out_len; j0 += 128) {
-				const int j = j0 + lane * 2;
-				if (j < out_len)
-					reinterpret_cast<double2 *>(row_p)[j >> 1] = reinterpret_cast<const double2 *>(L.ps)[j >> 1];
+				reinterpret_cast<uint4 *>(row_nt)[lane] = nt16;
+			for (int j0 = 0; j0 < out_len; j0 += 256) {
+				const int ja = j0 + lane * 2, jb = ja + 128;
+				const double2 pa = src[ja >> 1], pb = src[jb >> 1];
+				if (ja < out_len)
+					dst[ja >> 1] = pa;
+				if (jb < out_len)
+					dst[jb >> 1] = pb;
 			}
 		}
 		if (want_phred) {
