@@ -1522,23 +1522,17 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		bool low_p = false;
 		double pmin = 0.0;	// every log-p is <= 0
 		const double qs0 = want_phred ? ltab[PAMD_LT_SCORE] : 0.0;
-		// The three loops are branch-free: a lane past the end of its range reads staged bytes it ignores, takes its
-		// log-p from a table slot that holds 0.0 (PAMD_LT_ZERO) and writes where a later loop writes again or, past the
-		// row's end, into the 64 entries of slack each staging array has.  Without exec-masked blocks the compiler can
-		// overlap the LDS round trips of consecutive rounds, which is what these loops wait for.
-		// forward-only bases (assembler.c:162-173)
-#pragma unroll 2
-		for (int j0 = 0; j0 < A; j0 += 64) {
-			const int j = j0 + lane;
-			const bool in = j < A;
-			const unsigned e = L.F[j + fo];
-			const unsigned nt = e & 0xFFu;
-			const int qi = in ? PAMD_LT_SCORE + clampq(qual_of(e)) : PAMD_LT_ZERO;
-			const double q = ltab[qi];
-			L.nts[j] = (uint8_t) nt;
-			L.ps[j] = q;
+		// The merge is branch-free: a lane past the end of its range reads staged bytes it ignores, takes its log-p
+		// from a table slot that holds 0.0 (PAMD_LT_ZERO) and writes where a later range writes again or, past the
+		// row's end, into the 64 entries of slack each staging array has.  Two rounds of 64 bases are in flight
+		// at a time, written out in the order reads, table reads, writes: LDS operations complete in order and the
+		// compiler keeps a read behind an earlier write it cannot tell apart, so this order is what lets one wait
+		// cover both rounds' round trips (the wave is parked on those waits for half its time).
+		auto put_base = [&](int at, unsigned nt, int qi, double q) {	// one merged base into the staged row
+			L.nts[at] = (uint8_t) nt;
+			L.ps[at] = q;
 			if (post)
-				L.pidx[j] = (uint16_t) qi;
+				L.pidx[at] = (uint16_t) qi;
 			if (!EXACT)
 				qacc += q;
 			// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
@@ -1548,21 +1542,38 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				low_p |= q <= qs0;
 				pmin = (q > qs0 && q < pmin) ? q : pmin;
 			}
-			degen += __popcll(ballot(in) & ballot(__popc(nt) != 1));	// PANDA_NT_IS_DEGN
-		}
+		};
+		// bases of one read only: forward-only (assembler.c:162-173) at [0, A), reverse-only (assembler.c:231-243)
+		// at [A + novl, seqlen); `entry(i)` is the staged read position of the i-th of them
+		auto single_read = [&](const uint16_t *S, int n, int at0, auto entry) {
+			int j0 = 0;
+			for (; j0 + 64 < n; j0 += 128) {
+				const int ia = j0 + lane, ib = ia + 64;
+				const bool inb = ib < n;
+				const unsigned ea = S[entry(ia)], eb = S[inb ? entry(ib) : 0];
+				const int qia = PAMD_LT_SCORE + clampq(qual_of(ea)), qib = inb ? PAMD_LT_SCORE + clampq(qual_of(eb)) : PAMD_LT_ZERO;
+				const double qa = ltab[qia], qb = ltab[qib];
+				put_base(at0 + ia, ea & 0xFFu, qia, qa);
+				put_base(at0 + ib, eb & 0xFFu, qib, qb);
+				degen += __popcll(ballot(__popc(ea & 0xFFu) != 1)) + __popcll(ballot(inb) & ballot(__popc(eb & 0xFFu) != 1));	// PANDA_NT_IS_DEGN
+			}
+			if (j0 < n) {
+				const int i = j0 + lane;
+				const bool in = i < n;
+				const unsigned e = S[in ? entry(i) : 0];
+				const int qi = in ? PAMD_LT_SCORE + clampq(qual_of(e)) : PAMD_LT_ZERO;
+				const double q = ltab[qi];
+				put_base(at0 + i, e & 0xFFu, qi, q);
+				degen += __popcll(ballot(in) & ballot(__popc(e & 0xFFu) != 1));
+			}
+		};
+		single_read(L.F, A, 0, [&](int j) { return j + fo; });
 		// overlapping bases (assembler.c:181-228)
-#pragma unroll 2
-		for (int i0 = 0; i0 < novl; i0 += 64) {
-			const int i = i0 + lane;
-			const bool in = i < novl;
-			const int fi = fo + A + i;
-			const int ri = in ? rlen - i - 1 + wdf : 0;
-			const unsigned ef = L.F[fi];
-			const unsigned er = L.R[ri];
+		auto overlap_index = [&](unsigned ef, unsigned er, int fi, int ri, bool in, unsigned &nt) -> int {
 			const unsigned a = ef & 0xFFu, b = er & 0xFFu;
 			const int fq = qual_of(ef), rq = qual_of(er);
 			const bool match = (a & b) != 0;
-			const unsigned nt = match ? (a & b) : (fq < rq ? b : a);	// assembler.c:212-220
+			nt = match ? (a & b) : (fq < rq ? b : a);	// assembler.c:212-220
 			const bool fmask = fi >= uf, rmask = ri >= ur;	// B-cliff
 			// one table read, its index chosen without a branch (slot 47 of the score block holds qual_nn)
 			const int cf = clampq(fq), cr = clampq(rq);
@@ -1581,43 +1592,41 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			}
 			qi = rmask ? PAMD_LT_SCORE + cf : qi;	// B-cliff (assembler.c:192-207)
 			qi = fmask ? PAMD_LT_SCORE + (rmask ? 47 : cr) : qi;
-			qi = in ? qi : PAMD_LT_ZERO;
-			const double q = ltab[qi];
-			L.nts[A + i] = (uint8_t) nt;
-			L.ps[A + i] = q;
-			if (post)
-				L.pidx[A + i] = (uint16_t) qi;
-			if (!EXACT)
-				qacc += q;
-			if (want_phred) {
-				low_p |= q <= qs0;
-				pmin = (q > qs0 && q < pmin) ? q : pmin;
+			return in ? qi : PAMD_LT_ZERO;
+		};
+		{
+			int i0 = 0;
+			for (; i0 + 64 < novl; i0 += 128) {
+				const int ia = i0 + lane, ib = ia + 64;
+				const bool inb = ib < novl;
+				const int fia = fo + A + ia, fib = fia + 64;
+				const int ria = rlen - ia - 1 + wdf, rib = inb ? ria - 64 : 0;
+				const unsigned efa = L.F[fia], era = L.R[ria], efb = L.F[fib], erb = L.R[rib];
+				unsigned nta, ntb;
+				const int qia = overlap_index(efa, era, fia, ria, true, nta), qib = overlap_index(efb, erb, fib, rib, inb, ntb);
+				const double qa = ltab[qia], qb = ltab[qib];
+				put_base(A + ia, nta, qia, qa);
+				put_base(A + ib, ntb, qib, qb);
+				const u64 inmask = ballot(inb);
+				mism += __popcll(ballot((efa & era & 0xFFu) == 0)) + __popcll(inmask & ballot((efb & erb & 0xFFu) == 0));
+				degen += __popcll(ballot(__popc(nta) != 1)) + __popcll(inmask & ballot(__popc(ntb) != 1));
 			}
-			const u64 inmask = ballot(in);
-			mism += __popcll(inmask & ballot((a & b) == 0));
-			degen += __popcll(inmask & ballot(__popc(nt) != 1));
-		}
-		// reverse-only bases (assembler.c:231-243)
-#pragma unroll 2
-		for (int i0 = 0; i0 < Bn; i0 += 64) {
-			const int i = i0 + lane;
-			const bool in = i < Bn;
-			const unsigned e = L.R[in ? rlen - bo - i - 1 : 0];
-			const unsigned nt = e & 0xFFu;
-			const int qi = in ? PAMD_LT_SCORE + clampq(qual_of(e)) : PAMD_LT_ZERO;
-			const double q = ltab[qi];
-			L.nts[A + novl + i] = (uint8_t) nt;
-			L.ps[A + novl + i] = q;
-			if (post)
-				L.pidx[A + novl + i] = (uint16_t) qi;
-			if (!EXACT)
-				qacc += q;
-			if (want_phred) {
-				low_p |= q <= qs0;
-				pmin = (q > qs0 && q < pmin) ? q : pmin;
+			if (i0 < novl) {
+				const int i = i0 + lane;
+				const bool in = i < novl;
+				const int fi = fo + A + i;
+				const int ri = in ? rlen - i - 1 + wdf : 0;
+				const unsigned ef = L.F[fi], er = L.R[ri];
+				unsigned nt;
+				const int qi = overlap_index(ef, er, fi, ri, in, nt);
+				const double q = ltab[qi];
+				put_base(A + i, nt, qi, q);
+				const u64 inmask = ballot(in);
+				mism += __popcll(inmask & ballot((ef & er & 0xFFu) == 0));
+				degen += __popcll(inmask & ballot(__popc(nt) != 1));
 			}
-			degen += __popcll(ballot(in) & ballot(__popc(nt) != 1));
 		}
+		single_read(L.R, Bn, A + novl, [&](int i) { return rlen - bo - i - 1; });
 		wave_sync();
 		int out_len = seqlen;	// bases the row keeps
 		if (post) {
