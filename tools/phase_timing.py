@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=1)
 ap.add_argument("--pairs", type=int, default=4_000_000)
+ap.add_argument("--only", choices=["all", "slow", "ordinary"], default="all", help="fill the batch with copies of the pairs that scan every overlap / of the others")
 args = ap.parse_args()
 prof = os.path.join(ROOT, "pandaseq_amd", "libpandaseq_amd_phase.so")
 csrc = os.path.join(ROOT, "pandaseq_amd", "csrc")
@@ -34,6 +35,15 @@ outs = pa.alloc_outputs(n, n * 420 + (1 << 27), "cuda:0")
 b = pa.DeviceBatch(n=n, fwd=f, rev=r, flen=fl, rlen=rl, **outs)
 asm.assemble_device(b)
 torch.cuda.synchronize()
+if args.only != "all":
+    slow = torch.from_numpy(b.results_numpy()["slow"] != 0).cuda()
+    src = (slow if args.only == "slow" else ~slow).nonzero().flatten()
+    idx = src[torch.arange(n, device="cuda") % src.numel()]
+    f, r, fl, rl = f[idx].contiguous(), r[idx].contiguous(), fl[idx].contiguous(), rl[idx].contiguous()
+    b = pa.DeviceBatch(n=n, fwd=f, rev=r, flen=fl, rlen=rl, **outs)
+    b.cursor.zero_(); b.counters.zero_()
+    asm.assemble_device(b)
+    torch.cuda.synchronize()
 buf = np.zeros(10, dtype=np.uint64)
 _lib.check(_lib.lib().pamd_debug_phase_cycles(asm._h, buf.ctypes.data, 1))
 b.cursor.zero_(); b.counters.zero_()
