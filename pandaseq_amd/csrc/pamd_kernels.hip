@@ -1034,9 +1034,12 @@ __device__ __forceinline__ double quality_sum(double qacc) {	// the any-order su
 	return wave_sum_any_order(qacc);
 }
 
-__device__ __forceinline__ double fast_quality(const WaveLds &L, double qacc, double threshold, int len, int seqlen, int A, int novl, bool always_exact, int lane) {
+// `row`: the pair's log-p row -- staged in LDS (`-a`), or the one this wave has just written to HBM (plain cached loads:
+// wave_sync() retires the stores, and a CU's vector L1 is coherent for its own stores, as in finish_group())
+__device__ __forceinline__ double fast_quality(const double *row, double qacc, double threshold, int len, int seqlen, int A, int novl, bool always_exact, int lane) {
 	double quality = quality_sum(qacc) / (double) len;
 	if (always_exact || fabs(quality - threshold) <= 1e-9) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// a row in HBM: its stores must have reached L2
 		wave_sync();
 		double acc = 0.0;
 		int lo = 0, hi = 0;
@@ -1050,7 +1053,7 @@ __device__ __forceinline__ double fast_quality(const WaveLds &L, double qacc, do
 			hi = A + novl;
 		}
 		for (int j = lo; j < hi; j++)
-			acc += L.ps[j];
+			acc += row[j];
 		const double fq = lane_f64(acc, 0), rq = lane_f64(acc, 1), oq = lane_f64(acc, 2);
 		quality = (fq + rq + oq) / (double) len;	// assembler.c:244
 	}
@@ -1528,11 +1531,17 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		// at a time, written out in the order reads, table reads, writes: LDS operations complete in order and the
 		// compiler keeps a read behind an earlier write it cannot tell apart, so this order is what lets one wait
 		// cover both rounds' round trips (the wave is parked on those waits for half its time).
-		auto put_base = [&](int at, unsigned nt, int qi, double q) {	// one merged base into the staged row
+		// The log-p goes straight to the pair's row in HBM (8 bytes per lane, 512 contiguous bytes per round) unless
+		// the row is still to be cut (`-a`), which needs it staged; the nt bytes are staged either way and leave
+		// in 16-byte stores.  `in`: this lane's base exists (always true for the first round of a pair of rounds).
+		auto put_base = [&](int at, unsigned nt, int qi, double q, bool in) {	// one merged base
 			L.nts[at] = (uint8_t) nt;
-			L.ps[at] = q;
-			if (post)
+			if (post) {
+				L.ps[at] = q;
 				L.pidx[at] = (uint16_t) qi;
+			} else if (store && in) {
+				row_p[at] = q;
+			}
 			if (!EXACT)
 				qacc += q;
 			// panda_result_phred (nt.c:126-150) is 1 for p <= qual_score[0] and non-decreasing above
@@ -1553,8 +1562,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const unsigned ea = S[entry(ia)], eb = S[inb ? entry(ib) : 0];
 				const int qia = PAMD_LT_SCORE + clampq(qual_of(ea)), qib = inb ? PAMD_LT_SCORE + clampq(qual_of(eb)) : PAMD_LT_ZERO;
 				const double qa = ltab[qia], qb = ltab[qib];
-				put_base(at0 + ia, ea & 0xFFu, qia, qa);
-				put_base(at0 + ib, eb & 0xFFu, qib, qb);
+				put_base(at0 + ia, ea & 0xFFu, qia, qa, true);
+				put_base(at0 + ib, eb & 0xFFu, qib, qb, inb);
 				degen += __popcll(ballot(__popc(ea & 0xFFu) != 1)) + __popcll(ballot(inb) & ballot(__popc(eb & 0xFFu) != 1));	// PANDA_NT_IS_DEGN
 			}
 			if (j0 < n) {
@@ -1563,7 +1572,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const unsigned e = S[in ? entry(i) : 0];
 				const int qi = in ? PAMD_LT_SCORE + clampq(qual_of(e)) : PAMD_LT_ZERO;
 				const double q = ltab[qi];
-				put_base(at0 + i, e & 0xFFu, qi, q);
+				put_base(at0 + i, e & 0xFFu, qi, q, in);
 				degen += __popcll(ballot(in) & ballot(__popc(e & 0xFFu) != 1));
 			}
 		};
@@ -1605,8 +1614,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				unsigned nta, ntb;
 				const int qia = overlap_index(efa, era, fia, ria, true, nta), qib = overlap_index(efb, erb, fib, rib, inb, ntb);
 				const double qa = ltab[qia], qb = ltab[qib];
-				put_base(A + ia, nta, qia, qa);
-				put_base(A + ib, ntb, qib, qb);
+				put_base(A + ia, nta, qia, qa, true);
+				put_base(A + ib, ntb, qib, qb, inb);
 				const u64 inmask = ballot(inb);
 				mism += __popcll(ballot((efa & era & 0xFFu) == 0)) + __popcll(inmask & ballot((efb & erb & 0xFFu) == 0));
 				degen += __popcll(ballot(__popc(nta) != 1)) + __popcll(inmask & ballot(__popc(ntb) != 1));
@@ -1620,7 +1629,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				unsigned nt;
 				const int qi = overlap_index(ef, er, fi, ri, in, nt);
 				const double q = ltab[qi];
-				put_base(A + i, nt, qi, q);
+				put_base(A + i, nt, qi, q, in);
 				const u64 inmask = ballot(in);
 				mism += __popcll(inmask & ballot((ef & er & 0xFFu) == 0));
 				degen += __popcll(inmask & ballot(__popc(nt) != 1));
@@ -1632,7 +1641,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		if (post) {
 			// ---- `-a`: find the primers in the merged sequence and cut them off it (assembler.c:300-333) ----
 			if (!EXACT)
-				quality_fast = fast_quality(L, qacc, P.threshold, len, seqlen, A, novl, P.exact_sums != 0, lane);	// needs the whole row: before it is cut
+				quality_fast = fast_quality(L.ps, qacc, P.threshold, len, seqlen, A, novl, P.exact_sums != 0, lane);	// needs the whole row: before it is cut
 			int pfo = P.ftrim, pro = P.rtrim;
 			if (P.fprimer_len > 0) {
 				const int r = primer_offset_result(P, L, seqlen, lprimers, P.fprimer_len, false, lane);
@@ -1695,7 +1704,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			double2 *dst = reinterpret_cast<double2 *>(row_p);
 			if (lane * 16 < out_len)
 				reinterpret_cast<uint4 *>(row_nt)[lane] = nt16;
-			for (int j0 = 0; j0 < out_len; j0 += 256) {
+			for (int j0 = 0; post && j0 < out_len; j0 += 256) {
 				const int ja = j0 + lane * 2, jb = ja + 128;
 				const double2 pa = src[ja >> 1], pb = src[jb >> 1];
 				if (ja < out_len)
@@ -1720,8 +1729,9 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			quality_fast = quality_sum(qacc);	// divided by len in finish64() ...
 			// ... unless the quotient would land within 1e-9 of the LOWQ threshold (tested without dividing):
 			// then the three sums are redone here, in reference order, from the staged row
-			if (fabs(quality_fast - P.threshold * (double) len) <= 1e-9 * (double) len) {
-				quality_fast = fast_quality(L, qacc, P.threshold, len, seqlen, A, novl, true, lane);
+			// (a row the arena had no room for was not written: the launch reports the overflow and its results are void)
+			if (store && fabs(quality_fast - P.threshold * (double) len) <= 1e-9 * (double) len) {
+				quality_fast = fast_quality(row_p, qacc, P.threshold, len, seqlen, A, novl, true, lane);
 				quality_final_flag = true;
 			}
 		}
