@@ -467,22 +467,30 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	// the merge loops are branch-free: up to 63 lanes past the row's end write into slack (pamd_kernels.hip)
 	p.w_nt = o;
 	o += mmax + 64u;
-	p.w_p = o;
-	o += (mmax * 8u > 2048u ? mmax * 8u : 2048u) + 64u * 8u;
-	p.w_pidx = o;
-	if (a->post_primers)
-		o += mmax * 2u + 64u * 2u;
-	p.lds_wave_bytes = up16(o);
+	// w_p: the k-mer table while seeding; then the pear / rdp_mle per-base terms of a candidate (up to mmax of them)
+	// or a u16 candidate list; with `-a` also the merged row's log-p (+ slack), which otherwise goes straight to HBM
 	{
-		const uint32_t region = (mmax * 8u > 2048u ? mmax * 8u : 2048u);
+		const uint32_t row = (mmax * 8u > 2048u ? mmax * 8u : 2048u);
 		uint32_t slots = 512, shift = 23;
-		while (slots * 2u * 4u <= region && slots < 2048u) {
+		while (slots * 2u * 4u <= row && slots < 2048u) {
 			slots *= 2u;
 			shift--;
 		}
 		p.hash_slots = slots;
 		p.hash_shift = shift;
+		const bool counting = a->algo != PAMD_ALGO_PEAR && a->algo != PAMD_ALGO_RDP_MLE;
+		uint32_t region = slots * 4u > 2048u ? slots * 4u : 2048u;
+		if (a->post_primers)
+			region = row + 64u * 8u;
+		else if (!counting)
+			region = row;
+		p.w_p = o;
+		o += region;
 	}
+	p.w_pidx = o;
+	if (a->post_primers)
+		o += mmax * 2u + 64u * 2u;
+	p.lds_wave_bytes = up16(o);
 
 	int waves = (int) ((LDS_LIMIT - p.lds_wave_off) / p.lds_wave_bytes);
 	if (waves > MAX_WAVES_PER_WG)
