@@ -162,6 +162,31 @@ def test_assembler_settings(built, settings, sums):
         compare_counters(b.counters_dict(), o[3])
 
 
+def test_threshold_on_a_pairs_own_quality(built, sums):
+    """The LOWQ verdict when the threshold IS a pair's quality (assembler.c:334: quality < threshold).  In fast-sums
+    mode this is the case the kernel re-sums in the reference's order, reading the log-p row it has just written to
+    HBM; the threshold goes through exp() and the setter's log(), so it lands within an ulp or two of the quality,
+    on either side of it."""
+    import math
+
+    from pandaseq_amd import synth
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = adversarial_pairs(spec, 3000, seed=11)
+    o0 = _oracle("simple_bayesian", fwd, rev, flen, rlen)
+    ok = np.nonzero(o0[0]["status"] == 0)[0]
+    flips = 0
+    for k in ok[[3, len(ok) // 3, len(ok) // 2, len(ok) - 5]]:
+        for nudge in (0.0, 1e-15, -1e-15):
+            t = math.exp(float(o0[0]["quality"][k])) * (1.0 + nudge)
+            asm = _asm_for("simple_bayesian", exact=sums == "exact", threshold=t)
+            b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
+            o = _oracle("simple_bayesian", fwd, rev, flen, rlen, threshold=t)
+            compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+            compare_counters(b.counters_dict(), o[3])
+            flips += int(o[0]["status"][k] != 0)
+    assert 0 < flips < 12, "the chosen pairs must land on both sides of their threshold for the test to mean anything"
+
+
 def test_algorithm_parameters(built):
     import math
 
