@@ -1259,7 +1259,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			}
 		}
 		bool per_lane_done = false;
-		if (counting_algo<ALGO>() && !EXACT && ncand > MANY) {
+		if (counting_algo<ALGO>() && ncand > MANY) {
 			// Many candidates: 64 at a time, one per lane (scan_many_counting).  An IUPAC ambiguity code inside
 			// a compared range abandons that path: the pair is then scanned by the step path below.
 			const ManyScan ms = scan_many_counting<ALGO>(L.fc, L.rc, L.fn, L.rn, reinterpret_cast<uint16_t *>(L.ps), mybits, minov, flen, rlen, P.qual_nn, P.sb_pmatch, P.sb_pmismatch, best, lane);
