@@ -1109,8 +1109,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		}
 		// previous pair's readers are done with this wave's LDS
 		wave_sync();
-		const int uf = stage_read<true, BPL, EXACT>(fregs, flen, lane, L.F, L.fc, L.fn);
-		const int ur = stage_read<false, BPL, EXACT>(rregs, rlen, lane, L.R, L.rc, L.rn);
+		const int uf = stage_read<true, BPL, true>(fregs, flen, lane, L.F, L.fc, L.fn);
+		const int ur = stage_read<false, BPL, true>(rregs, rlen, lane, L.R, L.rc, L.rn);
 		// clear the k-mer table (aliases the log-p staging area) and the candidate bitmap
 		for (unsigned s4 = lane; s4 < P.hash_slots / 4; s4 += 64)
 			reinterpret_cast<uint4 *>(L.hash)[s4] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
