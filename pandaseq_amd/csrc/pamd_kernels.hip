@@ -1066,6 +1066,18 @@ struct Carry {
 	uint4 f, r;
 };
 
+// Pins the carried registers (the compiler must treat them as written here).  With four bases per lane a row is two
+// words per lane: the upper two words of each uint4 are constant zero and are left to the compiler.
+template <int BPL>
+__device__ __forceinline__ void settle_carry(Carry &c) {
+	if (BPL == 8) {
+		asm volatile("" : "+v"(c.flen_v), "+v"(c.rlen_v), "+v"(c.f.x), "+v"(c.f.y), "+v"(c.f.z), "+v"(c.f.w), "+v"(c.r.x), "+v"(c.r.y), "+v"(c.r.z), "+v"(c.r.w));
+	} else {
+		asm volatile("" : "+v"(c.flen_v), "+v"(c.rlen_v), "+v"(c.f.x), "+v"(c.f.y), "+v"(c.r.x), "+v"(c.r.y));
+		c.f.z = c.f.w = c.r.z = c.r.w = 0u;
+	}
+}
+
 // ---- one pair: everything up to its parked record ----------------------------------------------
 template <int ALGO, bool PHRED, int BPL, bool EXACT, bool POST>
 __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, const uint8_t *lprimers, unsigned *lctr, const WaveLds &L, WaveArena &arena, PendRec *slot_rec, Pend64 &pd, int slot_idx, unsigned wave_gid, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt
@@ -1453,7 +1465,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		// and stores in one in-order queue, so waiting for the (long finished) loads here is free,
 		// while waiting for them at the top of the next iteration would also wait for the stores.
 		cur = nxt;
-		asm volatile("" : "+v"(cur.flen_v), "+v"(cur.rlen_v), "+v"(cur.f.x), "+v"(cur.f.y), "+v"(cur.f.z), "+v"(cur.f.w), "+v"(cur.r.x), "+v"(cur.r.y), "+v"(cur.r.z), "+v"(cur.r.w));
+		settle_carry<BPL>(cur);
 		rotated = true;
 
 		if (score_parked > 0) {
@@ -1738,7 +1750,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 	} while (0);
 	if (!rotated) {
 		cur = nxt;
-		asm volatile("" : "+v"(cur.flen_v), "+v"(cur.rlen_v), "+v"(cur.f.x), "+v"(cur.f.y), "+v"(cur.f.z), "+v"(cur.f.w), "+v"(cur.r.x), "+v"(cur.r.y), "+v"(cur.r.z), "+v"(cur.r.w));
+		settle_carry<BPL>(cur);
 	}
 	rec.st = status;
 	PH_MARK_END(7);
@@ -1808,7 +1820,7 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	cur.r = load_read<BPL>(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
 	// settle the prologue loads before the loop so that, at the loop header, the carried registers
 	// are known-ready on both incoming edges
-	asm volatile("" : "+v"(cur.flen_v), "+v"(cur.rlen_v), "+v"(cur.f.x), "+v"(cur.f.y), "+v"(cur.f.z), "+v"(cur.f.w), "+v"(cur.r.x), "+v"(cur.r.y), "+v"(cur.r.z), "+v"(cur.r.w));
+	settle_carry<BPL>(cur);
 	int npend = 0;
 	Pend64 pd = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
 	u64 group_first = pair;	// fast sums: the pair parked in lane 0 of the pending registers
