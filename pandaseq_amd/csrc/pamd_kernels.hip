@@ -185,7 +185,7 @@ __device__ __forceinline__ constexpr unsigned lut_word(int w) {
 	return v;
 }
 
-template <bool FORWARD, int BPL, bool BYTEWISE>
+template <bool FORWARD, int BPL>
 __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint16_t *dst, uint32_t *codes, uint32_t *nmap) {
 	if (lane * BPL < len) {
 		if (BPL == 8)
@@ -204,9 +204,8 @@ __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint
 	// reverse read stores 2 instead of 1 (entries are bit-swapped like its codes)
 	constexpr unsigned SPECIAL_F = 0xD5545441u, SPECIAL_R = 0xEAA8A882u;	// 16 two-bit entries, nt 0 in the low bits
 	constexpr unsigned CODE_OF = FORWARD ? 0x00030210u : 0x00030120u;
-	if (BPL == 4 && BYTEWISE) {
-		// four bases at once (used where it does not push the kernel over its register budget: DESIGN.md "the
-		// register cliff"): the nt and quality bytes are gathered into one word each, the two 2-bit
+	if (BPL == 4) {
+		// four bases at once: the nt and quality bytes are gathered into one word each, the two 2-bit
 		// maps come out of ONE 16-entry byte table (code | special << 2) read with v_perm_b32, and
 		// "quality == 2" is a zero-byte test
 		const unsigned n4 = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u) & 0x0F0F0F0Fu;
@@ -1121,8 +1120,8 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		}
 		// previous pair's readers are done with this wave's LDS
 		wave_sync();
-		const int uf = stage_read<true, BPL, true>(fregs, flen, lane, L.F, L.fc, L.fn);
-		const int ur = stage_read<false, BPL, true>(rregs, rlen, lane, L.R, L.rc, L.rn);
+		const int uf = stage_read<true, BPL>(fregs, flen, lane, L.F, L.fc, L.fn);
+		const int ur = stage_read<false, BPL>(rregs, rlen, lane, L.R, L.rc, L.rn);
 		// clear the k-mer table (aliases the log-p staging area) and the candidate bitmap
 		for (unsigned s4 = lane; s4 < P.hash_slots / 4; s4 += 64)
 			reinterpret_cast<uint4 *>(L.hash)[s4] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
