@@ -1217,8 +1217,12 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				// positions of this k-mer, which are the reference's first two.  entry ^ (kmer << 16) is the
 				// bare position (< 0x10000) for an entry of this k-mer and >= 0x10000 for any other k-mer;
 				// an empty slot gives >= 0xFFFF, above every real position, so plain unsigned minima do it.
-				unsigned m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
-				bool more = true;
+				// first step peeled: with nothing found yet the two-smallest network is one min and one max
+				const uint2 w0 = *reinterpret_cast<const uint2 *>(&L.hash[slot]);
+				unsigned m1 = (w0.x ^ kk) < (w0.y ^ kk) ? (w0.x ^ kk) : (w0.y ^ kk);
+				unsigned m2 = (w0.x ^ kk) < (w0.y ^ kk) ? (w0.y ^ kk) : (w0.x ^ kk);
+				slot = (slot + 2) & hmask;
+				bool more = w0.x != HASH_EMPTY && w0.y != HASH_EMPTY;
 				while (more) {
 					const uint2 w = *reinterpret_cast<const uint2 *>(&L.hash[slot]);
 					const unsigned x0 = w.x ^ kk, x1 = w.y ^ kk;
