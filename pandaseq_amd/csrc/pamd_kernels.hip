@@ -1188,9 +1188,9 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			const bool inr = p >= 8 && p < flen;
 			// both windows are read unconditionally (clamped) so the two LDS round trips overlap
 			const int sn = inr ? p - 8 : 0;	// no N among the 9 positions ending at p (misc.h:41)
-			const int sc = inr ? p - 7 : 0;
 			const unsigned nwin = __builtin_amdgcn_alignbit(L.fn[(sn >> 4) + 1], L.fn[sn >> 4], 2u * ((unsigned) sn & 15u)) & 0x2AAAAu;	// N = high bit of an entry
-			unsigned kmer = __builtin_amdgcn_alignbit(L.fc[(sc >> 4) + 1], L.fc[sc >> 4], 2u * ((unsigned) sc & 15u)) & 0xFFFFu;
+			// the k-mer is the eight codes ending at p: entries 1..8 of the same nine-entry window (one address computation)
+			unsigned kmer = (__builtin_amdgcn_alignbit(L.fc[(sn >> 4) + 1], L.fc[sn >> 4], 2u * ((unsigned) sn & 15u)) >> 2) & 0xFFFFu;
 			asm volatile("" : "+v"(kmer));	// pins the second window read above the branch (the compiler sinks it into it otherwise)
 			if (inr && nwin == 0) {
 				const unsigned word = (kmer << 16) | (unsigned) p;
