@@ -1194,9 +1194,15 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			asm volatile("" : "+v"(kmer));	// pins the second window read above the branch (the compiler sinks it into it otherwise)
 			if (inr && nwin == 0) {
 				const unsigned word = (kmer << 16) | (unsigned) p;
-				unsigned slot = kmer_hash(kmer, hshift) & ~1u;	// chains start on a slot pair (see the probe)
-				while (atomicCAS(&L.hash[slot], HASH_EMPTY, word) != HASH_EMPTY)
-					slot = (slot + 1) & hmask;
+				// A chain starts on the k-mer's slot PAIR (the probe reads pairs); which of the pair's two slots is tried
+				// first is one more hash bit, so two lanes that meet in a pair collide only half the time; then the
+				// other slot of the pair, then slot by slot onward.
+				unsigned slot = kmer_hash(kmer, hshift);
+				if (atomicCAS(&L.hash[slot], HASH_EMPTY, word) != HASH_EMPTY && atomicCAS(&L.hash[slot ^ 1u], HASH_EMPTY, word) != HASH_EMPTY) {
+					slot = ((slot | 1u) + 1u) & hmask;
+					while (atomicCAS(&L.hash[slot], HASH_EMPTY, word) != HASH_EMPTY)
+						slot = (slot + 1) & hmask;
+				}
 			}
 		}
 		wave_sync();
