@@ -463,7 +463,8 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.w_bits = o;
 	o += 128;
 	p.w_pend = o;
-	o += 8 * 80;	// GROUP parked records of 80 bytes
+	if (a->exact_sums && !a->post_primers)	// parked records of 80 bytes: only the exact-sums kernels park pairs in LDS (finish_group);
+		o += ((a->algo == PAMD_ALGO_PEAR || a->algo == PAMD_ALGO_RDP_MLE) ? 8 : 16) * 80;	// group_size<ALGO>() of pamd_kernels.hip
 	// the merge loops are branch-free: up to 63 lanes past the row's end write into slack (pamd_kernels.hip)
 	p.w_nt = o;
 	o += mmax + 64u;
@@ -514,7 +515,7 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	a->last_lds = (int) lds_bytes;
 
 	if ((a->algo == PAMD_ALGO_PEAR || a->algo == PAMD_ALGO_RDP_MLE) && a->exact_sums) {
-		const size_t rows = (size_t) wgs * (size_t) waves * 8u;	// GROUP parked rows per wave
+		const size_t rows = (size_t) wgs * (size_t) waves * 8u;	// group_size<pear / rdp_mle>() parked rows per wave
 		if (rows > a->scratch_rows) {
 			if (a->d_scratch)
 				HIP_TRY(hipFree(a->d_scratch));

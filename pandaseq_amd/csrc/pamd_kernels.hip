@@ -757,12 +757,17 @@ struct WaveArena {
 // ---- deferred finish ---------------------------------------------------------------------------
 // The three quality sums of a pair (assembler.c:171,226,236) are ordered f64 chains: one lane can
 // advance one chain, so doing them per pair keeps 3 of 64 lanes busy for ~200 dependent adds.
-// Instead every wave parks each merged pair in a small LDS record, and once GROUP pairs are parked
+// Instead every wave parks each merged pair in a small LDS record, and once group_size<ALGO>() pairs are parked
 // (or its work runs out) finishes them together: lane 3*slot + chain walks one chain of one pair,
 // reading the log-probabilities back from the pair's output row (just written, L2/MALL resident),
 // so 48 lanes advance 48 chains with the same instructions.  Then lane `slot` finishes pair `slot`:
 // quality, LOWQ, check modules, the 48-byte record and the counters.
-constexpr int GROUP = 8;
+// 16 pairs per group for the counting scorers (three chains per pair: 48 lanes busy), 8 for pear / rdp_mle (four chains,
+// and their larger tables leave less LDS for parked records: a sixteen-pair group costs them a wave per CU)
+template <int ALGO>
+__device__ __forceinline__ constexpr int group_size() {
+	return (ALGO == PAMD_ALGO_PEAR || ALGO == PAMD_ALGO_RDP_MLE) ? 8 : 16;
+}
 constexpr int SCORE_STRIDE = 456;	// doubles per parked score-term row
 #ifndef FINISH_DEPTH
 #define FINISH_DEPTH 6	/* 16-byte loads in flight per chain */
@@ -802,7 +807,7 @@ __device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsi
 			if (chain == 3) {
 				// pear / rdp_mle: the winning candidate's terms, parked by assemble_pair()
 				end = r.score_n;
-				rowp = P.score_scratch + ((size_t) wave_gid * GROUP + (size_t) slot) * SCORE_STRIDE;
+				rowp = P.score_scratch + ((size_t) wave_gid * group_size<ALGO>() + (size_t) slot) * SCORE_STRIDE;
 			} else if (r.st == PAMD_ST_OK && r.off != ~0ull) {
 				j = chain == 0 ? 0 : (chain == 1 ? r.A + r.novl : r.A);
 				end = chain == 0 ? r.A : (chain == 1 ? r.seqlen : r.A + r.novl);
@@ -844,7 +849,7 @@ __device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsi
 		}
 	}
 	// ---- one lane per pair ----
-	const int src = lane < GROUP ? NCH * lane : 0;
+	const int src = lane < group_size<ALGO>() ? NCH * lane : 0;
 	const double fquality = __shfl(acc, src);
 	const double rquality = __shfl(acc, src + 1);
 	const double oquality = __shfl(acc, src + 2);
@@ -1479,7 +1484,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 
 		if (score_parked > 0) {
 			// park the winner's terms for the finish: 16-byte stores into this wave's scratch row
-			double *dst = P.score_scratch + ((size_t) wave_gid * GROUP + (size_t) slot_idx) * SCORE_STRIDE;
+			double *dst = P.score_scratch + ((size_t) wave_gid * group_size<ALGO>() + (size_t) slot_idx) * SCORE_STRIDE;
 			for (int j0 = 0; j0 < score_parked; j0 += 128) {
 				const int j = j0 + lane * 2;
 				if (j < score_parked)
@@ -1853,7 +1858,7 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 			npend = 0;
 			group_first = next;
 		}
-		if (EXACT && npend == GROUP) {
+		if (EXACT && npend == group_size<ALGO>()) {
 #ifdef PAMD_PHASE_TIMING
 			const u64 t0 = __builtin_amdgcn_s_memtime();
 #endif
