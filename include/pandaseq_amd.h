@@ -64,7 +64,9 @@ enum {
 	PAMD_ST_NORP = 3,	/* norpcount     (assembler.c:276-279) */
 	PAMD_ST_NOALGN = 4,	/* noalgncount   (assembler.c:293-299) */
 	PAMD_ST_LOWQ = 5,	/* lowqcount     (assembler.c:334-338) */
-	PAMD_ST_REJECT = 6	/* a check module rejected it (module.c:124-136) */
+	PAMD_ST_REJECT = 6,	/* a check module rejected it (module.c:124-136) */
+	PAMD_ST_NOSPACE = 7	/* not a reference outcome: the pair assembled but the output arena (seq_capacity) had no room
+				 * for its row; it is counted in `count` only, and pamd_assemble_status() reports the launch */
 };
 
 /* What panda_result_seq (pandaseq-common.h:277-330) carries per pair, minus the pointers. 48 bytes. */
@@ -170,6 +172,14 @@ int pamd_clear_modules(pamd_assembler *a);
  *           per-base log-probabilities stay bit-identical; only `quality` and, for pear / rdp_mle,
  *           `est_overlap_prob` may differ in their last bits.  About 15 % faster, 40 % less HBM traffic. */
 int pamd_set_exact_sums(pamd_assembler *a, int exact);
+/* Two kernels serve a launch: a lean one for ordinary pairs (reads of at most 256 bases holding only
+ * A C G T N with qualities 0..46, a handful of seeded overlaps) and the general one, which then assembles whatever the
+ * lean kernel deferred -- and everything, when the configuration is outside the lean kernel's (primers, `-a`, a maximum
+ * overlap, min_phred, exact sums).  Results do not depend on which kernel produced them.  enable = 0 sends every pair
+ * to the general kernel (tests use it to compare the two); default 1. */
+int pamd_set_fast_path(pamd_assembler *a, int enable);
+/* how many pairs of the most recent launch the lean kernel handed to the general one (synchronises); < 0 if none ran */
+long long pamd_last_deferred(pamd_assembler *a);
 
 /* The probability tables this library computes (host side; works without a GPU).
  * Order: qual_nn, qual_score[47], qual_score_err[47], then eight 47x47 row-major matrices:
@@ -180,6 +190,10 @@ int pamd_tables_get(double *out, size_t n_doubles);
 
 /* Enqueue the assembly of one batch on `stream`; returns once launched (asynchronous). */
 int pamd_assemble_device(pamd_assembler *a, const pamd_batch *batch, void *stream);
+/* After the launch has completed (synchronise the stream first): 0, or PAMD_EINVAL when pairs of the most recent
+ * pamd_assemble_device() on this assembler did not fit in seq_capacity (their records say PAMD_ST_NOSPACE);
+ * *n_overflowed (may be NULL) receives how many.  Resets the flag. */
+int pamd_assemble_status(pamd_assembler *a, uint64_t *n_overflowed);
 /* Same, from/to host memory: uploads, runs, downloads, synchronises. */
 int pamd_assemble_host(pamd_assembler *a, const pamd_batch *batch);
 /* HIP-event time in milliseconds of the most recent pamd_assemble_device() kernel on this

@@ -17,7 +17,7 @@ NUM_COUNTERS = 8 + MAX_MODULES + 2 * MAX_LEN
 TABLE_DOUBLES = 1 + 47 + 47 + 8 * 47 * 47
 
 ALGO = {"simple_bayesian": 0, "pear": 1, "rdp_mle": 2, "uparse": 3, "flash": 4, "ea_util": 5, "stitch": 6}
-STATUS = ["OK", "BADR", "NOFP", "NORP", "NOALGN", "LOWQ", "REJECT"]
+STATUS = ["OK", "BADR", "NOFP", "NORP", "NOALGN", "LOWQ", "REJECT", "NOSPACE"]
 CTR = {"count": 0, "badr": 1, "nofp": 2, "norp": 3, "noalgn": 4, "lowq": 5, "ok": 6, "slow": 7}
 CTR_REJECTED0 = 8
 CTR_OVERLAP0 = 8 + MAX_MODULES
@@ -69,6 +69,7 @@ SYMBOLS = [
     "pamd_set_primer_penalty", "pamd_set_primers_after", "pamd_add_module_min_phred", "pamd_add_module_min_overlapbits",
     "pamd_clear_modules", "pamd_set_exact_sums", "pamd_tables_get", "pamd_assemble_device", "pamd_assemble_host",
     "pamd_last_kernel_ms", "pamd_last_launch_info", "pamd_synth_generate", "pamd_debug_phase_cycles",
+    "pamd_assemble_status", "pamd_set_fast_path", "pamd_last_deferred",
 ]
 
 
@@ -112,6 +113,10 @@ def lib():
     L.pamd_tables_get.argtypes = [C.c_void_p, C.c_size_t]
     L.pamd_assemble_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
     L.pamd_assemble_host.argtypes = [C.c_void_p, C.POINTER(Batch)]
+    L.pamd_assemble_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.pamd_set_fast_path.argtypes = [C.c_void_p, C.c_int]
+    L.pamd_last_deferred.restype = C.c_longlong
+    L.pamd_last_deferred.argtypes = [C.c_void_p]
     L.pamd_last_kernel_ms.restype = C.c_float
     L.pamd_last_kernel_ms.argtypes = [C.c_void_p]
     L.pamd_debug_phase_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int]

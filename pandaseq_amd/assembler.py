@@ -86,7 +86,7 @@ def upload_batch(fwd, rev, flen, rlen, device="cuda:0", seq_stride=None, capacit
         seq_stride = min(2 * _lib.MAX_LEN, fwd.shape[1] + rev.shape[1])
         seq_stride = ((seq_stride + 15) // 16) * 16
     if capacity is None:
-        capacity = n * (seq_stride if seq_stride else ((min(900, fwd.shape[1] + rev.shape[1]) + 15) // 16) * 16) + 16384 * 4096
+        capacity = n * (seq_stride if seq_stride else ((min(900, fwd.shape[1] + rev.shape[1]) + 15) // 16) * 16) + 2 * 16384 * 4096
     outs = alloc_outputs(n, capacity if seq_stride == 0 else n * seq_stride, device, seq_stride)
     return DeviceBatch(
         n=n,
@@ -173,6 +173,21 @@ class Assembler:
 
     def clear_modules(self):
         check(lib().pamd_clear_modules(self._h))
+
+    def set_fast_path(self, enable: bool):
+        """False: every pair goes through the general kernel (the lean kernel of pamd_fast.hip is skipped).
+        Results are the same either way; tests use it to compare the two."""
+        check(lib().pamd_set_fast_path(self._h, 1 if enable else 0))
+
+    def last_deferred(self) -> int:
+        """Pairs the lean kernel handed to the general one in the last launch (-1: it did not run)."""
+        return int(lib().pamd_last_deferred(self._h))
+
+    def check_overflow(self):
+        """After synchronising: raise if pairs of the last launch did not fit in the output arena
+        (their records carry status NOSPACE)."""
+        n = C.c_uint64(0)
+        check(lib().pamd_assemble_status(self._h, C.byref(n)))
 
     # ---- the hot path ----
     def assemble_device(self, b: DeviceBatch, stream=None):

@@ -18,6 +18,7 @@
 namespace {
 
 thread_local char g_error[512] = "";
+uint8_t *g_debug_buf = nullptr;	// development aid, see pamd_debug_fetch()
 
 #define HIP_TRY(call)                                                                       \
 	do {                                                                                \
@@ -63,6 +64,11 @@ struct pamd_assembler {
 	PamdModule modules[PAMD_MAX_MODULES];
 	int exact_sums = 1;
 	int post_primers = 0;
+	int fast_path = 1;		// ordinary pairs go through the lean kernel when the configuration allows (pamd_fast.hip)
+	uint32_t *d_defer = nullptr;	// the pairs it leaves to the general kernel ...
+	size_t defer_cap = 0;
+	unsigned *d_defer_count = nullptr;	// ... and how many
+	bool last_two_kernels = false;
 	double *d_notp = nullptr;
 	// tables
 	PamdTables tabs;
@@ -162,7 +168,7 @@ pamd_assembler *pamd_assembler_create(int device) {
 	a->pear_random_base = std::log(0.25);	// algo_pear.c:106
 	a->threshold = std::log(0.6);	// assembler_support.c:76
 	memset(a->primers, 0, sizeof a->primers);
-	if (hipMalloc(&a->d_tables, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_notp, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_primers, sizeof a->primers) != hipSuccess || hipMalloc(&a->d_error, sizeof(unsigned long long)) != hipSuccess || hipMalloc(&a->d_phase, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_phase, 0, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_error, 0, sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&a->ev_start) != hipSuccess || hipEventCreate(&a->ev_stop) != hipSuccess) {
+	if (hipMalloc(&a->d_tables, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_notp, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_primers, sizeof a->primers) != hipSuccess || hipMalloc(&a->d_error, sizeof(unsigned long long)) != hipSuccess || hipMalloc(&a->d_defer_count, sizeof(unsigned)) != hipSuccess || hipMemset(a->d_defer_count, 0, sizeof(unsigned)) != hipSuccess || hipMalloc(&a->d_phase, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_phase, 0, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_error, 0, sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&a->ev_start) != hipSuccess || hipEventCreate(&a->ev_stop) != hipSuccess) {
 		pamd_set_error("device allocation failed on device %d", device);
 		pamd_assembler_destroy(a);
 		return nullptr;
@@ -186,6 +192,10 @@ void pamd_assembler_destroy(pamd_assembler *a) {
 		(void) hipFree(a->d_phase);
 	if (a->d_scratch)
 		(void) hipFree(a->d_scratch);
+	if (a->d_defer)
+		(void) hipFree(a->d_defer);
+	if (a->d_defer_count)
+		(void) hipFree(a->d_defer_count);
 	for (void *q : a->hb_ptr)
 		if (q)
 			(void) hipFree(q);
@@ -307,6 +317,39 @@ int pamd_set_exact_sums(pamd_assembler *a, int exact) {
 	return PAMD_OK;
 }
 
+int pamd_set_fast_path(pamd_assembler *a, int enable) {
+	if (a == nullptr)
+		return PAMD_EINVAL;
+	a->fast_path = enable ? 1 : 0;
+	return PAMD_OK;
+}
+
+long long pamd_last_deferred(pamd_assembler *a) {
+	if (a == nullptr || !a->timed || !a->last_two_kernels)
+		return -1;
+	unsigned n = 0;
+	if (hipSetDevice(a->device) != hipSuccess || hipEventSynchronize(a->ev_stop) != hipSuccess || hipMemcpy(&n, a->d_defer_count, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
+		return -1;
+	return (long long) n;
+}
+
+int pamd_assemble_status(pamd_assembler *a, uint64_t *n_overflowed) {
+	if (a == nullptr)
+		return PAMD_EINVAL;
+	HIP_TRY(hipSetDevice(a->device));
+	unsigned long long overflow = 0;
+	HIP_TRY(hipMemcpy(&overflow, a->d_error, sizeof overflow, hipMemcpyDeviceToHost));
+	if (overflow != 0)
+		HIP_TRY(hipMemset(a->d_error, 0, sizeof overflow));
+	if (n_overflowed)
+		*n_overflowed = overflow;
+	if (overflow != 0) {
+		pamd_set_error("output arena too small: %llu assembled pairs did not fit in seq_capacity (status PAMD_ST_NOSPACE)", overflow);
+		return PAMD_EINVAL;
+	}
+	return PAMD_OK;
+}
+
 int pamd_clear_modules(pamd_assembler *a) {
 	a->n_modules = 0;
 	return PAMD_OK;
@@ -406,11 +449,21 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.counters = reinterpret_cast<unsigned long long *>(b->counters);
 	p.error_flag = a->d_error;
 	p.phase_cycles = a->d_phase;
+	if (const char *dp = getenv("PAMD_DEBUG_PAIR")) {	// -DPAMD_FK_DEBUG builds: dump the lean kernel's LDS for one pair
+		if (g_debug_buf == nullptr && hipMalloc(&g_debug_buf, 4 * 8192) != hipSuccess)
+			g_debug_buf = nullptr;
+		p.debug_buf = g_debug_buf;
+		p.debug_pair = strtoull(dp, nullptr, 10);
+	}
 	p.tables = a->d_tables;
 	p.notp = a->d_notp;
 	p.post_primers = a->post_primers;
 	p.primers = a->d_primers;
 	p.n_pairs = b->n_pairs;
+	// Every wave that merges a pair reserves a chunk of the compact arena (one global atomic per chunk), so a launch
+	// can leave up to waves x chunk bases unused: 16384 per wave for large batches, less for small ones and for
+	// the general kernel's pass over the lean kernel's deferred pairs (a few per wave).
+	p.arena_chunk = b->n_pairs >= 262144 ? 16384 : 2048;
 	p.seq_stride = b->seq_stride;
 	p.seq_capacity = b->seq_capacity;
 	p.fwd_row_bytes = (uint32_t) b->fwd_stride * 2u;
@@ -526,7 +579,44 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 		}
 		p.score_scratch = a->d_scratch;
 	}
+	// Two kernels (pamd_fast.hip): the lean one takes every pair and hands the unusual ones, by index, to the general
+	// one, which runs second on the same stream and reads how many there are from device memory.
+	const char *nofast = getenv("PAMD_NO_FAST");	// development aid
+	const bool two = a->fast_path && pamd_fast_supports(p) && !(nofast && nofast[0] == '1');
+	if (two && a->defer_cap < b->n_pairs) {
+		if (a->d_defer)
+			HIP_TRY(hipFree(a->d_defer));
+		a->d_defer = nullptr;
+		a->defer_cap = 0;
+		HIP_TRY(hipMalloc(&a->d_defer, b->n_pairs * sizeof(uint32_t)));
+		a->defer_cap = b->n_pairs;
+	}
 	HIP_TRY(hipEventRecord(a->ev_start, st));
+	if (two) {
+		HIP_TRY(hipMemsetAsync(a->d_defer_count, 0, sizeof(unsigned), st));
+		PamdKernelParams pf = p;
+		pf.defer_list = a->d_defer;
+		pf.defer_count = a->d_defer_count;
+		int fwaves = MAX_WAVES_PER_WG;
+		while (fwaves > 1 && pamd_fast_lds_bytes(pf, fwaves) > LDS_LIMIT)
+			fwaves--;
+		if (fwaves > waves && getenv("PAMD_MAX_WAVES"))
+			fwaves = waves;
+		size_t fwant = (b->n_pairs + (size_t) fwaves - 1) / (size_t) fwaves;
+		int fwgs = a->cu_count > 0 ? a->cu_count : 256;
+		if ((size_t) fwgs > fwant)
+			fwgs = (int) fwant;
+		rc = pamd_launch_fast(pf, fwgs, fwaves, pamd_fast_lds_bytes(pf, fwaves), stream);
+		if (rc != PAMD_OK)
+			return rc;
+		a->last_wgs = fwgs;
+		a->last_waves = fwaves;
+		a->last_lds = (int) pamd_fast_lds_bytes(pf, fwaves);
+		p.pair_list = a->d_defer;
+		p.pair_count = a->d_defer_count;
+		p.arena_chunk = b->n_pairs >= 262144 ? 4096 : 1024;
+	}
+	a->last_two_kernels = two;
 	rc = pamd_launch_assemble(p, wgs, waves, lds_bytes, stream);
 	if (rc != PAMD_OK)
 		return rc;
@@ -544,6 +634,14 @@ float pamd_last_kernel_ms(pamd_assembler *a) {
 	if (hipEventElapsedTime(&ms, a->ev_start, a->ev_stop) != hipSuccess)
 		return -1.0f;
 	return ms;
+}
+
+int pamd_debug_fetch(void *dst, size_t bytes) {	// development aid (-DPAMD_FK_DEBUG builds): not declared in the public header
+	if (g_debug_buf == nullptr || bytes > 4 * 8192)
+		return PAMD_EINVAL;
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipMemcpy(dst, g_debug_buf, bytes, hipMemcpyDeviceToHost));
+	return PAMD_OK;
 }
 
 int pamd_debug_phase_cycles(pamd_assembler *a, unsigned long long *out10, int reset) {
@@ -621,8 +719,8 @@ int pamd_assemble_host(pamd_assembler *a, const pamd_batch *hb) {
 	if (rc != PAMD_OK)
 		return rc;
 	HIP_TRY(hipDeviceSynchronize());
-	unsigned long long overflow = 0;
-	HIP_TRY(hipMemcpy(&overflow, a->d_error, 8, hipMemcpyDeviceToHost));
+	uint64_t overflow = 0;
+	(void) pamd_assemble_status(a, &overflow);
 	HIP_TRY(hipMemcpy(hb->results, dres, n * sizeof(pamd_pair_result), hipMemcpyDeviceToHost));
 	// compact arena: only the part the launch used comes back
 	size_t used = cap;
@@ -642,7 +740,7 @@ int pamd_assemble_host(pamd_assembler *a, const pamd_batch *hb) {
 			hb->counters[i] += tmp[i];
 	}
 	if (overflow) {
-		pamd_set_error("output arena too small: %llu accepted pairs did not fit in seq_capacity=%zu bases", overflow, cap);
+		pamd_set_error("output arena too small: %llu assembled pairs did not fit in seq_capacity=%zu bases", (unsigned long long) overflow, cap);
 		return PAMD_EINVAL;
 	}
 	return PAMD_OK;
