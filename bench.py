@@ -135,7 +135,7 @@ def main():
     torch.cuda.empty_cache()
     while True:
         try:
-            capacity = int(n * per_pair * 1.03) + (1 << 27)
+            capacity = int(n * per_pair * 1.03) + (1 << 28)
             batch = make_batch(n, first, capacity)
             break
         except torch.OutOfMemoryError:

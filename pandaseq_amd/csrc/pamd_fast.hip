@@ -118,13 +118,13 @@ __device__ __forceinline__ int stage(const uint2 v, const int len, int lane, uns
 	nmap = FORWARD ? nb : nb << 1;
 	wb[(FORWARD ? FK_FC : FK_RC) + lane] = (unsigned char) codes;
 	wb[(FORWARD ? FK_FN : FK_RN) + lane] = (unsigned char) nmap;
+	// the usual read does not end in quality 2: one lane read settles it
+	const unsigned lastq = (unsigned) __builtin_amdgcn_readlane((int) q4, (len - 1) >> 2);
+	if (((lastq >> (8 * ((len - 1) & 3))) & 0xFFu) != 2u)
+		return len;
 	const unsigned x = q4 ^ 0x02020202u;
 	const unsigned t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);	// 0x80 where quality == 2
 	const unsigned is2 = (((t >> 7) * 0x00204081u) >> 21) & 0xFu;
-	// the usual read does not end in quality 2: one lane read settles it
-	const unsigned lastq = (unsigned) __builtin_amdgcn_readlane((int) is2, (len - 1) >> 2);
-	if (((lastq >> ((len - 1) & 3)) & 1u) == 0)
-		return len;
 	const unsigned not2 = ~is2 & ((1u << cnt) - 1u);
 	const int mine = not2 ? lane * 4 + (31 - __builtin_clz(not2)) + 1 : 0;
 	const u64 has = ballot(not2 != 0);
@@ -156,6 +156,103 @@ __device__ __forceinline__ unsigned word_counts(const unsigned char *wb, int fle
 	return (unsigned) __popc(valid & isn) | ((unsigned) __popc(valid & same & ~isn) << 10);
 }
 
+// ---- many candidates: pairs without a seeded overlap (every overlap is a candidate) and tandem repeats -----------------
+// Every lane scores up to four candidates by itself, 16 positions per step with the same whole-word arithmetic as above and
+// no cross-lane traffic.  Candidates are dealt so that the lanes finish together: with the candidates in ascending
+// order, lane l takes numbers l and 127 - l (first half of the steps) and 128 + l and 255 - l (second half) -- a short
+// overlap always travels with a long one.  Returns what the ascending scan of assembler.c:120-133 returns: the largest
+// score above `best`, the smallest overlap among equals.  Out of line: it runs for three pairs in a hundred.
+struct ManyResult {
+	double best;
+	int bo, examined;
+};
+
+template <int ALGO>
+__device__ __attribute__((noinline)) ManyResult scan_many(unsigned char *wb, int all, int size, int minov, int flen, int rlen, double qual_nn, double pmatch, double pmismatch, double best, int lane) {
+	// the candidates in ascending order, one byte each (overlap - minov < 256), where the k-mer tables were
+	uint8_t *list = wb + FK_T1;
+	int total = size;
+	if (!all) {
+		const unsigned mine = reinterpret_cast<const unsigned *>(wb + FK_FLAGS)[lane];	// flag bytes are 0 or 1
+		const unsigned c = (mine * 0x01010101u) >> 24;	// how many of this lane's four overlaps are flagged
+		unsigned before = 0;
+		total = 0;
+#pragma unroll
+		for (int b = 0; b < 3; b++) {
+			const u64 m = ballot(((c >> b) & 1u) != 0);
+			before += (unsigned) __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u)) << b;
+			total += __popcll(m) << b;
+		}
+		wave_sync();
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			if ((mine >> (8 * k)) & 1u) {
+				list[before] = (uint8_t) (4 * lane + k);
+				before++;
+			}
+		}
+		wave_sync();
+	}
+	int ov[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const int c = k == 0 ? lane : (k == 1 ? 127 - lane : (k == 2 ? 128 + lane : 255 - lane));
+		const int idx = all ? c : (int) list[c < total ? c : 0];
+		ov[k] = c < total ? idx + minov : 0;
+	}
+	unsigned acc[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+	for (int half = 0; half < 2; half++) {
+		const int ova = ov[2 * half], ovb = ov[2 * half + 1];
+		const int wa = (ova + 15) >> 4;
+		int steps = wa + ((ovb + 15) >> 4);
+		for (int o = 32; o > 0; o >>= 1) {
+			const int other = __shfl_xor(steps, o);
+			steps = other > steps ? other : steps;
+		}
+		steps = uni(steps);
+		unsigned a = 0, b = 0;
+		for (int s = 0; s < steps; s++) {
+			const bool first = s < wa;
+			const int o = first ? ova : ovb;
+			const int i0 = 16 * (first ? s : s - wa);
+			const unsigned cnt = word_counts(wb, flen, rlen, o, i0, i0 < o);
+			a += first ? cnt : 0u;
+			b += first ? 0u : cnt;
+		}
+		acc[2 * half] = a;
+		acc[2 * half + 1] = b;
+	}
+	// this lane's best, its candidates in ascending order; then the wave's
+	double pr = -__builtin_inf();
+	int bov = 0x7FFFFFFF;
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const double sc = count_score<ALGO>(qual_nn, pmatch, pmismatch, flen, rlen, ov[k], (int) (acc[k] & 1023u), (int) (acc[k] >> 10), ov[k]);
+		if (ov[k] != 0 && sc > pr) {
+			pr = sc;
+			bov = ov[k];
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		const double opr = __shfl_xor(pr, o);
+		const int oov = __shfl_xor(bov, o);
+		if (opr > pr || (opr == pr && oov < bov)) {
+			pr = opr;
+			bov = oov;
+		}
+	}
+	ManyResult out;
+	out.best = best;
+	out.bo = -1;
+	out.examined = total;
+	if (pr > best) {	// strict, as every step of the ascending scan is
+		out.best = pr;
+		out.bo = bov;
+	}
+	return out;
+}
+
 // LDS by byte address: the compiler then sees plain integer arithmetic (no symbolic base to add per access) and folds
 // constant steps into the instructions' offset field
 typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
@@ -172,6 +269,17 @@ __device__ __forceinline__ void lds_write_u8(unsigned addr, unsigned v) {
 }
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
 	return (unsigned) (uintptr_t) p;	// a flat pointer into LDS carries the LDS byte address in its low half
+}
+
+// (x << S) + y in one instruction (the compiler prefers a shift, a mask and an add when it sees (x >> a) << S)
+template <int S>
+__device__ __forceinline__ unsigned lshl_add(unsigned x, unsigned y) {
+	unsigned r;
+	asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(S), "v"(y));
+	return r;
+}
+__device__ __forceinline__ unsigned lds_read_u32(unsigned addr) {
+	return *reinterpret_cast<__attribute__((address_space(3))) const unsigned *>(addr);
 }
 
 struct WaveArena {
@@ -205,10 +313,17 @@ __device__ __forceinline__ unsigned insert_level(unsigned *table, unsigned slot,
 	}
 	return carry;
 }
+__device__ __forceinline__ unsigned insert_at(unsigned lds_byte_addr, unsigned carry) {	// the same, by LDS byte address
+	if (carry != EMPTY) {
+		// (through a generic pointer for the overload's sake; the compiler sees where it came from and emits ds_min_rtn_u32)
+		const unsigned old = atomicMin((unsigned *) reinterpret_cast<__attribute__((address_space(3))) unsigned *>(lds_byte_addr), carry);
+		carry = old > carry ? old : carry;
+	}
+	return carry;
+}
 
 // why pairs are deferred, counted in P.phase_cycles[0..5] (read back with pamd_debug_phase_cycles): 0 an nt or quality
-// outside the lean domain, 1 a k-mer found no slot, 2 no seeded overlap (every overlap is a candidate), 3 more than four
-// candidates, 4 quality too close to the LOWQ threshold; (debug builds) 5 counts pairs that used the last two k-mer tables
+// outside the lean domain, 1 a k-mer found no slot, (2, 3: unused) 4 quality too close to the LOWQ threshold; (debug builds) 5 counts pairs that used the last two k-mer tables
 __device__ __forceinline__ void note(const PamdKernelParams &P, int what, int lane) {
 	if (lane == 0 && P.phase_cycles != nullptr)
 		atomicAdd(&P.phase_cycles[what], 1ull);
@@ -321,12 +436,13 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				const unsigned word = ((w << (14 - 2 * j)) & 0xFFFF0000u) | (unsigned) (4 * lane + j);
 				carry[j] = (nw & (0x15555u << (2 * j))) == 0 ? word : EMPTY;
 			}
+			const unsigned l1 = lds_addr(t1), l2 = lds_addr(t2);
 #pragma unroll
 			for (int j = 0; j < 4; j++)
-				carry[j] = insert_level(t1, slot1(carry[j] >> 16), carry[j]);
+				carry[j] = insert_at(lshl_add<2>(mul24(carry[j] >> 16, HASH_C) >> 22, l1), carry[j]);
 #pragma unroll
 			for (int j = 0; j < 4; j++)
-				carry[j] = insert_level(t2, slot2(carry[j] >> 16), carry[j]);
+				carry[j] = insert_at(lshl_add<2>(__builtin_amdgcn_ubfe(mul24(carry[j] >> 16, HASH_C), 14, 8), l2), carry[j]);
 			bool lost = false;
 #pragma unroll
 			for (int j = 0; j < 4; j++) {
@@ -334,7 +450,14 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 					deep = true;
 					carry[j] = insert_level(t3, slot3(carry[j] >> 16), carry[j]);
 					carry[j] = insert_level(t4, slot4(carry[j] >> 16), carry[j]);
-					lost |= ballot(carry[j] != EMPTY) != 0;
+					if (ballot(carry[j] != EMPTY) != 0) {
+						// A word found no slot.  The words of one k-mer that did are always its smallest positions (a slot
+						// keeps its minimum), so a k-mer with two of them in the tables loses nothing the reference keeps
+						// (assembler.c:94-99 drops a third position as well): tandem repeats pass here.
+						const unsigned k = carry[j] >> 16, kk = carry[j] & 0xFFFF0000u;
+						const int kept = (int) ((t1[slot1(k)] ^ kk) < 0x10000u) + (int) ((t2[slot2(k)] ^ kk) < 0x10000u) + (int) ((t3[slot3(k)] ^ kk) < 0x10000u) + (int) ((t4[slot4(k)] ^ kk) < 0x10000u);
+						lost |= ballot(carry[j] != EMPTY && kept < 2) != 0;
+					}
 				}
 			}
 			deep_dirty = deep;
@@ -362,18 +485,24 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			const unsigned nw = ((x0 >> 8) & 0xFFu) | (x1 & 0xFF00u) | ((x2 & 0xFF00u) << 8);	// its N flag at bit 2b+1
 			const unsigned br = __builtin_bitreverse32(w);	// base b now at bits 30-2b..31-2b, codes read as forward codes
 			const unsigned top = (unsigned) (flen + rlen - minov - 1 - 4 * lane);	// assembler.c:107: index = top - j - forward position
-			unsigned m1[4], m2[4];
+			unsigned m1[4], m2[4], xk[4];
 			bool ok[4];
+			const unsigned l1 = lds_addr(t1), l2 = lds_addr(t2);
 #pragma unroll
 			for (int j = 0; j < 4; j++) {
-				const unsigned xj = br << (2 * j);	// this k-mer in the top half
-				const unsigned kmer = xj >> 16, kk = xj & 0xFFFF0000u;
+				xk[j] = br << (2 * j);	// this k-mer in the top half
 				ok[j] = (nw & (0x2AAAAu << (2 * j))) == 0;
-				const unsigned e1 = t1[slot1(kmer)] ^ kk, e2 = t2[slot2(kmer)] ^ kk;
+				const unsigned prod = mul24(xk[j] >> 16, HASH_C), kk = xk[j] & 0xFFFF0000u;
+				const unsigned e1 = lds_read_u32(lshl_add<2>(prod >> 22, l1)) ^ kk;
+				const unsigned e2 = lds_read_u32(lshl_add<2>(__builtin_amdgcn_ubfe(prod, 14, 8), l2)) ^ kk;
 				// an entry of this k-mer reads as its bare position (< 0x10000), anything else as >= 0x10000
 				m1[j] = e1 < e2 ? e1 : e2;
 				m2[j] = e1 < e2 ? e2 : e1;
-				if (deep) {	// wave-uniform: the last two tables hold something
+			}
+			if (deep) {	// wave-uniform: the last two tables hold something
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					const unsigned kmer = xk[j] >> 16, kk = xk[j] & 0xFFFF0000u;
 					const unsigned e3 = t3[slot3(kmer)] ^ kk, e4 = t4[slot4(kmer)] ^ kk;
 					const unsigned l34 = e3 < e4 ? e3 : e4, h34 = e3 < e4 ? e4 : e3;
 					const unsigned hi = m1[j] < l34 ? l34 : m1[j];
@@ -403,16 +532,13 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		STOP(2);
 		MARK("candidates");
 
-		// ---- the candidates (assembler.c:118-143): at most four here ----
+		// ---- the candidates (assembler.c:118-143) ----
 		int ncand = 0, ov0 = 0, ov1 = 0, ov2 = 0, ov3 = 0;
+		bool all = false;
 		{
 			const unsigned mine = reinterpret_cast<const unsigned *>(flags)[lane];	// overlaps minov + 4*lane + 0..3
 			u64 nz = ballot(mine != 0);
-			if (nz == 0) {	// ALL_BITS_IF_NONE: every overlap is a candidate
-				note(P, 2, lane);
-				status = PAMD_ST_DEFER;
-				break;
-			}
+			all = nz == 0;	// ALL_BITS_IF_NONE: every overlap is a candidate
 			while (nz != 0 && ncand <= 4) {
 				const int w = __builtin_ctzll(nz);
 				nz &= nz - 1;
@@ -432,16 +558,18 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 					ncand++;
 				}
 			}
-			if (ncand > 4) {	// tandem repeats and the like: a candidate per lane in the general kernel
-				note(P, 3, lane);
-				status = PAMD_ST_DEFER;
-				break;
-			}
 		}
 		MARK("scan");
-		// ---- scan + argmax: one candidate per 16-lane row, 16 positions per lane ----
 		best = P.qual_nn * (double) (flen + rlen);	// assembler.c:60
-		{
+		if (all || ncand > 4) {
+			// ---- pairs without a seeded overlap, tandem repeats: a candidate per lane (three pairs in a hundred) ----
+			const ManyResult mr = scan_many<ALGO>(wb, all ? 1 : 0, size, minov, flen, rlen, P.qual_nn, P.sb_pmatch, P.sb_pmismatch, best, lane);
+			best = uni_f64(mr.best);	// a function's results come back in vector registers
+			bo = uni(mr.bo);
+			ncand = uni(mr.examined);
+			deep_dirty = true;	// the candidate list lay over the k-mer tables
+		} else {
+			// ---- scan + argmax: one candidate per 16-lane row, 16 positions per lane ----
 			const int row = lane >> 4;
 			const int myov = row == 0 ? ov0 : (row == 1 ? ov1 : (row == 2 ? ov2 : ov3));
 			unsigned packed = word_counts(wb, flen, rlen, myov, 16 * (lane & 15), row < ncand);
@@ -486,8 +614,14 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		const int A = flen - bo, Bn = rlen - bo, novl = bo;
 		seqlen = A + novl + Bn;	// len - 1; len = seqlen + 1 is in 3 .. 511
 		const u64 need = ((u64) seqlen + 15ull) & ~15ull;
-		if (P.seq_stride != 0) {
-			off = pair * P.seq_stride;
+		// (the launch parameters this block needs, read together: the compiler otherwise re-reads each from the kernel
+		// argument segment, one exposed scalar-memory round trip per use, in whichever branch it is used)
+		u64 k_stride = P.seq_stride, k_capacity = P.seq_capacity;
+		uint8_t *k_nt = P.seq_nt;
+		double *k_p = P.seq_p;
+		asm volatile("" : "+s"(k_stride), "+s"(k_capacity), "+s"(k_nt), "+s"(k_p));
+		if (k_stride != 0) {
+			off = pair * k_stride;
 		} else {
 			if (arena.cur + need > arena.end) {
 				u64 got = 0;
@@ -505,12 +639,12 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			}
 			off = arena.cur;
 			arena.cur += need;
-			if (off + need > P.seq_capacity)
+			if (off + need > k_capacity)
 				off = ~0ull;
 		}
 		const bool store = off != ~0ull;
-		uint8_t *const row_nt = P.seq_nt + (store ? off : 0);
-		double *const row_p = P.seq_p + (store ? off : 0);
+		uint8_t *const row_nt = k_nt + (store ? off : 0);
+		double *const row_p = k_p + (store ? off : 0);
 		double qacc = 0.0;	// this lane's share of the quality sum, any order
 		// ROUNDS rounds of 64 bases per region, straight-line: forward-only bases [0, A) (assembler.c:162-173), overlapping
 		// bases [A, A + novl) (assembler.c:181-228), reverse-only bases [A + novl, seqlen) (assembler.c:231-243), in two
@@ -520,7 +654,12 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		// byte lands where a later region writes again or in the staging slack.
 		const unsigned lF = lds_addr(wb + FK_F), lR = lds_addr(wb + FK_R), lT = lds_addr(ltab), lN = lds_addr(nts);
 		// a pair whose row does not fit stores nothing (it ends as NOSPACE whatever its sums are)
+#ifdef FK_NO_PSTORE	/* experiment: what do the log-p stores cost? (results are wrong) */
+		const int sA = 0, sO = 0, sB = 0;
+		qacc = -1.0;
+#else
 		const int sA = store ? A : 0, sO = store ? novl : 0, sB = store ? Bn : 0;
+#endif
 		auto lanes_below = [](int n) -> u64 {	// lanes 0 .. n-1 as a mask (scalar arithmetic)
 			return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
 		};
