@@ -167,10 +167,44 @@ __device__ __forceinline__ unsigned put_lane(unsigned reg, unsigned value, bool 
 // through the lean kernel's deferred pairs) entry first_pair + s * pair_step of P.pair_list.
 // DEFER (the lean kernel): a pair parked as PAMD_ST_DEFER gets no record and no counter here; its index is appended
 // to P.defer_list -- one global atomic per 64 pairs -- and the general kernel assembles it from scratch.
-template <bool LIST, bool DEFER>
+// One ordered chain of a row's log-probabilities: acc += row[j] for j = lo .. hi-1, left to right (assembler.c:171,226,236),
+// eight values (four 16-byte loads) in flight per lane.  Every lane walks its OWN pair's row, so a load instruction
+// touches 64 different lines: measured on 8 M config-1 pairs, this depth costs the lean kernel 18 % against any-order
+// sums; sixteen values in flight cost 27 % (the lines no longer stay in the L1), and walking a row's three chains at once
+// with 8-byte loads doubles the kernel's time.
+__device__ __forceinline__ double ordered_row_sum(const double *row, int lo, int hi) {
+	double acc = 0.0;
+	int j = lo;
+	if (j < hi && (j & 1)) {	// reach a 16-byte boundary
+		acc += row[j];
+		j++;
+	}
+	for (; j + 8 <= hi; j += 8) {
+		const double2 v0 = *reinterpret_cast<const double2 *>(row + j), v1 = *reinterpret_cast<const double2 *>(row + j + 2);
+		const double2 v2 = *reinterpret_cast<const double2 *>(row + j + 4), v3 = *reinterpret_cast<const double2 *>(row + j + 6);
+		acc += v0.x;
+		acc += v0.y;
+		acc += v1.x;
+		acc += v1.y;
+		acc += v2.x;
+		acc += v2.y;
+		acc += v3.x;
+		acc += v3.y;
+	}
+	for (; j < hi; j++)
+		acc += row[j];
+	return acc;
+}
+
+// EXACTQ (the lean kernel with exact sums): the quality sums are made here, in the reference's order, every lane walking
+// the three chains of its own pair's row (which this wave wrote; dg_fo carries the number of forward-only bases in its
+// upper half instead of a forward offset, which the lean kernel does not have).
+template <bool LIST, bool DEFER, bool EXACTQ = false>
 __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64 &pd, int npend, u64 first_pair, u64 pair_step, int lane) {
 	int status = -1, reject = -1;
 	bool slow = false;
+	if (EXACTQ)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// this wave's row stores have reached L2
 	u64 pair = first_pair + (u64) lane * pair_step;
 	if (LIST && lane < npend)
 		pair = P.pair_list[pair];
@@ -201,6 +235,20 @@ __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64
 		slow = ((pd.ro_st >> 24) & 1u) != 0;
 		const bool q_final = ((pd.ro_st >> 25) & 1u) != 0;
 		const int seqlen = (int) (pd.len_bo & 0xFFFFu), bo = (int) (pd.len_bo >> 16);
+		unsigned dg_fo = pd.dg_fo;
+		if (EXACTQ) {
+			dg_fo &= 0xFFFFu;
+			if (status == PAMD_ST_OK && row != ~0ull) {
+				// plain cached loads: this wave's own stores have been waited for (below), and a CU's vector L1 is
+				// coherent for its own stores
+				const int A = (int) (pd.dg_fo >> 16);
+				const double *rowp = P.seq_p + row;
+				const double fq = ordered_row_sum(rowp, 0, A);
+				const double rq = ordered_row_sum(rowp, A + bo, seqlen);
+				const double oq = ordered_row_sum(rowp, A, A + bo);
+				q.d = (fq + rq + oq) / (double) (seqlen + 1);	// assembler.c:244
+			}
+		}
 		double quality = 0.0;
 		u64 off = ~0ull;
 		if (status == PAMD_ST_OK && row == ~0ull) {
@@ -212,7 +260,7 @@ __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64
 		if (status == PAMD_ST_OK) {
 			// assembler.c:244: the divisor is the sequence length + 1.  A sum that lands within 1e-9 of the LOWQ
 			// threshold was already redone in reference order when the pair was parked (flagged final).
-			quality = q_final ? q.d : q.d / (double) (seqlen + 1);
+			quality = (q_final || EXACTQ) ? q.d : q.d / (double) (seqlen + 1);
 			if (quality < P.threshold) {	// assembler.c:334-338
 				status = PAMD_ST_LOWQ;
 			} else {
@@ -237,7 +285,7 @@ __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64
 		uint4 *dst = reinterpret_cast<uint4 *>(&P.results[pair]);
 		dst[0] = make_uint4(q.u[0], q.u[1], e.u[0], e.u[1]);
 		dst[1] = make_uint4((unsigned) off, (unsigned) (off >> 32), pd.len_bo, pd.ex_mm);
-		dst[2] = make_uint4(pd.dg_fo, (pd.ro_st & 0xFFFFu) | ((unsigned) status << 16) | (((unsigned) reject & 0xFFu) << 24), slow ? 1u : 0u, 0u);
+		dst[2] = make_uint4(dg_fo, (pd.ro_st & 0xFFFFu) | ((unsigned) status << 16) | (((unsigned) reject & 0xFFu) << 24), slow ? 1u : 0u, 0u);
 		if (status == PAMD_ST_OK)
 			atomicAdd(&lctr[PAMD_CTR_OVERLAP0 + bo], 1u);
 		else if (status == PAMD_ST_REJECT)

@@ -365,7 +365,7 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 #define DEBUG_DUMP(...)
 #endif
 
-template <int ALGO, int ROUNDS>
+template <int ALGO, int ROUNDS, bool EXACT>
 __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt) {
 	const uint2 fv = cur.f, rv = cur.r;
 	bool rotated = false;
@@ -775,14 +775,17 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		// the nt row leaves LDS in 16-byte stores (rows are 16-base aligned)
 		if (store && lane * 16 < seqlen)
 			reinterpret_cast<uint4 *>(row_nt)[lane] = reinterpret_cast<const uint4 *>(nts)[lane];
-		qsum = wave_sum_any_order(qacc);	// divided by len in finish64() ...
-		// ... unless the quotient could land within 1e-9 of the LOWQ threshold (tested without dividing): the general
-		// kernel then makes the three sums in reference order (assembler.c:171,226,236,244,334)
-		if (fabs(qsum - P.threshold * (double) (seqlen + 1)) <= 1e-9 * (double) (seqlen + 1)) {
-			note(P, 4, lane);
-			status = PAMD_ST_DEFER;	// (its row stays behind in the arena as a hole)
-			break;
+		if (!EXACT) {
+			qsum = wave_sum_any_order(qacc);	// divided by len in finish64() ...
+			// ... unless the quotient could land within 1e-9 of the LOWQ threshold (tested without dividing): the general
+			// kernel then makes the three sums in reference order (assembler.c:171,226,236,244,334)
+			if (fabs(qsum - P.threshold * (double) (seqlen + 1)) <= 1e-9 * (double) (seqlen + 1)) {
+				note(P, 4, lane);
+				status = PAMD_ST_DEFER;	// (its row stays behind in the arena as a hole)
+				break;
+			}
 		}
+		// (exact sums: finish64 walks the row's three chains in reference order, sixty-four pairs at a time)
 	} while (0);
 	MARK("park");
 	if (!rotated) {
@@ -805,12 +808,12 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	pd.b_hi = put_lane(pd.b_hi, bb.u[1], mine);
 	pd.len_bo = put_lane(pd.len_bo, (unsigned) seqlen | ((unsigned) (bo < 0 ? 0 : bo) << 16), mine);
 	pd.ex_mm = put_lane(pd.ex_mm, (unsigned) examined | ((unsigned) mism << 16), mine);
-	pd.dg_fo = put_lane(pd.dg_fo, (unsigned) degen, mine);
+	pd.dg_fo = put_lane(pd.dg_fo, (unsigned) degen | (EXACT ? (unsigned) (seqlen - rlen) << 16 : 0u), mine);	// exact sums: + the forward-only bases
 	pd.ro_st = put_lane(pd.ro_st, ((unsigned) status << 16) | ((unsigned) slow << 24) | (63u << 26), mine);
 }
 
 // ROUNDS: rounds of 64 bases a read can span (rows of at most 64 * ROUNDS bases)
-template <int ALGO, int ROUNDS>
+template <int ALGO, int ROUNDS, bool EXACT>
 __global__ __launch_bounds__(1024) void pamd_fast_kernel(const PamdKernelParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	double *ltab = reinterpret_cast<double *>(lds);
@@ -855,18 +858,18 @@ __global__ __launch_bounds__(1024) void pamd_fast_kernel(const PamdKernelParams 
 		nxt.f = load_row(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
 		nxt.r = load_row(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
-		fast_pair<ALGO, ROUNDS>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane, flen, rlen, cur, nxt);
+		fast_pair<ALGO, ROUNDS, EXACT>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane, flen, rlen, cur, nxt);
 		MARK("loop");
 		npend++;
 		if (npend == 64) {
-			finish64<false, true>(P, lctr, pd, npend, group_first, total_waves, lane);
+			finish64<false, true, EXACT>(P, lctr, pd, npend, group_first, total_waves, lane);
 			npend = 0;
 			group_first = next;
 		}
 		pair = next;
 	}
 	if (npend > 0)
-		finish64<false, true>(P, lctr, pd, npend, group_first, total_waves, lane);
+		finish64<false, true, EXACT>(P, lctr, pd, npend, group_first, total_waves, lane);
 	__syncthreads();
 	if (P.counters != nullptr) {
 		for (unsigned i = tid; i < PAMD_NUM_COUNTERS; i += blockDim.x) {
@@ -883,7 +886,7 @@ __global__ __launch_bounds__(1024) void pamd_fast_kernel(const PamdKernelParams 
 int pamd_fast_supports(const PamdKernelParams &p) {
 	if (p.algo == PAMD_ALGO_PEAR || p.algo == PAMD_ALGO_RDP_MLE)
 		return 0;	// per-base scores: the general kernel
-	if (p.smax > 256 || p.post_primers || p.exact_sums || p.has_min_phred)
+	if (p.smax > 256 || p.post_primers || p.has_min_phred)
 		return 0;
 	if (p.fprimer_len > 0 || p.rprimer_len > 0 || p.ftrim != 0 || p.rtrim != 0 || p.maxoverlap != 0)
 		return 0;
@@ -901,7 +904,8 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	void (*kern)(const PamdKernelParams) = nullptr;
 	const int rounds = p.smax <= 128 ? 2 : (p.smax <= 192 ? 3 : 4);
-#define FK_PICK(A) (rounds == 2 ? pamd_fast_kernel<A, 2> : (rounds == 3 ? pamd_fast_kernel<A, 3> : pamd_fast_kernel<A, 4>))
+#define FK_PICK2(A, E) (rounds == 2 ? pamd_fast_kernel<A, 2, E> : (rounds == 3 ? pamd_fast_kernel<A, 3, E> : pamd_fast_kernel<A, 4, E>))
+#define FK_PICK(A) (p.exact_sums ? FK_PICK2(A, true) : FK_PICK2(A, false))
 	switch (p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
 		kern = FK_PICK(PAMD_ALGO_SIMPLE_BAYES);
@@ -923,6 +927,7 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 		return PAMD_EINVAL;
 	}
 #undef FK_PICK
+#undef FK_PICK2
 	hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 	if (e0 != hipSuccess) {
 		pamd_set_error("hipFuncSetAttribute(%zu bytes LDS, lean kernel): %s", lds_bytes, hipGetErrorString(e0));
