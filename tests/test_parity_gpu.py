@@ -248,8 +248,8 @@ def test_empty_and_tiny_batches(built):
     assert len(res) == 0 and ctr["count"] == 0
 
 
-def test_golden_fixtures(built):
-    """The committed fixtures (tests/golden): device output against stored expectations."""
+def test_golden_fixtures(built, sums):
+    """The committed fixtures (tests/golden): device output against stored expectations, in both summation modes."""
     import glob
     import os
     import sys
@@ -264,15 +264,19 @@ def test_golden_fixtures(built):
         cfg_index, n, kw = make_golden.CASES[name]
         spec = synth.config_spec(cfg_index)
         mods = [f"{k}:{v}" for k, v in kw.get("modules", [])]
-        asm = _asm_for(kw["algo"], spec, primers=kw.get("primers", False), modules=mods)
+        asm = _asm_for(kw["algo"], spec, primers=kw.get("primers", False), modules=mods, exact=sums == "exact")
         b = _run(asm, g["fwd"], g["rev"], g["flen"], g["rlen"], seq_stride=0)
         res = b.results_numpy()
         gr = g["res"]
         assert np.array_equal(res["status"], gr["status"].astype(np.uint8)), name
         ok = gr["status"] == 0
         assert np.array_equal(res["overlap"][ok], gr["overlap"][ok].astype(np.uint16)), name
-        assert np.array_equal(res["quality"][ok].view(np.uint64), gr["quality"][ok].view(np.uint64)), name
-        assert np.array_equal(res["est_overlap_prob"][ok].view(np.uint64), gr["est_prob"][ok].view(np.uint64)), name
+        if sums == "exact":
+            assert np.array_equal(res["quality"][ok].view(np.uint64), gr["quality"][ok].view(np.uint64)), name
+            assert np.array_equal(res["est_overlap_prob"][ok].view(np.uint64), gr["est_prob"][ok].view(np.uint64)), name
+        else:
+            assert np.abs(res["quality"][ok] - gr["quality"][ok]).max() <= 1e-9, name
+            assert np.abs(res["est_overlap_prob"][ok] - gr["est_prob"][ok]).max() <= 1e-9, name
         nt = b.seq_nt.cpu().numpy()
         p = b.seq_p.cpu().numpy()
         for i in np.nonzero(ok)[0]:
@@ -309,7 +313,14 @@ def test_full_size_properties(built):
     order = np.argsort(offs)
     ends = offs[order] + res["seq_len"][ok][order]
     assert (offs % 16 == 0).all() and (ends[:-1] <= offs[order][1:]).all() and ends[-1] <= int(b.cursor.item())
-    assert float(b.seq_p[: int(b.cursor.item())].max().item()) <= 0.0 or True  # unwritten gaps are uninitialised
+    # every written log-p is <= 0 (the arena between rows is never written: only rows are looked at)
+    import torch as _t
+    sample = np.nonzero(ok)[0][:: max(1, int(ok.sum()) // 20000)]
+    so = _t.from_numpy(res["seq_offset"][sample].astype(np.int64)).cuda()
+    sl = _t.from_numpy(res["seq_len"][sample].astype(np.int64)).cuda()
+    col = _t.arange(512, device="cuda:0")
+    vals = b.seq_p[(so[:, None] + col[None, :]).clamp(max=b.seq_p.numel() - 1)]
+    assert float(vals[col[None, :] < sl[:, None]].max().item()) <= 0.0
     cs1 = _row_checksums(b, res, ok)
     b.cursor.zero_()
     b.counters.zero_()
@@ -320,6 +331,53 @@ def test_full_size_properties(built):
         assert np.array_equal(res[k], res2[k])
     assert np.array_equal(res["quality"].view(np.uint64), res2["quality"].view(np.uint64))
     assert np.array_equal(cs1, _row_checksums(b, res2, ok))
+
+
+@pytest.mark.parametrize("cfg", [2, 3, 4])
+def test_full_size_properties_other_configs(built, cfg, sums):
+    """The same size-independent properties on 1 M pairs of BASELINE configs 2, 3 and 4: counters add up (every pair has
+    exactly one outcome), accepted rows lie inside the arena without touching, merged length = reads - overlap - clipped
+    primers, and the two-kernel launch agrees with the general kernel alone on every record."""
+    import torch
+
+    import bench
+    import pandaseq_amd as pa
+    from pandaseq_amd import synth
+    n = 1_000_000
+    spec = synth.config_spec(cfg)
+    f, r, fl, rl = synth.generate_device(spec, 0, n)
+    recs = []
+    for fast_path in (True, False):
+        asm, _ = bench.setup_assembler(pa, synth, cfg, 0, exact_sums=sums == "exact")
+        asm.set_fast_path(fast_path)
+        outs = pa.alloc_outputs(n, n * 600 + (1 << 28), "cuda:0")
+        b = pa.DeviceBatch(n=n, fwd=f, rev=r, flen=fl, rlen=rl, **outs)
+        asm.assemble_device(b)
+        torch.cuda.synchronize()
+        asm.check_overflow()
+        res = b.results_numpy().copy()
+        c = b.counters_dict()
+        assert c["count"] == n == c["ok"] + c["noalgn"] + c["lowq"] + c["badr"] + c["nofp"] + c["norp"] + sum(c["rejected"])
+        assert int(c["overlapcount"].sum()) == c["ok"] == int((res["status"] == 0).sum())
+        ok = res["status"] == 0
+        L = spec.read_len
+        assert (res["seq_len"][ok].astype(np.int64) == 2 * L - res["overlap"][ok].astype(np.int64) - res["fwd_offset"][ok] - res["rev_offset"][ok]).all()
+        rows = ok & (res["seq_len"] > 0)   # (primers "found" at the very end of both reads leave an empty merge: no row)
+        offs = res["seq_offset"][rows].astype(np.int64)
+        order = np.argsort(offs)
+        ends = offs[order] + res["seq_len"][rows][order]
+        assert (offs % 16 == 0).all() and (ends[:-1] <= offs[order][1:]).all() and ends[-1] <= int(b.cursor.item())
+        recs.append((res, c))
+        del b, outs
+        torch.cuda.empty_cache()
+    (ra, ca), (rb, cb) = recs
+    for k in ("status", "overlap", "seq_len", "examined", "mismatches", "degenerates", "fwd_offset", "rev_offset", "slow", "reject_module"):
+        assert np.array_equal(ra[k], rb[k]), k
+    assert np.array_equal(ca["overlapcount"], cb["overlapcount"])
+    if sums == "exact":
+        assert np.array_equal(ra["quality"].view(np.uint64), rb["quality"].view(np.uint64))
+    else:
+        assert np.abs(ra["quality"] - rb["quality"]).max() <= 1e-9
 
 
 def _row_checksums(b, res, ok, sample=4000):

@@ -19,6 +19,8 @@ def adversarial_pairs(spec, n, seed=1, ragged=True, weird_quals=True, iupac=True
             arr[:, :L, 0][m] = rng.integers(3, 15, size=int(m.sum())).astype(np.uint8)
             m = rng.random((n, L)) < 0.003
             arr[:, :L, 0][m] = 15
+            m = rng.random((n, L)) < 0.0005
+            arr[:, :L, 0][m] = 0    # not a nucleotide at all: matches nothing, hashes as A (misc.h:41)
     if weird_quals:
         for arr in (fwd, rev):
             m = rng.random((n, L)) < 0.003
