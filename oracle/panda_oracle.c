@@ -138,6 +138,16 @@ void po_config_default(po_config *c) {	/* assembler_support.c:61-97 */
 	c->primer_penalty = 0;
 }
 
+/* the two one-line pieces of the input domain, exported so that tests can hold them against the reference's own macros
+ * (oracle/ref_macros.c: PHREDCLAMP prob.h:23, PANDA_NT_IS_DEGN pandaseq-nt.h:55) */
+int po_phredclamp(int q) {
+	return clampq(q);
+}
+
+int po_nt_is_degenerate(unsigned nt) {
+	return is_degenerate(nt);
+}
+
 /* ------------------------------------------------------------------ k-mers */
 
 static inline unsigned kcode(unsigned nt) {	/* misc.h:41: T=3 G=2 C=1, everything else 0 */

@@ -152,6 +152,8 @@ int po_result_phred(const po_tables *t, double p);
 double po_log1mexp(double p);	/* panda_log1mexp, offset.c:35-38 */
 /* panda_compute_offset_result (offset.c:114-133): the primer scan over merged bases; reverse = from the 3' end */
 size_t po_compute_offset_result(double threshold, double penalty, int reverse, const uint8_t *nt, const double *p, size_t len, const uint8_t *primer, size_t plen);
+int po_phredclamp(int q);		/* PHREDCLAMP, prob.h:23 */
+int po_nt_is_degenerate(unsigned nt);	/* PANDA_NT_IS_DEGN, pandaseq-nt.h:55 */
 size_t po_kmers_forward(const po_qual *s, size_t len, uint16_t *kmer, uint16_t *posn);
 size_t po_kmers_reverse(const po_qual *s, size_t len, uint16_t *kmer, uint16_t *posn);
 

@@ -105,6 +105,8 @@ def lib():
         L.po_kmers_forward.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.po_kmers_reverse.restype = C.c_size_t
         L.po_kmers_reverse.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.po_phredclamp.argtypes = [C.c_int]
+        L.po_nt_is_degenerate.argtypes = [C.c_uint]
         batch_args = [C.POINTER(Config), C.POINTER(Tables), C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.po_assemble_batch.argtypes = batch_args

@@ -309,3 +309,72 @@ def test_stat_block_format():
     assert lines[1] == "g0\tSTAT\tNOALGN\t2" and "g0\tSTAT\tmin_phred\t1" in lines and lines[-2] == "g0\tSTAT\tOK\t7"
     assert lines[-1] == "g0\tSTAT\tOVERLAPS\t0 0 0 7"   # proxy.c:182-187: bins 0..longest_overlap
     assert [shard_range(10, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]
+
+
+# ---------------------------------------------------------------- pinned on the reference's own header-only macros
+
+def test_kmer_macros_of_the_reference_pin_the_oracle(po):
+    """FOREACH_KMER / FOREACH_KMER_REVERSE (misc.h:36-45), compiled from the reference's own text (oracle/ref_macros.c),
+    against the oracle's restatement: same (k-mer, position) emissions in the same order on adversarial reads (Ns, IUPAC
+    codes, nt 0, ragged lengths down to 0) -- SURVEY.md 8a row a3."""
+    import ctypes as C
+
+    import pins
+    from pandaseq_amd import synth
+    from util import adversarial_pairs
+    if pins.lib() is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference; built by __graft_entry__.build() in the dev container)")
+    assert pins.lib().ref_kmer_len() == 8
+    L = po.lib()
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = adversarial_pairs(spec, 400, seed=3)
+    emitted = 0
+    for reads, lens in ((fwd, flen), (rev, rlen)):
+        for i in range(len(reads)):
+            n = int(lens[i])
+            row = np.ascontiguousarray(reads[i])
+            for reverse in (False, True):
+                rk, rp = pins.kmers(row, n, reverse)
+                k = np.zeros(512, dtype=np.uint16)
+                p = np.zeros(512, dtype=np.uint16)
+                m = (L.po_kmers_reverse if reverse else L.po_kmers_forward)(row.ctypes.data, n, k.ctypes.data, p.ctypes.data)
+                assert m == len(rk) and np.array_equal(k[:m], rk) and np.array_equal(p[:m], rp), (i, reverse)
+                emitted += m
+    assert emitted > 100000
+
+
+def test_domain_macros_of_the_reference_pin_the_oracle(po):
+    """PHREDCLAMP (prob.h:23) over every char, PANDA_NT_IS_N / PANDA_NT_IS_DEGN (pandaseq-nt.h:51-55) over every byte."""
+    import pins
+    R = pins.lib()
+    if R is None:
+        pytest.skip("oracle/_ref not built")
+    L = po.lib()
+    for q in range(-128, 128):
+        assert R.ref_phredclamp(q) == L.po_phredclamp(q) == min(46, max(0, q))
+    for nt in range(16):   # panda_nt is a 4-bit IUPAC set (pandaseq-nt.h:35-50); the macro's bit trick means nothing beyond it
+        assert R.ref_nt_is_degn(nt) == L.po_nt_is_degenerate(nt) == (1 if bin(nt).count("1") != 1 else 0), nt
+    for nt in range(256):
+        assert R.ref_nt_is_n(nt) == (1 if nt == 15 else 0)
+
+
+def test_candidate_sets_from_reference_kmers_match_the_oracle(po):
+    """overlaps_examined rebuilt from the reference macros' k-mers (tests/pins.py) equals the oracle's on every pair
+    whose scan ran: the seeding of assembler.c:84-118 on top of pinned k-mers."""
+    import pins
+    from pandaseq_amd import synth
+    from util import adversarial_pairs
+    if pins.lib() is None:
+        pytest.skip("oracle/_ref not built")
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = adversarial_pairs(spec, 1500, seed=9)
+    res = po.assemble_batch(po.make_config("simple_bayesian"), fwd, rev, flen, rlen, want_seq=False)[0]
+    checked = 0
+    for i in range(len(res)):
+        ex = pins.examined(fwd[i], rev[i], flen[i], rlen[i])
+        if ex is None:
+            assert res["status"][i] in (1, 4)
+            continue
+        assert int(res["examined"][i]) == ex, i
+        checked += 1
+    assert checked > 1000
