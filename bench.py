@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs[] index")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (0 = the config's size)")
+    ap.add_argument("--chunk-pairs", type=int, default=0, help="pairs per launch (0 = the whole shard when its output fits in HBM beside "
+                                                                "its input, else the largest chunk whose two output arenas do)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-clock target of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sums", choices=["fast", "exact"], default="fast",
@@ -129,28 +131,50 @@ def main():
     cal = make_batch(ncal, first, ncal * 912)
     asm.assemble_device(cal)
     torch.cuda.synchronize()
+    asm.check_overflow()
     used = int(cal.cursor.item())
     per_pair = used / ncal
     del cal
     torch.cuda.empty_cache()
-    while True:
-        try:
-            capacity = int(n * per_pair * 1.03) + (1 << 28)
-            batch = make_batch(n, first, capacity)
-            break
-        except torch.OutOfMemoryError:
-            torch.cuda.empty_cache()
-            n //= 2
-            if n < 1024:
-                raise
+    # The shard's INPUT is resident as a whole.  Its merged output is too when it fits beside it (config 1); otherwise the
+    # launch is cut into chunks of pairs whose rows go to two arenas used in turn (a consumer would drain one while the
+    # other fills): every pair is still assembled and every output byte written in the timed region, the arena is reused.
+    # No halving of the shard: a shard that cannot be served fails.
+    stride = spec.row_stride()
+    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    fixed = n * (2 * stride * 2 + 4 + 48) + (1 << 30)
+    slack = 1 << 28
+
+    def arena_bytes(pairs):
+        return 9 * (int(pairs * per_pair * 1.03) + slack)
+
+    budget = int(free_b * 0.94)
+    if args.chunk_pairs:
+        chunk = min(n, args.chunk_pairs)
+    elif fixed + arena_bytes(n) <= budget:
+        chunk = n
+    else:
+        chunk = n
+        while chunk > (1 << 20) and fixed + 2 * arena_bytes(chunk) > budget:
+            chunk = (chunk + 1) // 2
+        if fixed + 2 * arena_bytes(chunk) > budget:
+            raise SystemExit(f"a shard of {n} pairs does not fit this GPU ({free_b >> 30} GiB free)")
+    n_chunks = (n + chunk - 1) // chunk
+    f, r, fl, rl = synth.generate_device(spec, first, n, device=dev)
+    arenas = [pa.alloc_outputs(0, int(chunk * per_pair * 1.03) + slack, dev, seq_stride=0) for _ in range(1 if n_chunks == 1 else 2)]
+    results = torch.empty((n, 48), dtype=torch.uint8, device=dev)
+    batch = pa.DeviceBatch(n=n, fwd=f, rev=r, flen=fl, rlen=rl, results=results, seq_nt=arenas[0]["seq_nt"], seq_p=arenas[0]["seq_p"],
+                           cursor=arenas[0]["cursor"], counters=arenas[0]["counters"], seq_stride=0)
     torch.cuda.synchronize()
 
     def one_step(ev0=None, ev1=None):
-        batch.cursor.zero_()
         batch.counters.zero_()
         if ev0 is not None:
             ev0.record()
-        asm.assemble_device(batch)
+        for k in range(n_chunks):
+            ar = arenas[k % len(arenas)]
+            ar["cursor"].zero_()
+            asm.assemble_device(batch, first=k * chunk, count=min(chunk, n - k * chunk), arena=ar)
         if ev1 is not None:
             ev1.record()
         if dist is not None:
@@ -180,7 +204,7 @@ def main():
     ctr = batch.counters_dict()
     total_expected = n * world if dist is not None else n
     assert ctr["count"] == total_expected, (ctr["count"], total_expected)
-    assert int(batch.cursor.item()) <= batch.capacity - 16, "output arena overflow"
+    asm.check_overflow()   # raises if a row did not fit its arena
 
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
     avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
@@ -225,11 +249,13 @@ def main():
             "workload": CONFIGS[cfg_index]["name"] + (f" [scorer overridden: {args.algo}]" if args.algo else "") + (" [-a]" if args.primers_after else ""),
             "config_index": cfg_index,
             "pairs_per_gpu": n,
+            "launches_per_step": n_chunks,
+            "pairs_per_launch": chunk,
             "read_len": L,
             "algorithm": args.algo or CONFIGS[cfg_index]["algo"],
             "primers_after": bool(args.primers_after),
             "sharding": f"{world} contiguous shard(s), one RCCL all-reduce of STAT counters per step" if world > 1 else "single GPU",
-            "output": "compact arena, nt u8 + log-p f64 per merged base",
+            "output": "compact arena, nt u8 + log-p f64 per merged base" + ("" if n_chunks == 1 else f"; the shard's input is resident, its output goes to two arenas used in turn, {chunk} pairs per launch"),
             "sums": ("reference order (all outputs bit-identical)" if args.sums == "exact" else
                      "any order + exactness guards (decisions, bases, per-base log-p bit-identical; quality / est_overlap_prob within 1e-9)"),
             "launch": asm.last_launch_info(),

@@ -190,6 +190,12 @@ int pamd_tables_get(double *out, size_t n_doubles);
 
 /* Enqueue the assembly of one batch on `stream`; returns once launched (asynchronous). */
 int pamd_assemble_device(pamd_assembler *a, const pamd_batch *batch, void *stream);
+/* The same for pairs [first, first + count) of a batch that is resident as a whole: the streaming form of the reference's
+ * unbounded loop (pool.c:71-108) when a shard's merged output does not fit beside its input.  Records go to
+ * results[first ..]; with a compact arena the caller decides where this range's rows go by what seq_nt / seq_p /
+ * seq_cursor / seq_capacity it passes (e.g. two arenas used in turn, each drained while the other fills); with strided
+ * rows pair i still writes at i * seq_stride. */
+int pamd_assemble_device_range(pamd_assembler *a, const pamd_batch *batch, size_t first, size_t count, void *stream);
 /* After the launch has completed (synchronise the stream first): 0, or PAMD_EINVAL when pairs of the most recent
  * pamd_assemble_device() on this assembler did not fit in seq_capacity (their records say PAMD_ST_NOSPACE);
  * *n_overflowed (may be NULL) receives how many.  Resets the flag. */

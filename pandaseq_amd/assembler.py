@@ -190,8 +190,10 @@ class Assembler:
         check(lib().pamd_assemble_status(self._h, C.byref(n)))
 
     # ---- the hot path ----
-    def assemble_device(self, b: DeviceBatch, stream=None):
-        """Enqueue the assembly of a device-resident batch on the current (or given) torch stream."""
+    def assemble_device(self, b: DeviceBatch, stream=None, first=None, count=None, arena=None):
+        """Enqueue the assembly of a device-resident batch on the current (or given) torch stream.
+        first / count: only pairs [first, first + count) (pamd_assemble_device_range); arena: a dict with seq_nt, seq_p,
+        cursor (as from alloc_outputs) that receives this range's rows instead of the batch's own arena."""
         torch = _torch()
         st = stream if stream is not None else torch.cuda.current_stream(b.fwd.device)
         cb = Batch()
@@ -205,7 +207,14 @@ class Assembler:
         cb.seq_capacity = b.capacity - 16
         cb.seq_cursor = b.cursor.data_ptr()
         cb.counters = b.counters.data_ptr()
-        check(lib().pamd_assemble_device(self._h, C.byref(cb), C.c_void_p(st.cuda_stream)))
+        if arena is not None:
+            cb.seq_nt, cb.seq_p = arena["seq_nt"].data_ptr(), arena["seq_p"].data_ptr()
+            cb.seq_capacity = int(arena["seq_nt"].numel()) - 16
+            cb.seq_cursor = arena["cursor"].data_ptr()
+        if first is not None:
+            check(lib().pamd_assemble_device_range(self._h, C.byref(cb), int(first), int(count if count is not None else b.n - first), C.c_void_p(st.cuda_stream)))
+        else:
+            check(lib().pamd_assemble_device(self._h, C.byref(cb), C.c_void_p(st.cuda_stream)))
 
     def last_kernel_ms(self) -> float:
         return float(lib().pamd_last_kernel_ms(self._h))

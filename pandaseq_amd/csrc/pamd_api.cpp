@@ -625,6 +625,25 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	return PAMD_OK;
 }
 
+int pamd_assemble_device_range(pamd_assembler *a, const pamd_batch *b, size_t first, size_t count, void *stream) {
+	if (a == nullptr || b == nullptr || first > b->n_pairs || count > b->n_pairs - first) {
+		pamd_set_error("pamd_assemble_device_range: range outside the batch");
+		return PAMD_EINVAL;
+	}
+	pamd_batch r = *b;
+	r.n_pairs = count;
+	r.fwd = b->fwd + first * b->fwd_stride;
+	r.rev = b->rev + first * b->rev_stride;
+	r.flen = b->flen + first;
+	r.rlen = b->rlen + first;
+	r.results = b->results + first;
+	if (b->seq_stride != 0) {	// strided rows: pair i of the batch keeps its row
+		r.seq_nt = b->seq_nt + first * b->seq_stride;
+		r.seq_p = b->seq_p + first * b->seq_stride;
+	}
+	return pamd_assemble_device(a, &r, stream);
+}
+
 float pamd_last_kernel_ms(pamd_assembler *a) {
 	if (a == nullptr || !a->timed)
 		return -1.0f;

@@ -126,3 +126,49 @@ def test_arena_overflow_through_the_device_path(built):
                 off, m = int(res["seq_offset"][i]), int(res["seq_len"][i])
                 assert off + m <= 600_000
                 assert np.array_equal(nt[off:off + m], o_nt[i, :m]) and np.array_equal(p[off:off + m], o_p[i, :m])
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_streaming_a_shard_in_chunks(built, exact):
+    """pamd_assemble_device_range (the streaming form of pool.c:71-108): a resident shard assembled in three launches whose
+    rows go to two arenas used in turn gives the counters and records of the single launch; rows of a chunk are intact
+    until its arena is used again."""
+    import torch
+
+    import pandaseq_amd as pa
+    from pandaseq_amd import synth
+    spec = synth.config_spec(1)
+    n, chunk = 30_000, 11_000
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
+    asm = pa.Assembler(0)
+    asm.set_exact_sums(exact)
+    whole = pa.upload_batch(fwd, rev, flen, rlen, device="cuda:0", seq_stride=0)
+    asm.assemble_device(whole)
+    torch.cuda.synchronize()
+    asm.check_overflow()
+    b = pa.upload_batch(fwd, rev, flen, rlen, device="cuda:0", seq_stride=0, capacity=16)
+    arenas = [pa.alloc_outputs(0, chunk * 440 + 2 * 16384 * 4096, "cuda:0") for _ in range(2)]
+    res_w = whole.results_numpy()
+    nt_w, p_w = whole.seq_nt.cpu().numpy(), whole.seq_p.cpu().numpy()
+    for k in range(3):
+        ar = arenas[k % 2]
+        ar["cursor"].zero_()
+        lo, cnt = k * chunk, min(chunk, n - k * chunk)
+        asm.assemble_device(b, first=lo, count=cnt, arena=ar)
+        torch.cuda.synchronize()
+        asm.check_overflow()
+        res = b.results_numpy()[lo:lo + cnt]
+        nt, p = ar["seq_nt"].cpu().numpy(), ar["seq_p"].cpu().numpy()
+        for name in res.dtype.names:
+            if name not in ("seq_offset", "reserved", "quality"):
+                assert np.array_equal(res[name], res_w[name][lo:lo + cnt]), name
+        if exact:
+            assert np.array_equal(res["quality"].view(np.uint64), res_w["quality"][lo:lo + cnt].view(np.uint64))
+        else:
+            assert np.abs(res["quality"] - res_w["quality"][lo:lo + cnt]).max() <= 1e-9
+        for i in np.nonzero(res["status"] == 0)[0][::11]:
+            m, o1, o2 = int(res["seq_len"][i]), int(res["seq_offset"][i]), int(res_w["seq_offset"][lo + i])
+            assert np.array_equal(nt[o1:o1 + m], nt_w[o2:o2 + m]) and np.array_equal(p[o1:o1 + m], p_w[o2:o2 + m])
+    assert np.array_equal(b.counters.cpu().numpy(), whole.counters.cpu().numpy())
+    with pytest.raises(pa.PamdError, match="range outside"):
+        asm.assemble_device(b, first=n - 5, count=6, arena=arenas[0])
