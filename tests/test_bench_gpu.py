@@ -56,3 +56,17 @@ def test_bench_two_ranks_sharded(built):
     assert single.returncode == 0, single.stderr[-2000:]
     s = json.loads(single.stdout.strip().splitlines()[-1])
     assert d["stat"] == s["stat"]
+
+
+def test_bench_chunked_launches(built):
+    """A shard cut into three launches (what bench.py does by itself when the output does not fit beside the input)
+    reports the same counters as the single launch, and says how it ran."""
+    runs = []
+    for extra in ([], ["--chunk-pairs", "110000"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "300000", "--steps", "1", "--warmup", "0", "--no-cpu"] + extra,
+                             capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        runs.append(_check(out.stdout.strip().splitlines()[-1], 1, 1, 0))
+    assert runs[0]["config"]["launches_per_step"] == 1 and runs[1]["config"]["launches_per_step"] == 3
+    assert runs[0]["stat"] == runs[1]["stat"]
+    assert runs[0]["roofline"]["algorithmic_bytes_per_launch"] == runs[1]["roofline"]["algorithmic_bytes_per_launch"]
