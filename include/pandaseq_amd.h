@@ -196,6 +196,14 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *batch, void *strea
  * seq_cursor / seq_capacity it passes (e.g. two arenas used in turn, each drained while the other fills); with strided
  * rows pair i still writes at i * seq_stride. */
 int pamd_assemble_device_range(pamd_assembler *a, const pamd_batch *batch, size_t first, size_t count, void *stream);
+/* Merged log-probabilities as table indices, for the trip to the host (2 bytes per base instead of 8): every log-p the
+ * kernels write (panda_result.p, pandaseq-common.h:221-230) is an entry of the assembler's table image for the
+ * current algorithm -- qual_score[], the scorer's match / mismatch matrices, qual_nn -- so seq_idx[j] = its index and
+ * pamd_table_image()[seq_idx[j]] is seq_p[j], bit for bit.  n_bases values starting at seq_p (16-byte aligned; rounded up
+ * to an even count); what lies between rows of a compact arena encodes as 0xFFFF.  Enqueued on `stream`. */
+int pamd_encode_rows_device(pamd_assembler *a, const double *seq_p, size_t n_bases, uint16_t *seq_idx, void *stream);
+/* the image itself (host side): *used doubles are written to out (capacity n_doubles) */
+int pamd_table_image(pamd_assembler *a, double *out, size_t n_doubles, size_t *used);
 /* After the launch has completed (synchronise the stream first): 0, or PAMD_EINVAL when pairs of the most recent
  * pamd_assemble_device() on this assembler did not fit in seq_capacity (their records say PAMD_ST_NOSPACE);
  * *n_overflowed (may be NULL) receives how many.  Resets the flag. */

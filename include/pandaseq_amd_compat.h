@@ -234,10 +234,17 @@ double panda_quality_log_probability(const panda_qual *q);	/* qual_score[PHREDCL
 char panda_result_phred(const panda_result *r);			/* the reference's bisection over qual_score, quirks included */
 
 /* ---- extensions (not in the reference) ---- */
-/* which GPU new assemblers are created on (default 0), and how many pairs panda_assembler_next()
- * pulls from the source per kernel launch (default 16384) */
+/* Which GPU a new assembler is created on, in this order: the calling thread's own choice
+ * (pamd_compat_set_thread_device; a negative value clears it), else the next entry -- round robin over the process -- of
+ * the environment variable PAMD_DEVICES ("0,1,2,3": the embedder that builds one assembler per thread, pool.c:140-160,
+ * gets them spread over the GPUs without a code change), else the process default (pamd_compat_set_device, 0). */
 void pamd_compat_set_device(int device);
+void pamd_compat_set_thread_device(int device);
+/* how many pairs panda_assembler_next() pulls from the source per batch (default 65536); two batches are in flight */
 void pamd_compat_set_batch_pairs(size_t pairs);
+/* how assemblers created from now on sum quality and pear / rdp_mle scores (pamd_set_exact_sums): 1 (default) = in the
+ * reference's order, every output bit-identical; 0 = any order with every decision guarded, faster */
+void pamd_compat_set_exact_sums(int exact);
 
 #ifdef __cplusplus
 }

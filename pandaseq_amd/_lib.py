@@ -69,7 +69,7 @@ SYMBOLS = [
     "pamd_set_primer_penalty", "pamd_set_primers_after", "pamd_add_module_min_phred", "pamd_add_module_min_overlapbits",
     "pamd_clear_modules", "pamd_set_exact_sums", "pamd_tables_get", "pamd_assemble_device", "pamd_assemble_host",
     "pamd_last_kernel_ms", "pamd_last_launch_info", "pamd_synth_generate", "pamd_debug_phase_cycles",
-    "pamd_assemble_status", "pamd_set_fast_path", "pamd_last_deferred", "pamd_assemble_device_range",
+    "pamd_assemble_status", "pamd_set_fast_path", "pamd_last_deferred", "pamd_assemble_device_range", "pamd_encode_rows_device", "pamd_table_image",
 ]
 
 
@@ -114,6 +114,8 @@ def lib():
     L.pamd_assemble_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
     L.pamd_assemble_host.argtypes = [C.c_void_p, C.POINTER(Batch)]
     L.pamd_assemble_device_range.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_size_t, C.c_size_t, C.c_void_p]
+    L.pamd_encode_rows_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.pamd_table_image.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.pamd_assemble_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.pamd_set_fast_path.argtypes = [C.c_void_p, C.c_int]
     L.pamd_last_deferred.restype = C.c_longlong

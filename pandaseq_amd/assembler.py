@@ -216,6 +216,24 @@ class Assembler:
         else:
             check(lib().pamd_assemble_device(self._h, C.byref(cb), C.c_void_p(st.cuda_stream)))
 
+    def encode_rows(self, b: "DeviceBatch", n_bases=None, stream=None):
+        """The batch's merged log-p as u16 indices into table_image() (2 bytes per base for the trip to the host):
+        returns an int16-storage tensor of n_bases entries (default: the arena's used part)."""
+        torch = _torch()
+        st = stream if stream is not None else torch.cuda.current_stream(b.fwd.device)
+        n = int(b.cursor.item()) if n_bases is None else int(n_bases)
+        n = (n + 1) & ~1
+        out = torch.empty(max(n, 2), dtype=torch.int16, device=b.seq_p.device)
+        check(lib().pamd_encode_rows_device(self._h, b.seq_p.data_ptr(), n, out.data_ptr(), C.c_void_p(st.cuda_stream)))
+        return out[:n]
+
+    def table_image(self):
+        """The table image the indices of encode_rows() point into (host copy, float64)."""
+        buf = np.zeros(8192, dtype=np.float64)
+        used = C.c_size_t(0)
+        check(lib().pamd_table_image(self._h, buf.ctypes.data, buf.size, C.byref(used)))
+        return buf[:used.value].copy()
+
     def last_kernel_ms(self) -> float:
         return float(lib().pamd_last_kernel_ms(self._h))
 

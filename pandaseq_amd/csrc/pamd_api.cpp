@@ -70,6 +70,8 @@ struct pamd_assembler {
 	unsigned *d_defer_count = nullptr;	// ... and how many
 	bool last_two_kernels = false;
 	double *d_notp = nullptr;
+	std::vector<double> h_image;	// host copy of the table image on the device (pamd_table_image)
+	uint16_t *d_slots = nullptr;	// log-p -> index of the image (pamd_encode.hip)
 	// tables
 	PamdTables tabs;
 	double *d_tables = nullptr;	// image for the current algorithm
@@ -168,7 +170,7 @@ pamd_assembler *pamd_assembler_create(int device) {
 	a->pear_random_base = std::log(0.25);	// algo_pear.c:106
 	a->threshold = std::log(0.6);	// assembler_support.c:76
 	memset(a->primers, 0, sizeof a->primers);
-	if (hipMalloc(&a->d_tables, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_notp, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_primers, sizeof a->primers) != hipSuccess || hipMalloc(&a->d_error, sizeof(unsigned long long)) != hipSuccess || hipMalloc(&a->d_defer_count, sizeof(unsigned)) != hipSuccess || hipMemset(a->d_defer_count, 0, sizeof(unsigned)) != hipSuccess || hipMalloc(&a->d_phase, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_phase, 0, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_error, 0, sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&a->ev_start) != hipSuccess || hipEventCreate(&a->ev_stop) != hipSuccess) {
+	if (hipMalloc(&a->d_tables, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_notp, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_primers, sizeof a->primers) != hipSuccess || hipMalloc(&a->d_slots, PAMD_ENCODE_SLOTS * sizeof(uint16_t)) != hipSuccess || hipMalloc(&a->d_error, sizeof(unsigned long long)) != hipSuccess || hipMalloc(&a->d_defer_count, sizeof(unsigned)) != hipSuccess || hipMemset(a->d_defer_count, 0, sizeof(unsigned)) != hipSuccess || hipMalloc(&a->d_phase, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_phase, 0, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_error, 0, sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&a->ev_start) != hipSuccess || hipEventCreate(&a->ev_stop) != hipSuccess) {
 		pamd_set_error("device allocation failed on device %d", device);
 		pamd_assembler_destroy(a);
 		return nullptr;
@@ -186,6 +188,8 @@ void pamd_assembler_destroy(pamd_assembler *a) {
 		(void) hipFree(a->d_notp);
 	if (a->d_primers)
 		(void) hipFree(a->d_primers);
+	if (a->d_slots)
+		(void) hipFree(a->d_slots);
 	if (a->d_error)
 		(void) hipFree(a->d_error);
 	if (a->d_phase)
@@ -393,6 +397,20 @@ static int upload_tables(pamd_assembler *a, hipStream_t st) {
 		for (size_t i = 0; i < img.size(); i++)
 			notp[i] = (img[i] > M_LN2) ? std::log1p(-std::exp(-img[i])) : std::log(-std::expm1(-img[i]));
 		HIP_TRY(hipMemcpy(a->d_notp, notp.data(), sizeof(double) * notp.size(), hipMemcpyHostToDevice));
+		// log-p -> index: open addressing over the distinct values of the image (the first index of a value wins)
+		const size_t n_image = a->algo == PAMD_ALGO_RDP_MLE ? img.size() : (size_t) PAMD_LT_C;
+		a->h_image.assign(img.begin(), img.begin() + n_image);
+		std::vector<uint16_t> slots(PAMD_ENCODE_SLOTS, 0xFFFFu);
+		for (size_t i = 0; i < n_image; i++) {
+			unsigned long long bits;
+			memcpy(&bits, &img[i], 8);
+			unsigned h = (unsigned) ((bits * 0x9E3779B97F4A7C15ull) >> 50) & (PAMD_ENCODE_SLOTS - 1u);
+			while (slots[h] != 0xFFFFu && memcmp(&img[slots[h]], &img[i], 8) != 0)
+				h = (h + 1u) & (PAMD_ENCODE_SLOTS - 1u);
+			if (slots[h] == 0xFFFFu)
+				slots[h] = (uint16_t) i;
+		}
+		HIP_TRY(hipMemcpy(a->d_slots, slots.data(), slots.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
 		a->d_tables_algo = a->algo;
 	}
 	if (a->primers_dirty) {
@@ -642,6 +660,37 @@ int pamd_assemble_device_range(pamd_assembler *a, const pamd_batch *b, size_t fi
 		r.seq_p = b->seq_p + first * b->seq_stride;
 	}
 	return pamd_assemble_device(a, &r, stream);
+}
+
+int pamd_encode_rows_device(pamd_assembler *a, const double *seq_p, size_t n_bases, uint16_t *seq_idx, void *stream) {
+	if (a == nullptr || seq_p == nullptr || seq_idx == nullptr || ((uintptr_t) seq_p & 15u) || ((uintptr_t) seq_idx & 3u)) {
+		pamd_set_error("pamd_encode_rows_device: null or misaligned argument");
+		return PAMD_EINVAL;
+	}
+	HIP_TRY(hipSetDevice(a->device));
+	int rc = upload_tables(a, static_cast<hipStream_t>(stream));
+	if (rc != PAMD_OK)
+		return rc;
+	return pamd_launch_encode(seq_p, seq_idx, n_bases, a->d_tables, (unsigned) a->h_image.size(), a->d_slots, stream);
+}
+
+int pamd_table_image(pamd_assembler *a, double *out, size_t n_doubles, size_t *used) {
+	if (a == nullptr || out == nullptr) {
+		pamd_set_error("pamd_table_image: null argument");
+		return PAMD_EINVAL;
+	}
+	HIP_TRY(hipSetDevice(a->device));
+	int rc = upload_tables(a, nullptr);
+	if (rc != PAMD_OK)
+		return rc;
+	if (n_doubles < a->h_image.size()) {
+		pamd_set_error("pamd_table_image: need room for %zu doubles", a->h_image.size());
+		return PAMD_EINVAL;
+	}
+	memcpy(out, a->h_image.data(), a->h_image.size() * sizeof(double));
+	if (used)
+		*used = a->h_image.size();
+	return PAMD_OK;
 }
 
 float pamd_last_kernel_ms(pamd_assembler *a) {

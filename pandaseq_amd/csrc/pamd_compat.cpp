@@ -3,14 +3,19 @@
 // per-pair callbacks and counters in source order (assembler.c:252-366), and the getters/setters of
 // assembler_support.c.  All assembly arithmetic happens in the HIP kernel; nothing here scores,
 // merges or sums anything.
+#include <hip/hip_runtime_api.h>
 #include <dlfcn.h>
+#include <atomic>
 #include <cctype>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "pamd_internal.h"
 #include "../../include/pandaseq_amd_compat.h"
@@ -22,9 +27,34 @@ static_assert(sizeof(panda_result_seq) == 480 && offsetof(panda_result_seq, sequ
 static_assert(sizeof(panda_qual) == sizeof(pamd_qual), "panda_qual == pamd_qual");
 
 namespace {
-int g_device = 0;
-size_t g_batch_pairs = 16384;
+// Which GPU a new assembler lives on: the calling thread's own choice (pamd_compat_set_thread_device), else the next
+// entry of PAMD_DEVICES ("0,1,2,3": an embedder that builds one assembler per thread, as pool.c:140-160 does, then
+// spreads them over the GPUs without a code change), else the process default (pamd_compat_set_device).
+std::atomic<int> g_device{0};
+thread_local int t_device = -1;
+std::atomic<unsigned> g_device_rr{0};
+std::atomic<size_t> g_batch_pairs{65536};
+std::atomic<int> g_exact_sums{1};
 std::mutex g_ref_lock;	// one lock for all refcounts, like module.c:38-41
+
+int pick_device() {
+	if (t_device >= 0)
+		return t_device;
+	if (const char *list = getenv("PAMD_DEVICES")) {
+		std::vector<int> ids;
+		for (const char *c = list; *c;) {
+			char *end = nullptr;
+			const long v = strtol(c, &end, 10);
+			if (end == c)
+				break;
+			ids.push_back((int) v);
+			c = *end == ',' ? end + 1 : end;
+		}
+		if (!ids.empty())
+			return ids[g_device_rr.fetch_add(1) % ids.size()];
+	}
+	return g_device.load();
+}
 constexpr size_t ROW = 456;	// staging row stride in bases (>= PANDA_MAX_LEN, multiple of 8)
 constexpr size_t OUT_ROW = 912;	// strided output row (>= 2 * PANDA_MAX_LEN, multiple of 16)
 }
@@ -512,6 +542,16 @@ struct panda_assembler {
 	std::vector<double> h_p;
 	size_t batch_n = 0, batch_pos = 0;
 	bool eof = false;
+	// panda_assembler_next(): two batches in flight (see "the pipelined source path" below)
+	static constexpr int NSLOT = 4;	// batches in flight: upload, kernels, download and expansion of different batches overlap
+	struct pamd_slot *slots[NSLOT] = { nullptr, nullptr, nullptr, nullptr };
+	pamd_assembler *devs[NSLOT] = { nullptr, nullptr, nullptr, nullptr };	// one device assembler per slot (a launch owns its assembler's deferred list); devs[0] == dev
+	int cur = 0;
+	bool primed = false;
+	std::vector<double> image;	// host copy of the device's table image: log-p comes back as indices into it
+	double t_fill = 0, t_wait = 0, t_bg = 0;	// PAMD_COMPAT_STATS=1: seconds pulling + staging, blocked on a batch, and of background work
+	long n_batches = 0;
+	int device = 0;
 };
 
 namespace {
@@ -542,7 +582,10 @@ int push_config(PandaAssembler a) {
 		pamd_set_error("algorithm %s has no device implementation (user-registered classes are not supported)", a->algo ? panda_algorithm_class(a->algo)->name : "(null)");
 		return PAMD_EUNSUPPORTED;
 	}
-	pamd_assembler *d = a->dev;
+	for (pamd_assembler *d : a->devs) {
+	if (d == nullptr)
+		continue;
+	pamd_set_exact_sums(d, g_exact_sums.load());
 	pamd_set_algorithm(d, algo, param);
 	pamd_set_primers_after(d, a->post_primers ? 1 : 0);
 	pamd_set_threshold(d, std::exp(a->threshold));
@@ -575,6 +618,15 @@ int push_config(PandaAssembler a) {
 			pamd_set_error("module %s follows a host-callback module; kernel-implemented modules must come first", a->modules[i]->name);
 			return PAMD_EUNSUPPORTED;
 		}
+	}
+	}	// both device assemblers
+	{
+		a->image.assign(8192, 0.0);
+		size_t used = 0;
+		const int rc = pamd_table_image(a->dev, a->image.data(), a->image.size(), &used);
+		if (rc != PAMD_OK)
+			return rc;
+		a->image.resize(used);
 	}
 	a->dev_dirty = false;
 	return PAMD_OK;
@@ -731,6 +783,373 @@ void stage_pair(PandaAssembler a, size_t i, const panda_seq_identifier *id, cons
 	a->h_pre[i] = pre;
 }
 
+// ---- the pipelined source path: panda_assembler_next() ------------------------------------------------------------
+// The reference overlaps reading with assembly through its prefetching reader thread (async.c:103-149) and hands a
+// worker one pair at a time (mux.c:132-161).  Here two batches are in flight: while the caller consumes the results of
+// batch k, batch k+1 is uploaded from pinned memory, assembled, its log-probabilities turned into table indices
+// (pamd_encode_rows_device: 3 bytes per base cross PCIe instead of 9), downloaded into pinned memory and expanded into
+// panda_result[] rows by a few helper threads.  The caller's thread only ever talks to the source (PandaNextSeq and the
+// module callbacks are the embedder's code, called from the thread that calls panda_assembler_next, in source order),
+// copies each pair's reads once, and fills in the record it returns.
+}	// namespace
+
+struct pamd_slot {
+	// pinned host memory
+	pamd_qual *h_fwd = nullptr, *h_rev = nullptr;
+	uint16_t *h_flen = nullptr, *h_rlen = nullptr;
+	pamd_pair_result *h_res = nullptr;
+	uint8_t *h_nt = nullptr;
+	uint16_t *h_idx = nullptr;
+	// device memory
+	pamd_qual *d_fwd = nullptr, *d_rev = nullptr;
+	uint16_t *d_flen = nullptr, *d_rlen = nullptr, *d_idx = nullptr;
+	pamd_pair_result *d_res = nullptr;
+	uint8_t *d_nt = nullptr;
+	double *d_p = nullptr;
+	int64_t *d_ctr = nullptr;
+	hipStream_t stream = nullptr;
+	size_t cap = 0;		// pairs all of the above are sized for (rows of ROW bases in, OUT_ROW bases out)
+	// the batch
+	std::vector<panda_result_seq> res;	// one record per pair pulled from the source; the source writes .name itself
+	std::vector<int> pre;			// -1 short read, >= 0 rejected by precheck module k, <= -3: device pair -(k+3)
+	panda_result *rows = nullptr;		// panda_result[] of the pairs the kernel accepted, back to back (never zero-filled)
+	size_t rows_cap = 0;
+	std::vector<size_t> row_off;		// per device pair: where its row starts in `rows`
+	size_t n = 0, n_dev = 0, pos = 0;
+	size_t stride = 256;	// bases per staged read row: 256 until a longer read arrives, then ROW
+	size_t seq_stride = 512;
+	pamd_assembler *dev = nullptr;
+	std::future<int> done;
+	std::string error;
+	double seconds = 0, sec_up = 0, sec_gpu = 0, sec_down = 0, sec_expand = 0;
+};
+
+namespace {
+
+// A read into its pinned staging row.  (Plain memcpy: streaming stores into hipHostMalloc'ed memory were measured six
+// times slower on this platform.)
+void stage_copy(pamd_qual *dst, const panda_qual *src, size_t bases) {
+	memcpy(dst, src, bases * sizeof(panda_qual));
+}
+
+double now_s() {
+	return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void slot_free(pamd_slot *s) {
+	if (s == nullptr)
+		return;
+	if (s->done.valid())
+		s->done.wait();
+	for (void *q : { (void *) s->h_fwd, (void *) s->h_rev, (void *) s->h_flen, (void *) s->h_rlen, (void *) s->h_res, (void *) s->h_nt, (void *) s->h_idx })
+		if (q)
+			(void) hipHostFree(q);
+	for (void *q : { (void *) s->d_fwd, (void *) s->d_rev, (void *) s->d_flen, (void *) s->d_rlen, (void *) s->d_idx, (void *) s->d_res, (void *) s->d_nt, (void *) s->d_p, (void *) s->d_ctr })
+		if (q)
+			(void) hipFree(q);
+	if (s->stream)
+		(void) hipStreamDestroy(s->stream);
+	free(s->rows);
+	delete s;
+}
+
+bool slot_reserve(PandaAssembler a, pamd_slot *s, size_t pairs) {
+	if (s->cap >= pairs)
+		return true;
+	if (hipSetDevice(a->device) != hipSuccess)
+		return false;
+	bool ok = true;
+	auto pin = [&](auto &ptr, size_t bytes) {
+		void *q = nullptr;
+		ok = ok && hipHostMalloc(&q, bytes, hipHostMallocDefault) == hipSuccess;
+		ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(q);
+	};
+	auto dev = [&](auto &ptr, size_t bytes) {
+		void *q = nullptr;
+		ok = ok && hipMalloc(&q, bytes) == hipSuccess;
+		ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(q);
+	};
+	// free what is there (no batch is in flight on a slot that is being refilled)
+	for (void *q : { (void *) s->h_fwd, (void *) s->h_rev, (void *) s->h_flen, (void *) s->h_rlen, (void *) s->h_res, (void *) s->h_nt, (void *) s->h_idx })
+		if (q)
+			(void) hipHostFree(q);
+	for (void *q : { (void *) s->d_fwd, (void *) s->d_rev, (void *) s->d_flen, (void *) s->d_rlen, (void *) s->d_idx, (void *) s->d_res, (void *) s->d_nt, (void *) s->d_p, (void *) s->d_ctr })
+		if (q)
+			(void) hipFree(q);
+	pin(s->h_fwd, pairs * ROW * sizeof(pamd_qual));
+	pin(s->h_rev, pairs * ROW * sizeof(pamd_qual));
+	pin(s->h_flen, pairs * 2);
+	pin(s->h_rlen, pairs * 2);
+	pin(s->h_res, pairs * sizeof(pamd_pair_result));
+	pin(s->h_nt, pairs * OUT_ROW);
+	pin(s->h_idx, pairs * OUT_ROW * 2);
+	dev(s->d_fwd, pairs * ROW * sizeof(pamd_qual));
+	dev(s->d_rev, pairs * ROW * sizeof(pamd_qual));
+	dev(s->d_flen, pairs * 2);
+	dev(s->d_rlen, pairs * 2);
+	dev(s->d_res, pairs * sizeof(pamd_pair_result));
+	dev(s->d_nt, pairs * OUT_ROW + 16);
+	dev(s->d_p, (pairs * OUT_ROW + 16) * sizeof(double));
+	dev(s->d_idx, (pairs * OUT_ROW + 16) * 2);
+	dev(s->d_ctr, PAMD_NUM_COUNTERS * 8);
+	if (s->stream == nullptr)
+		ok = ok && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+	s->cap = ok ? pairs : 0;
+	return ok;
+}
+
+// What the background thread of a batch does: upload, assemble, encode, download, expand.
+int slot_run(PandaAssembler a, pamd_slot *s) {
+#define SLOT_TRY(call)                                                          \
+	do {                                                                    \
+		hipError_t e_ = (call);                                         \
+		if (e_ != hipSuccess) {                                         \
+			s->error = std::string(#call ": ") + hipGetErrorString(e_); \
+			return PAMD_ENODEVICE;                                  \
+		}                                                               \
+	} while (0)
+	const size_t n = s->n_dev;
+	if (n == 0)
+		return PAMD_OK;
+	const double t_begin = now_s();
+	SLOT_TRY(hipSetDevice(a->device));
+	const size_t st = s->stride, ss = s->seq_stride;
+	SLOT_TRY(hipMemcpyAsync(s->d_fwd, s->h_fwd, n * st * sizeof(pamd_qual), hipMemcpyHostToDevice, s->stream));
+	SLOT_TRY(hipMemcpyAsync(s->d_rev, s->h_rev, n * st * sizeof(pamd_qual), hipMemcpyHostToDevice, s->stream));
+	SLOT_TRY(hipMemcpyAsync(s->d_flen, s->h_flen, n * 2, hipMemcpyHostToDevice, s->stream));
+	SLOT_TRY(hipMemcpyAsync(s->d_rlen, s->h_rlen, n * 2, hipMemcpyHostToDevice, s->stream));
+	pamd_batch b;
+	memset(&b, 0, sizeof b);
+	b.n_pairs = n;
+	b.fwd = s->d_fwd;
+	b.rev = s->d_rev;
+	b.fwd_stride = b.rev_stride = st;
+	b.flen = s->d_flen;
+	b.rlen = s->d_rlen;
+	b.results = s->d_res;
+	b.seq_nt = s->d_nt;
+	b.seq_p = s->d_p;
+	b.seq_stride = ss;	// strided rows: what comes back is n * ss bases, no cursor to wait for
+	b.seq_capacity = n * ss;
+	b.counters = nullptr;	// the counters are the caller's, kept in source order by replay
+	int rc = pamd_assemble_device(s->dev, &b, s->stream);
+	if (rc == PAMD_OK)
+		rc = pamd_encode_rows_device(s->dev, s->d_p, n * ss, s->d_idx, s->stream);
+	if (rc != PAMD_OK) {
+		s->error = pamd_last_error();
+		return rc;
+	}
+	SLOT_TRY(hipMemcpyAsync(s->h_res, s->d_res, n * sizeof(pamd_pair_result), hipMemcpyDeviceToHost, s->stream));
+	SLOT_TRY(hipMemcpyAsync(s->h_nt, s->d_nt, n * ss, hipMemcpyDeviceToHost, s->stream));
+	SLOT_TRY(hipMemcpyAsync(s->h_idx, s->d_idx, n * ss * 2, hipMemcpyDeviceToHost, s->stream));
+	SLOT_TRY(hipStreamSynchronize(s->stream));
+#undef SLOT_TRY
+	// expand the accepted rows into the reference's 16-byte panda_result (pandaseq-common.h:221-230): nt from the
+	// device, p = the table entry the index names -- the very double the kernel wrote
+	s->row_off.resize(n + 1);
+	size_t total = 0;
+	for (size_t k = 0; k < n; k++) {
+		s->row_off[k] = total;
+		if (s->h_res[k].status == PAMD_ST_OK)
+			total += s->h_res[k].seq_len;
+	}
+	s->row_off[n] = total;
+	if (s->rows_cap < total) {
+		free(s->rows);
+		s->rows_cap = total + total / 8 + 4096;
+		s->rows = static_cast<panda_result *>(malloc(s->rows_cap * sizeof(panda_result)));
+		if (s->rows == nullptr) {
+			s->rows_cap = 0;
+			s->error = "out of host memory for the merged rows";
+			return PAMD_ENOMEM;
+		}
+	}
+	const double *image = a->image.data();
+	const size_t n_image = a->image.size();
+	unsigned helpers = std::thread::hardware_concurrency() / 4;	// the expansion writes 16 bytes per base: memory-bound, it scales with threads
+	helpers = helpers < 1 ? 1 : (helpers > 32 ? 32 : helpers);
+	if (n < 4096)
+		helpers = 1;
+	std::atomic<int> bad{0};
+	auto expand = [&](size_t lo, size_t hi) {
+		for (size_t k = lo; k < hi; k++) {
+			const pamd_pair_result &d = s->h_res[k];
+			if (d.status != PAMD_ST_OK)
+				continue;
+			const uint8_t *nt = s->h_nt + k * ss;
+			const uint16_t *ix = s->h_idx + k * ss;
+			panda_result *out = s->rows + s->row_off[k];
+			for (size_t j = 0; j < d.seq_len; j++) {
+				if (ix[j] >= n_image) {
+					bad.store(1);
+					continue;
+				}
+				out[j].nt = (panda_nt) nt[j];
+				out[j].p = image[ix[j]];
+			}
+		}
+	};
+	std::vector<std::thread> team;
+	for (unsigned t = 1; t < helpers; t++)
+		team.emplace_back(expand, n * t / helpers, n * (t + 1) / helpers);
+	expand(0, n / helpers);
+	for (std::thread &t : team)
+		t.join();
+	if (bad.load()) {
+		s->error = "a merged log-probability is not an entry of the table image";
+		return PAMD_EINVAL;
+	}
+	s->seconds = now_s() - t_begin;
+	return PAMD_OK;
+}
+
+// Pull the next batch from the source into slot `s` (the caller's thread) and start it.
+void slot_fill_and_submit(PandaAssembler a, pamd_slot *s) {
+	s->n = s->n_dev = s->pos = 0;
+	if (a->eof)
+		return;
+	const size_t want = g_batch_pairs.load();
+	if (!slot_reserve(a, s, want)) {
+		fprintf(stderr, "pandaseq_amd: cannot allocate the staging buffers of a %zu-pair batch\n", want);
+		abort();
+	}
+	if (s->res.size() < want) {
+		s->res.resize(want);
+		s->pre.resize(want);
+	}
+	s->stride = 256;
+	while (s->n < want) {
+		panda_result_seq &r = s->res[s->n];
+		const panda_qual *f = nullptr, *rv = nullptr;
+		size_t fl = 0, rl = 0;
+		if (!a->next(&r.name, &f, &fl, &rv, &rl, a->next_data)) {
+			a->eof = true;
+			break;
+		}
+		if (fl > PAMD_MAX_LEN || rl > PAMD_MAX_LEN) {	// assembler.c:359-360
+			fprintf(stderr, "pandaseq_amd: read longer than PANDA_MAX_LEN\n");
+			abort();
+		}
+		int pre = -2;
+		if (fl < 2 || rl < 2) {
+			pre = -1;
+		} else {
+			for (size_t m = 0; m < a->modules.size(); m++) {	// module_precheckseq, module.c:138-154
+				PandaModule mod = a->modules[m];
+				if (mod->precheck != nullptr && !mod->precheck(a->logger, &r.name, f, fl, rv, rl, mod->user_data)) {
+					pre = (int) m;
+					break;
+				}
+			}
+		}
+		if (pre == -2) {
+			if ((fl > 256 || rl > 256) && s->stride == 256) {	// first long read of the batch: re-lay the rows, last first
+				for (size_t k = s->n_dev; k-- > 0;) {
+					memmove(s->h_fwd + k * ROW, s->h_fwd + k * 256, 256 * sizeof(pamd_qual));
+					memmove(s->h_rev + k * ROW, s->h_rev + k * 256, 256 * sizeof(pamd_qual));
+				}
+				s->stride = ROW;
+			}
+			const size_t k = s->n_dev++;
+			stage_copy(s->h_fwd + k * s->stride, f, fl);
+			stage_copy(s->h_rev + k * s->stride, rv, rl);
+			s->h_flen[k] = (uint16_t) fl;
+			s->h_rlen[k] = (uint16_t) rl;
+			pre = -(int) k - 3;
+		}
+		r.forward_length = fl;
+		r.reverse_length = rl;
+		s->pre[s->n] = pre;
+		s->n++;
+	}
+	s->seq_stride = s->stride == 256 ? 512 : OUT_ROW;
+	if (push_config(a) != PAMD_OK) {
+		fprintf(stderr, "pandaseq_amd: %s\n", pamd_last_error());
+		abort();	// no CPU fallback: a device failure is fatal, never silently wrong
+	}
+	if (s->n_dev > 0)
+		s->done = std::async(std::launch::async, slot_run, a, s);
+}
+
+void slot_wait(pamd_slot *s) {
+	if (!s->done.valid())
+		return;
+	const int rc = s->done.get();
+	if (rc != PAMD_OK) {
+		fprintf(stderr, "pandaseq_amd: %s\n", s->error.c_str());
+		abort();
+	}
+}
+
+// assemble_seq()'s bookkeeping for pair i of a finished batch (assembler.c:252-348), in source order
+const panda_result_seq *slot_replay(PandaAssembler a, pamd_slot *s, size_t i) {
+	a->count++;
+	const int pre = s->pre[i];
+	if (pre == -1) {
+		a->badreadcount++;
+		return nullptr;
+	}
+	if (pre >= 0) {
+		a->rejected[pre]++;
+		return nullptr;
+	}
+	const size_t k = (size_t) (-pre - 3);
+	const pamd_pair_result &d = s->h_res[k];
+	panda_result_seq &res = s->res[i];
+	res.forward = reinterpret_cast<const panda_qual *>(s->h_fwd + k * s->stride);
+	res.reverse = reinterpret_cast<const panda_qual *>(s->h_rev + k * s->stride);
+	res.forward_offset = d.fwd_offset;
+	res.reverse_offset = d.rev_offset;
+	res.overlaps_examined = d.examined;
+	if (d.slow)
+		a->slowcount++;
+	switch (d.status) {
+	case PAMD_ST_BADR:
+		a->badreadcount++;
+		return nullptr;
+	case PAMD_ST_NOFP:
+		a->nofpcount++;
+		return nullptr;
+	case PAMD_ST_NORP:
+		a->norpcount++;
+		return nullptr;
+	case PAMD_ST_NOALGN:
+		if (a->noalgn != nullptr)	// assembler.c:294-296
+			a->noalgn(a, &res.name, res.forward, res.forward_length, res.reverse, res.reverse_length, a->noalgn_data);
+		a->noalgncount++;
+		return nullptr;
+	default:
+		break;
+	}
+	res.quality = d.quality;
+	res.degenerates = d.degenerates;
+	res.sequence = s->rows + s->row_off[k];
+	res.sequence_length = d.seq_len;
+	res.overlap_mismatches = d.mismatches;
+	res.overlap = d.overlap;
+	res.estimated_overlap_probability = d.est_overlap_prob;
+	if (d.status == PAMD_ST_LOWQ) {
+		a->lowqcount++;
+		return nullptr;
+	}
+	if (d.status == PAMD_ST_REJECT) {
+		a->rejected[d.reject_module]++;
+		return nullptr;
+	}
+	for (size_t m = a->fused_prefix; m < a->modules.size(); m++) {	// host-callback check modules, in order (module.c:124-136)
+		PandaModule mod = a->modules[m];
+		if (mod->check != nullptr && !mod->check(a->logger, &res, mod->user_data)) {
+			a->rejected[m]++;
+			return nullptr;
+		}
+	}
+	a->okcount++;
+	a->overlapcount[res.overlap]++;
+	if (a->longest_overlap < res.overlap)
+		a->longest_overlap = res.overlap;
+	return &res;
+}
+
 void ensure_staging(PandaAssembler a, size_t pairs) {
 	if (a->h_flen.size() < pairs) {
 		a->h_fwd.resize(pairs * ROW);
@@ -787,11 +1206,19 @@ char panda_result_phred(const panda_result *r) {
 }
 
 void pamd_compat_set_device(int device) {
-	g_device = device;
+	g_device.store(device);
+}
+
+void pamd_compat_set_thread_device(int device) {
+	t_device = device;
 }
 
 void pamd_compat_set_batch_pairs(size_t pairs) {
-	g_batch_pairs = pairs ? pairs : 1;
+	g_batch_pairs.store(pairs ? pairs : 1);
+}
+
+void pamd_compat_set_exact_sums(int exact) {
+	g_exact_sums.store(exact ? 1 : 0);
 }
 
 size_t panda_max_len(void) {	// misc.c:38-41
@@ -804,11 +1231,12 @@ PandaAssembler panda_assembler_new(PandaNextSeq next, void *next_data, PandaDest
 
 PandaAssembler panda_assembler_new_kmer(PandaNextSeq next, void *next_data, PandaDestroy next_destroy, PandaLogProxy logger, size_t num_kmers) {
 	pamd_assembler *dev = nullptr;
+	const int device = pick_device();
 	if (num_kmers != 2) {
 		// the reference's own table indexing only works for 2 (assembler.c:94 vs :99)
 		pamd_set_error("num_kmers = %zu is not supported on the device path (only 2)", num_kmers);
 	} else {
-		dev = pamd_assembler_create(g_device);
+		dev = pamd_assembler_create(device);
 	}
 	if (dev == nullptr) {
 		if (next_destroy != nullptr)
@@ -822,6 +1250,10 @@ PandaAssembler panda_assembler_new_kmer(PandaNextSeq next, void *next_data, Pand
 	a->next_destroy = next_destroy;
 	a->logger = logger;
 	a->dev = dev;
+	a->device = device;
+	a->devs[0] = dev;
+	for (int k = 1; k < panda_assembler::NSLOT && next != nullptr; k++)	// only a source-driven assembler keeps several batches in flight
+		a->devs[k] = pamd_assembler_create(device);
 	a->num_kmers = num_kmers;
 	a->algo = panda_algorithm_simple_bayes_new();	// assembler_support.c:77
 	memset(&a->result, 0, sizeof a->result);
@@ -851,8 +1283,13 @@ void panda_assembler_unref(PandaAssembler a) {	// assembler_support.c:151-175
 		a->next_destroy(a->next_data);
 	if (a->noalgn_destroy != nullptr && a->noalgn != nullptr)
 		a->noalgn_destroy(a->noalgn_data);
+	if (getenv("PAMD_COMPAT_STATS") != nullptr && a->n_batches > 0)
+		fprintf(stderr, "pandaseq_amd: %ld batches; caller: %.3f s pulling and staging, %.3f s blocked on a batch; background: %.3f s in all (%.2f ms per batch)\n", a->n_batches, a->t_fill, a->t_wait, a->t_bg, 1e3 * a->t_bg / (double) a->n_batches);
 	panda_algorithm_unref(a->algo);
-	pamd_assembler_destroy(a->dev);
+	for (pamd_slot *sl : a->slots)
+		slot_free(sl);
+	for (pamd_assembler *d : a->devs)
+		pamd_assembler_destroy(d);
 	delete a;
 }
 
@@ -879,12 +1316,16 @@ const panda_result_seq *panda_assembler_assemble(PandaAssembler a, panda_seq_ide
 		abort();
 	}
 	// a pending prefetched batch of panda_assembler_next() shares the staging area: refuse to mix
-	if (a->batch_pos < a->batch_n) {
+	bool pending = false;
+	for (pamd_slot *sl : a->slots)
+		pending |= sl != nullptr && (sl->pos < sl->n || sl->done.valid());
+	if (pending) {
 		fprintf(stderr, "pandaseq_amd: panda_assembler_assemble() called while panda_assembler_next() has prefetched pairs pending\n");
 		return nullptr;
 	}
 	ensure_staging(a, 1);
 	stage_pair(a, 0, id, forward, forward_length, reverse, reverse_length);
+	a->h_pre[0] = a->h_pre[0];
 	a->batch_n = 1;
 	a->batch_pos = 1;
 	if (run_batch(a) != PAMD_OK) {
@@ -897,44 +1338,40 @@ const panda_result_seq *panda_assembler_assemble(PandaAssembler a, panda_seq_ide
 const panda_result_seq *panda_assembler_next(PandaAssembler a) {
 	if (a->next == nullptr)
 		return nullptr;
-	while (true) {
-		if (a->batch_pos == a->batch_n) {
-			if (a->eof)
-				return nullptr;
-			// pull the next batch from the source; its buffers are only valid until the next call
-			// (pandaseq-common.h:486-487), so every pair is copied into the staging rows
-			ensure_staging(a, g_batch_pairs);
-			size_t n = 0;
-			while (n < g_batch_pairs) {
-				panda_seq_identifier id;
-				const panda_qual *f = nullptr, *r = nullptr;
-				size_t fl = 0, rl = 0;
-				if (!a->next(&id, &f, &fl, &r, &rl, a->next_data)) {
-					a->eof = true;
-					break;
-				}
-				if (fl > PAMD_MAX_LEN || rl > PAMD_MAX_LEN) {	// assembler.c:359-360
-					fprintf(stderr, "pandaseq_amd: read longer than PANDA_MAX_LEN\n");
-					abort();
-				}
-				stage_pair(a, n, &id, f, fl, r, rl);
-				n++;
-			}
-			a->batch_n = n;
-			a->batch_pos = 0;
-			if (n == 0)
-				return nullptr;
-			// keep an untouched copy of the reads for result.forward / result.reverse: run_batch compacts rows
-			if (run_batch(a) != PAMD_OK) {
-				fprintf(stderr, "pandaseq_amd: %s\n", pamd_last_error());
-				abort();
-			}
+	if (a->slots[0] == nullptr) {
+		for (int k = 0; k < panda_assembler::NSLOT; k++) {
+			a->slots[k] = new pamd_slot;
+			a->slots[k]->dev = a->devs[k];
 		}
-		const size_t i = a->batch_pos++;
-		// result.forward/reverse point at this assembler's copy of the reads (valid until the next call)
-		const int pre = a->h_pre[i];
-		const size_t row = pre <= -3 ? (size_t) (-pre - 3) : i;
-		const panda_result_seq *res = replay(a, i, reinterpret_cast<const panda_qual *>(&a->h_fwd[row * ROW]), reinterpret_cast<const panda_qual *>(&a->h_rev[row * ROW]));
+	}
+	while (true) {
+		pamd_slot *s = a->slots[a->cur];
+		if (s->pos == s->n) {
+			if (!a->primed) {	// the first call: every slot gets a batch, the first one is waited for
+				a->primed = true;
+				const double t0 = now_s();
+				for (int k = 0; k < panda_assembler::NSLOT; k++)
+					slot_fill_and_submit(a, a->slots[k]);
+				a->t_fill += now_s() - t0;
+				a->cur = 0;
+			} else {	// the batch just consumed makes room for a new one at the end of the line
+				if (s->n == 0 && a->eof)
+					return nullptr;
+				const double t0 = now_s();
+				slot_fill_and_submit(a, s);
+				a->t_fill += now_s() - t0;
+				a->cur = (a->cur + 1) % panda_assembler::NSLOT;
+			}
+			s = a->slots[a->cur];
+			const double t1 = now_s();
+			slot_wait(s);
+			a->t_wait += now_s() - t1;
+			a->t_bg += s->seconds;
+			a->n_batches++;
+			if (s->n == 0)
+				return nullptr;	// the source is exhausted (assembler.c:352-353)
+		}
+		const panda_result_seq *res = slot_replay(a, s, s->pos++);
 		if (res != nullptr)
 			return res;
 	}

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the drop-in API: tests/c/bench_next.c (the reference's own panda_assembler_next loop, plain C)
+over an in-memory source of synthetic pairs.  Builds the client, writes the pairs, runs it, prints its JSON line.
+
+    python tools/bench_next.py [--config 1] [--pairs 4000000] [--sums exact|fast] [--batch 65536]
+"""
+import argparse
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build(tmp):
+    exe = os.path.join(tmp, "bench_next")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "bench_next.c"), "-o", exe,
+                           "-L", os.path.join(ROOT, "pandaseq_amd"), "-lpandaseq_amd", "-Wl,-rpath," + os.path.join(ROOT, "pandaseq_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def write_pairs(path, fwd, rev, flen, rlen):
+    import numpy as np
+    n, stride = fwd.shape[0], fwd.shape[1]
+    rec = np.zeros((n, 4 + stride * 4), dtype=np.uint8)
+    rec[:, 0:2] = np.ascontiguousarray(flen, dtype="<u2").view(np.uint8).reshape(n, 2)
+    rec[:, 2:4] = np.ascontiguousarray(rlen, dtype="<u2").view(np.uint8).reshape(n, 2)
+    rec[:, 4:4 + stride * 2] = fwd.reshape(n, stride * 2)
+    rec[:, 4 + stride * 2:] = rev.reshape(n, stride * 2)
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<2I", n, stride))
+        fh.write(rec.tobytes())
+
+
+def run(config=1, pairs=4_000_000, sums="exact", batch=65536, distinct=8192, algo=None, consume=2):
+    from pandaseq_amd import synth
+    import bench
+    spec = synth.config_spec(config)
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build(tmp)
+        fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, min(distinct, pairs))
+        pin = os.path.join(tmp, "pairs.bin")
+        write_pairs(pin, fwd, rev, flen, rlen)
+        out = subprocess.check_output([exe, pin, str(pairs), algo or bench.CONFIGS[config]["algo"].replace("simple_bayesian", "sb"), "1" if sums == "exact" else "0", str(batch), str(consume)], timeout=1200)
+    d = json.loads(out.decode().strip().splitlines()[-1])
+    d.update(config=config, sums=sums, batch_pairs=batch, distinct_pairs=min(distinct, pairs),
+             path="in-memory PandaNextSeq source -> panda_assembler_next (pinned staging, two batches in flight, index-coded download) -> consumer reading every merged base")
+    return d
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=4_000_000)
+    ap.add_argument("--sums", default="exact")
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--consume", type=int, default=2)
+    args = ap.parse_args()
+    print(json.dumps(run(args.config, args.pairs, args.sums, args.batch, consume=args.consume)))
