@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--io", action="store_true", help="N=1 only: also time the data-format rows either side of the path (FASTQ ingest, FASTA / "
                                                       "FASTQ formatting, tools/bench_io.py) with their own CPU baseline; reported under \"io\"")
     ap.add_argument("--io-pairs", type=int, default=4_000_000)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (the reference's own panda_assembler_next loop "
+                                                          "through the drop-in C API, tests/c/bench_next.c)")
+    ap.add_argument("--e2e-pairs", type=int, default=24_000_000)
     return ap.parse_args()
 
 
@@ -312,9 +315,28 @@ def main():
             "single_thread_pairs_per_s": rate1,
             "matches_gpu_on_sample": same,
         }
+    # ---- end to end through the drop-in API (never `value`): the reference's loop, PCIe both ways, plain C ----
+    if rank == 0 and world == 1 and not args.no_e2e and cfg_index in (1, 3, 4):
+        del batch, arenas, results, f, r, fl, rl
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_next
+        try:
+            e2e = {}
+            for name, consume in (("record_only", 0), ("every_base_read", 2)):
+                d = bench_next.run(config=cfg_index, pairs=args.e2e_pairs if consume == 0 else args.e2e_pairs // 4, sums=args.sums, consume=consume)
+                e2e[name] = {k: d[k] for k in ("pairs", "seconds", "pairs_per_s", "ok", "batch_pairs", "distinct_pairs")}
+            e2e["unit"] = "pairs/s"
+            e2e["path"] = ("tests/c/bench_next.c: while ((r = panda_assembler_next(a)) != NULL) over an in-memory PandaNextSeq source; pinned staging, four "
+                           "batches in flight, log-p downloaded as u16 table indices, panda_result[] rows expanded by helper threads; record_only: the consumer "
+                           "reads each record's scalars; every_base_read: it reads nt and p of every merged base (16 B per base on its one thread)")
+            out["end_to_end"] = e2e
+        except Exception as exc:  # the headline number does not depend on this leg
+            out["end_to_end"] = {"error": str(exc)[:300]}
+        batch = None
     # ---- optional: the data-format rows either side of the path, with the oracle's reader / formatter as CPU baseline ----
     if rank == 0 and world == 1 and args.io:
-        del batch
+        batch = None
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_io

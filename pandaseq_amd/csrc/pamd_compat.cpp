@@ -861,7 +861,7 @@ bool slot_reserve(PandaAssembler a, pamd_slot *s, size_t pairs) {
 	bool ok = true;
 	auto pin = [&](auto &ptr, size_t bytes) {
 		void *q = nullptr;
-		ok = ok && hipHostMalloc(&q, bytes, hipHostMallocDefault) == hipSuccess;
+		ok = ok && hipHostMalloc(&q, bytes, hipHostMallocNonCoherent) == hipSuccess;	// host-cached; every hand-over is a stream synchronise
 		ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(q);
 	};
 	auto dev = [&](auto &ptr, size_t bytes) {

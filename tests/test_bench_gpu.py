@@ -29,12 +29,15 @@ def _check(line, n_gpus, steps, warmup):
 
 
 def test_bench_single_gpu(built):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "300000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "300000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2", "--e2e-pairs", "400000"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _check(out.stdout.strip().splitlines()[-1], 1, 2, 1)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["cores"] >= 1 and c["matches_gpu_on_sample"] is True
+    e = d["end_to_end"]
+    assert "error" not in e, e
+    assert e["record_only"]["pairs"] == 400000 and e["record_only"]["pairs_per_s"] > 0 and e["every_base_read"]["ok"] > 0
 
 
 def test_bench_two_ranks_sharded(built):
