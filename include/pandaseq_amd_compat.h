@@ -240,6 +240,8 @@ char panda_result_phred(const panda_result *r);			/* the reference's bisection o
  * gets them spread over the GPUs without a code change), else the process default (pamd_compat_set_device, 0). */
 void pamd_compat_set_device(int device);
 void pamd_compat_set_thread_device(int device);
+/* the device the next panda_assembler_new() of the calling thread would use (takes a turn of PAMD_DEVICES when that decides) */
+int pamd_compat_device_for_new_assembler(void);
 /* how many pairs panda_assembler_next() pulls from the source per batch (default 65536); two batches are in flight */
 void pamd_compat_set_batch_pairs(size_t pairs);
 /* how assemblers created from now on sum quality and pear / rdp_mle scores (pamd_set_exact_sums): 1 (default) = in the

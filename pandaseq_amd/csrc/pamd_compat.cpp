@@ -1213,6 +1213,10 @@ void pamd_compat_set_thread_device(int device) {
 	t_device = device;
 }
 
+int pamd_compat_device_for_new_assembler(void) {
+	return pick_device();
+}
+
 void pamd_compat_set_batch_pairs(size_t pairs) {
 	g_batch_pairs.store(pairs ? pairs : 1);
 }

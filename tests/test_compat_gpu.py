@@ -240,3 +240,22 @@ def test_reference_api_client(built, tmp_path, algo, mode):
             rec, o = _read_record(buf, o)
             assert rec["overlap"] == o_res["overlap"][i] and rec["quality"] == o_res["quality"][i]
             assert np.array_equal(rec["nt"], o_nt[i, :rec["seq_len"]]) and np.array_equal(rec["p"], o_p[i, :rec["seq_len"]])
+
+
+def test_one_assembler_per_thread(built, tmp_path):
+    """pool.c:140-160's shape: several threads, each with its own assembler and its own slice of the pairs, all on one GPU
+    at once; their summed counters equal one assembler's over everything."""
+    from pandaseq_amd import synth
+    from oracle import pyoracle as po
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 20000)
+    pin = tmp_path / "pairs.bin"
+    _write_pairs(pin, fwd, rev, flen, rlen)
+    exe = str(tmp_path / "test_threads")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "test_threads.c"), "-o", exe,
+                           "-L", os.path.join(ROOT, "pandaseq_amd"), "-lpandaseq_amd", "-Wl,-rpath," + os.path.join(ROOT, "pandaseq_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    o_ctr = po.assemble_batch(po.make_config("simple_bayesian"), fwd, rev, flen, rlen, want_seq=False)[3]
+    want = [int(o_ctr[k]) for k in ("count", "ok", "noalgn", "lowq", "badr", "slow")]
+    for threads in (1, 2, 5):
+        out = subprocess.check_output([exe, str(pin), str(threads)], timeout=300)
+        assert [int(x) for x in out.split()] == want, (threads, out)

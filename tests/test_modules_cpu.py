@@ -103,3 +103,48 @@ def test_algorithm_registry(lib):
     lib.panda_algorithm_register(ctypes.byref(mine))     # a second registration is a no-op (algo.c:107-111)
     got = names()
     assert got.count(b"middle") == 1 and got == sorted(got)
+
+
+def test_device_selection_is_per_thread(built):
+    """Which GPU a new assembler gets: the calling thread's own choice, else PAMD_DEVICES round robin, else the process
+    default -- decided without shared mutable state that two threads creating assemblers could race on (pool.c:140-160
+    builds one assembler per thread).  No GPU needed: only the choice is observed."""
+    import ctypes as C
+    import os
+    import threading
+
+    from pandaseq_amd import _lib
+    L = _lib.lib()
+    L.pamd_compat_set_device(2)
+    assert L.pamd_compat_device_for_new_assembler() == 2
+    seen = {}
+
+    def work(dev):
+        L.pamd_compat_set_thread_device(dev)
+        got = [L.pamd_compat_device_for_new_assembler() for _ in range(2000)]
+        seen[dev] = set(got)
+
+    ts = [threading.Thread(target=work, args=(d,)) for d in (3, 5, 6, 7)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert seen == {3: {3}, 5: {5}, 6: {6}, 7: {7}}
+    assert L.pamd_compat_device_for_new_assembler() == 2   # the main thread never chose
+    os.environ["PAMD_DEVICES"] = "4,1,6"
+    try:
+        got = [L.pamd_compat_device_for_new_assembler() for _ in range(6)]
+        assert sorted(got[:3]) == [1, 4, 6] and got[:3] == got[3:]
+        L.pamd_compat_set_thread_device(0)
+        assert L.pamd_compat_device_for_new_assembler() == 0   # a thread's own choice wins
+        L.pamd_compat_set_thread_device(-1)
+    finally:
+        del os.environ["PAMD_DEVICES"]
+        L.pamd_compat_set_device(0)
+    # without a GPU, concurrent constructors fail cleanly (NULL), they do not race
+    if L.pamd_device_count() == 0:
+        L.panda_assembler_new.restype = C.c_void_p
+        L.panda_assembler_new.argtypes = [C.c_void_p] * 4
+        out = []
+        ts = [threading.Thread(target=lambda: out.append(L.panda_assembler_new(None, None, None, None))) for _ in range(8)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert out == [None] * 8
