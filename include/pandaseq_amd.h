@@ -146,6 +146,7 @@ void pamd_assembler_destroy(pamd_assembler *a);
 int pamd_set_algorithm(pamd_assembler *a, int algo, double param);
 /* the setters below mirror assembler_support.c:201-410, including "silently ignore bad values" */
 int pamd_set_threshold(pamd_assembler *a, double threshold);		/* (0,1), stored as log */
+int pamd_set_log_threshold(pamd_assembler *a, double log_threshold);	/* the stored logarithm itself (< 0): no log(exp()) round trip for a caller that keeps it as struct panda_assembler does */
 int pamd_set_minimum_overlap(pamd_assembler *a, int overlap);		/* > 1 */
 int pamd_set_maximum_overlap(pamd_assembler *a, int overlap);		/* 0 = min(read lengths) */
 int pamd_set_forward_primer(pamd_assembler *a, const uint8_t *nt, size_t length);

@@ -232,6 +232,14 @@ int pamd_set_threshold(pamd_assembler *a, double threshold) {	// assembler_suppo
 	return PAMD_OK;
 }
 
+int pamd_set_log_threshold(pamd_assembler *a, double log_threshold) {	// the value assembler.c:334 compares with, as stored
+	if (a == nullptr)
+		return PAMD_EINVAL;
+	if (log_threshold < 0)
+		a->threshold = log_threshold;
+	return PAMD_OK;
+}
+
 int pamd_set_minimum_overlap(pamd_assembler *a, int overlap) {	// assembler_support.c:276-282
 	if (overlap > 1 && overlap < 2 * PAMD_MAX_LEN)
 		a->minoverlap = overlap;

@@ -588,7 +588,7 @@ int push_config(PandaAssembler a) {
 	pamd_set_exact_sums(d, g_exact_sums.load());
 	pamd_set_algorithm(d, algo, param);
 	pamd_set_primers_after(d, a->post_primers ? 1 : 0);
-	pamd_set_threshold(d, std::exp(a->threshold));
+	pamd_set_log_threshold(d, a->threshold);	// the stored logarithm itself (assembler_support.c:395): no exp / log round trip
 	pamd_set_minimum_overlap(d, a->minoverlap);
 	pamd_set_maximum_overlap(d, a->maxoverlap);
 	pamd_set_primer_penalty(d, a->primer_penalty);
@@ -613,12 +613,8 @@ int push_config(PandaAssembler a) {
 			break;
 		a->fused_prefix++;
 	}
-	for (size_t i = a->fused_prefix; i < a->modules.size(); i++) {
-		if (a->modules[i]->fused_kind != 0) {
-			pamd_set_error("module %s follows a host-callback module; kernel-implemented modules must come first", a->modules[i]->name);
-			return PAMD_EUNSUPPORTED;
-		}
-	}
+	// (a kernel-implemented module that FOLLOWS a host-callback module runs on the host too, from the same definitions:
+	// host_module_check() below)
 	}	// both device assemblers
 	{
 		a->image.assign(8192, 0.0);
@@ -677,6 +673,18 @@ int run_batch(PandaAssembler a) {
 	for (size_t k = 0; k < n; k++)
 		a->h_pre[sent[k]] = -(int) k - 3;
 	return PAMD_OK;
+}
+
+// min_phred / min_overlapbits on the host, for the case where one of them follows a host-callback module (the kernel can
+// only take a leading run of them without changing which module a rejection is blamed on, module.c:128-134)
+bool host_module_check(PandaModule mod, const panda_result_seq *res) {
+	if (mod->fused_kind == 1) {	// plugin_min_phred.c:8-22
+		for (size_t j = 0; j < res->sequence_length; j++)
+			if (panda_result_phred(&res->sequence[j]) < mod->fused_phred)
+				return false;
+		return true;
+	}
+	return mod->fused_bits * 0.69314718055994530942 <= res->estimated_overlap_probability;	// plugin_min_overlapbits.c:17-23
 }
 
 // Replay staged pair `i` the way assemble_seq() would have (assembler.c:252-348).  Returns the
@@ -748,7 +756,7 @@ const panda_result_seq *replay(PandaAssembler a, size_t i, const panda_qual *f, 
 	// remaining (host-callback) check modules, in order (module.c:124-136)
 	for (size_t m = a->fused_prefix; m < a->modules.size(); m++) {
 		PandaModule mod = a->modules[m];
-		if (mod->check != nullptr && !mod->check(a->logger, &res, mod->user_data)) {
+		if (mod->fused_kind != 0 ? !host_module_check(mod, &res) : (mod->check != nullptr && !mod->check(a->logger, &res, mod->user_data))) {
 			a->rejected[m]++;
 			return nullptr;
 		}
@@ -1138,7 +1146,7 @@ const panda_result_seq *slot_replay(PandaAssembler a, pamd_slot *s, size_t i) {
 	}
 	for (size_t m = a->fused_prefix; m < a->modules.size(); m++) {	// host-callback check modules, in order (module.c:124-136)
 		PandaModule mod = a->modules[m];
-		if (mod->check != nullptr && !mod->check(a->logger, &res, mod->user_data)) {
+		if (mod->fused_kind != 0 ? !host_module_check(mod, &res) : (mod->check != nullptr && !mod->check(a->logger, &res, mod->user_data))) {
 			a->rejected[m]++;
 			return nullptr;
 		}

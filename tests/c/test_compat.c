@@ -10,6 +10,8 @@
  *           plugin source (oracle/Makefile `ref`), opened the way module.c:227-298 does (dlopen, its
  *           <name>_LTX_opener) and attached as a host callback with panda_module_new
  *   mode 3: <name:args>: the same filter fused on the device (panda_module_load)
+ *   mode 4: a host check module FIRST, then min_phred:4 and min_overlapbits:15 (which therefore run on the host too:
+ *           the kernel only takes a leading run of them, module.c:128-134 blames the first module that fails)
  *   counters[8] = sequences rejected by the first module (panda_assembler_foreach_module)
  *
  * With -DUSE_REFERENCE_HEADERS the client is compiled against the reference's own pandaseq.h instead of
@@ -148,6 +150,19 @@ int main(int argc, char **argv) {
 		PandaModule m1 = panda_module_load(NULL, "min_overlapbits:15");
 		PandaModule m2 = panda_module_new("few_mismatches", check_few_mismatches, NULL, NULL, NULL);
 		PandaModule m3 = panda_module_new("not11", NULL, precheck_not_multiple_of_11, NULL, NULL);
+		if (!m1 || !m2 || !m3)
+			return 5;
+		panda_assembler_add_module(a, m1);
+		panda_assembler_add_module(a, m2);
+		panda_assembler_add_module(a, m3);
+		panda_module_unref(m1);
+		panda_module_unref(m2);
+		panda_module_unref(m3);
+	}
+	if (mode == 4) {
+		PandaModule m1 = panda_module_new("few_mismatches", check_few_mismatches, NULL, NULL, NULL);
+		PandaModule m2 = panda_module_load(NULL, "min_phred:4");
+		PandaModule m3 = panda_module_load(NULL, "min_overlapbits:15");
 		if (!m1 || !m2 || !m3)
 			return 5;
 		panda_assembler_add_module(a, m1);

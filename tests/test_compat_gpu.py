@@ -259,3 +259,23 @@ def test_one_assembler_per_thread(built, tmp_path):
     for threads in (1, 2, 5):
         out = subprocess.check_output([exe, str(pin), str(threads)], timeout=300)
         assert [int(x) for x in out.split()] == want, (threads, out)
+
+
+def test_fused_modules_after_a_host_module(built, tmp_path):
+    """min_phred / min_overlapbits AFTER a host-callback module: they run on the host then (the kernel may only take a
+    leading run of them), with the same results and the same module blamed."""
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    spec = synth.config_spec(1)
+    n = 3000
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
+    pin, pout = tmp_path / "pairs.bin", tmp_path / "out.bin"
+    _write_pairs(pin, fwd, rev, flen, rlen)
+    subprocess.check_call([_build_client(str(tmp_path)), str(pin), str(pout), "rdp_mle", "4"], timeout=300)
+    got, counters, _ = _parse_output(pout.read_bytes())
+    plain = po.assemble_batch(po.make_config("rdp_mle"), fwd, rev, flen, rlen)[0]
+    mods = po.assemble_batch(po.make_config("rdp_mle", modules=[("min_phred", 4), ("min_overlapbits", 15)]), fwd, rev, flen, rlen)[0]
+    expected = [i for i in range(n) if plain["status"][i] == 0 and plain["mismatches"][i] <= 3 and mods["status"][i] == 0]
+    assert [g["index"] for g in got] == expected
+    host_rejected = int(((plain["status"] == 0) & (plain["mismatches"] > 3)).sum())
+    assert counters[8] == host_rejected and 0 < len(expected) < int((plain["status"] == 0).sum()) - host_rejected
