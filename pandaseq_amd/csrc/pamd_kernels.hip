@@ -198,10 +198,10 @@ __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint
 // log-probability in primer order x = 0..plen-1, which is the order in which offset.c:79-87 adds
 // into bucket s.  That bucket is judged at index = s + plen (offset.c:72-77).
 // Returns what computeoffset() returns: 0 = not found, else 1 + number of bases to clip.
-__device__ int primer_offset(const PamdKernelParams &P, const double *ltab, const uint16_t *S, int len, const uint8_t *primer, int plen, int lane) {
-	if (plen > len)
-		return 0;
-	const bool logdomain = P.primer_penalty == 0.0;
+// logdomain: compare the values before exp() (zero penalty only, where exp is the last, monotone step); `near` then
+// reports whether a comparison was so close that exp() might have decided it otherwise.
+__device__ __forceinline__ int primer_offset_scan(const PamdKernelParams &P, const double *ltab, const uint16_t *S, int len, const uint8_t *primer, int plen, int lane, const bool logdomain, bool &near) {
+	bool close = false;
 	// bestpr = exp(primerlen * threshold); with a zero penalty every candidate is exp(x) of some x
 	// and exp is monotone, so we compare x (see DESIGN.md "exp in the primer scan").
 	double best = logdomain ? (double) plen * P.threshold : exp((double) plen * P.threshold);
@@ -255,6 +255,10 @@ __device__ int primer_offset(const PamdKernelParams &P, const double *ltab, cons
 		if (!logdomain)
 			v = exp(v) - (double) index * P.primer_penalty;
 		const bool better = have && v > best;	// strict: the earliest index wins ties (offset.c:74)
+		// Compared before exp(), two values may differ and their exponentials not: exp'(x) <= 1 here, so a difference
+		// below an ulp of 1 can vanish in rounding, and the reference then keeps the earlier index.  Such a scan is
+		// repeated with the comparisons made after exp(), as the reference makes them (primer_offset below).
+		close |= logdomain && better && v - best <= 4.5e-16;
 		if (better) {
 			best = v;
 			besti = index + 1;
@@ -268,17 +272,39 @@ __device__ int primer_offset(const PamdKernelParams &P, const double *ltab, cons
 			bound = uni_f64(m);
 		}
 	}
-	// first-maximum across lanes: larger value wins, equal values -> smaller index
+	// first-maximum across lanes: larger value wins, equal values -> smaller index (values whose exponentials may
+	// coincide are ordered by their exponentials, as above)
 	for (int off = 32; off > 0; off >>= 1) {
 		const double ob = __shfl_xor(best, off);
 		const int oi = __shfl_xor(besti, off);
-		const bool take = (oi != 0) && (besti == 0 || ob > best || (ob == best && oi < besti));
+		const bool greater = ob > best, equal = ob == best;
+		close |= logdomain && oi != 0 && besti != 0 && ob != best && fabs(ob - best) <= 4.5e-16;
+		const bool take = (oi != 0) && (besti == 0 || greater || (equal && oi < besti));
 		if (take) {
 			best = ob;
 			besti = oi;
 		}
 	}
+	near = ballot(close) != 0;
 	return uni(besti);
+}
+
+__device__ int primer_offset(const PamdKernelParams &P, const double *ltab, const uint16_t *S, int len, const uint8_t *primer, int plen, int lane) {
+	if (plen > len)
+		return 0;
+	// First with the comparisons made before exp() when there is no penalty; again with every comparison made after exp(),
+	// as offset.c:59,72-74 makes them, if two alignments came so close that exp() may not tell them apart (once in 1e13
+	// pairs).  One body, a run-time switch: an out-of-line second copy costs the hot scan 6 % through its call site.
+	bool logdomain = P.primer_penalty == 0.0;
+	int r;
+	while (true) {
+		bool near = false;
+		r = primer_offset_scan(P, ltab, S, len, primer, plen, lane, logdomain, near);
+		if (!near)
+			break;
+		logdomain = false;
+	}
+	return r;
 }
 
 // ---- primer offset in the MERGED sequence (`-a`: panda_compute_offset_result, offset.c:114-133) --------

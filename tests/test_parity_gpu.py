@@ -432,3 +432,70 @@ def test_arena_overflow_is_reported(built):
     asm = pa.Assembler(0)
     with pytest.raises(pa.PamdError, match="arena too small"):
         asm.assemble_host(fwd, rev, flen, rlen, seq_stride=0, capacity=200_000)
+
+
+def test_primer_scan_when_exp_collapses_two_alignments(built):
+    """offset.c:72-74 compares exp(sum / (index + 1)) and keeps the EARLIER index on a tie.  Two alignments whose values
+    differ by less than exp() can resolve are such a tie for the reference although the values themselves differ: the
+    forward primer is planted twice, with qualities searched so that the second copy's value exceeds the first's by a few
+    1e-18 (same exponential) or falls short of it, or exceeds it by 1e-14 (different exponentials).  The device, which
+    compares before exp, must give the reference's answer in all three cases."""
+    from pandaseq_amd import synth
+    from oracle import pyoracle as po
+    spec = synth.config_spec(2)
+    primer = synth.nt_codes(spec.fprimer)
+    P = len(primer)
+    score = po.tables_np()["score"]
+    rng = np.random.default_rng(2024)
+    n1 = 1_500_000
+    q1 = rng.integers(25, 42, size=(n1, P))
+    v1 = np.cumsum(score[q1], axis=1)[:, -1] / 18.0          # the first copy starts at 0: index + 1 = P + 1 = 18
+    order = np.argsort(v1)
+    v1s = v1[order]
+    cases = []   # (quality vector 1, quality vector 2, kind)
+    want = {"tie": 6, "below": 3, "clear": 3}
+    for _ in range(40):
+        q2 = rng.integers(20, 39, size=(400_000, P))
+        v2 = np.cumsum(score[q2], axis=1)[:, -1] / 36.0      # the second copy starts at 18: index + 1 = 36
+        j = np.searchsorted(v1s, v2, side="left")             # v1s[j-1] < v2 <= v1s[j]
+        lo = np.clip(j - 1, 0, n1 - 1)
+        d_up = v2 - v1s[lo]                                    # > 0: the later alignment is (slightly) better before exp
+        hi = np.clip(j, 0, n1 - 1)
+        d_dn = v1s[hi] - v2
+        for k in np.nonzero((d_up > 0) & (d_up <= 3e-18))[0]:
+            if want["tie"] > 0:
+                cases.append((q1[order[lo[k]]], q2[k], "tie"))
+                want["tie"] -= 1
+        for k in np.nonzero((d_dn > 0) & (d_dn <= 3e-18))[0]:
+            if want["below"] > 0:
+                cases.append((q1[order[hi[k]]], q2[k], "below"))
+                want["below"] -= 1
+        for k in np.nonzero((d_up > 5e-15) & (d_up <= 2e-14))[0]:
+            if want["clear"] > 0:
+                cases.append((q1[order[lo[k]]], q2[k], "clear"))
+                want["clear"] -= 1
+        if not any(want.values()):
+            break
+    assert sum(1 for c in cases if c[2] == "tie") >= 2, "the search must produce ties for the test to mean anything"
+    n = len(cases)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
+    other = {1: 2, 2: 4, 4: 8, 8: 1}
+    for i, (qa, qb, _kind) in enumerate(cases):
+        fwd[i, 0:P, 0] = primer
+        fwd[i, 0:P, 1] = qa
+        fwd[i, P, 0] = other[int(primer[0])]      # no third alignment
+        fwd[i, P, 1] = 40
+        fwd[i, 18:18 + P, 0] = primer
+        fwd[i, 18:18 + P, 1] = qb
+    ocfg = dict(fprimer=primer, rprimer=synth.nt_codes(spec.rprimer, complement=True))
+    o = _oracle("pear", fwd, rev, flen, rlen, **ocfg)
+    offs = o[0]["fwd_offset"]
+    kinds = np.array([c[2] for c in cases])
+    assert (o[0]["status"] != 2).all()
+    assert (offs[kinds == "tie"] == P).all(), "the reference keeps the first copy when exp() cannot tell the two apart"
+    assert (offs[kinds == "below"] == P).all() and (offs[kinds == "clear"] == 18 + P).all()
+    for exact in (True, False):
+        asm = _asm_for("pear", spec, primers=True, exact=exact)
+        b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
+        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=exact)
+        compare_counters(b.counters_dict(), o[3])
