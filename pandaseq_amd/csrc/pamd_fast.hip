@@ -38,10 +38,22 @@ constexpr unsigned EMPTY = 0xFFFFFFFFu;
 // of a stream: the neighbouring arrays, masked); candidate flags, one byte per overlap; merged-nt staging (+64: lanes past
 // a row's end write into slack); the four k-mer tables
 constexpr unsigned FK_F = 0, FK_R = 512, FK_FC = 1024, FK_RC = 1088, FK_FN = 1152, FK_RN = 1216, FK_FLAGS = 1296, FK_NT = 1552;
-constexpr unsigned FK_T1_SLOTS = 1024, FK_T2_SLOTS = 256, FK_T3_SLOTS = 64, FK_T4_SLOTS = 32;
-constexpr unsigned FK_T1 = 2128, FK_T2 = FK_T1 + 4 * FK_T1_SLOTS, FK_T3 = FK_T2 + 4 * FK_T2_SLOTS, FK_T4 = FK_T3 + 4 * FK_T3_SLOTS;
-constexpr unsigned FK_WAVE_BYTES = FK_T4 + 4 * FK_T4_SLOTS;
-static_assert(FK_WAVE_BYTES % 16 == 0 && FK_NT % 16 == 0 && FK_T1 % 16 == 0 && FK_FLAGS % 16 == 0, "16-byte LDS accesses");
+// the first k-mer table has 2^T1B slots: 1024 where the scorer's tables leave room (36 KB of them per workgroup), 512 for
+// rdp_mle (54 KB: a third matrix); the other three are fixed
+constexpr unsigned FK_T2_SLOTS = 256, FK_T3_SLOTS = 64, FK_T4_SLOTS = 32;
+constexpr unsigned FK_T1 = 2128;
+template <int T1B>
+struct Geo {
+	static constexpr unsigned T1_SLOTS = 1u << T1B;
+	static constexpr unsigned T2 = FK_T1 + 4u * T1_SLOTS, T3 = T2 + 4u * FK_T2_SLOTS, T4 = T3 + 4u * FK_T3_SLOTS;
+	static constexpr unsigned WAVE_BYTES = T4 + 4u * FK_T4_SLOTS;
+	static_assert(WAVE_BYTES % 16 == 0, "16-byte LDS accesses");
+};
+static_assert(FK_NT % 16 == 0 && FK_T1 % 16 == 0 && FK_FLAGS % 16 == 0, "16-byte LDS accesses");
+template <int ALGO>
+__device__ __host__ constexpr int t1_bits() {
+	return ALGO == PAMD_ALGO_RDP_MLE ? 9 : 10;
+}
 
 // k-mer -> slot of table 1..4: bit fields of one 24-bit multiplicative hash (a second one for the rarely used last table)
 constexpr unsigned HASH_C = 0x9E3779u, HASH_C4 = 0x85EBCBu;
@@ -49,8 +61,9 @@ constexpr unsigned HASH_C = 0x9E3779u, HASH_C4 = 0x85EBCBu;
 __device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) {
 	return (unsigned) __umul24(a, b);	// (this ROCm's __umul24 yields a SIGNED value: a plain >> on it is an arithmetic shift)
 }
+template <int T1B>
 __device__ __forceinline__ unsigned slot1(unsigned k) {
-	return mul24(k, HASH_C) >> 22;
+	return mul24(k, HASH_C) >> (32 - T1B);
 }
 __device__ __forceinline__ unsigned slot2(unsigned k) {
 	return (mul24(k, HASH_C) >> 14) & (FK_T2_SLOTS - 1u);
@@ -353,7 +366,7 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 	if (P.debug_buf == nullptr || pair != P.debug_pair)
 		return;
 	unsigned char *dst = P.debug_buf + (size_t) where * 8192u;
-	for (unsigned i = lane; i < FK_WAVE_BYTES / 4; i += 64)
+	for (unsigned i = lane; i < Geo<10>::WAVE_BYTES / 4; i += 64)
 		reinterpret_cast<unsigned *>(dst)[i] = reinterpret_cast<const unsigned *>(wb)[i];
 	if (lane == 0) {
 		int *s = reinterpret_cast<int *>(dst + 7680);
@@ -365,18 +378,20 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 #define DEBUG_DUMP(...)
 #endif
 
-template <int ALGO, int ROUNDS, bool EXACT>
+template <int ALGO, int ROUNDS, bool EXACT, bool PHRED>
 __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt) {
 	const uint2 fv = cur.f, rv = cur.r;
 	bool rotated = false;
 	int status = PAMD_ST_OK;
 	u64 off = ~0ull;
 	double best = 0.0, qsum = 0.0;
-	int seqlen = 0, bo = -1, examined = 0, mism = 0, degen = 0;
+	int seqlen = 0, bo = -1, examined = 0, mism = 0, degen = 0, phmin = 127;
 	bool slow = false;
 	const int minov = P.minoverlap;
-	unsigned *const t1 = reinterpret_cast<unsigned *>(wb + FK_T1), *const t2 = reinterpret_cast<unsigned *>(wb + FK_T2);
-	unsigned *const t3 = reinterpret_cast<unsigned *>(wb + FK_T3), *const t4 = reinterpret_cast<unsigned *>(wb + FK_T4);
+	constexpr int T1B = t1_bits<ALGO>();
+	typedef Geo<T1B> G;
+	unsigned *const t1 = reinterpret_cast<unsigned *>(wb + FK_T1), *const t2 = reinterpret_cast<unsigned *>(wb + G::T2);
+	unsigned *const t3 = reinterpret_cast<unsigned *>(wb + G::T3), *const t4 = reinterpret_cast<unsigned *>(wb + G::T4);
 	uint8_t *const flags = wb + FK_FLAGS;
 	uint8_t *const nts = wb + FK_NT;
 
@@ -400,7 +415,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		const int uf = stage<true>(fv, flen, lane, wb, fcodes, fnm, weird);
 		const int ur = stage<false>(rv, rlen, lane, wb, rcodes, rnm, weird);
 		{
-			const unsigned n16 = (deep_dirty ? FK_WAVE_BYTES - FK_T1 : FK_T3 - FK_T1) / 16u;
+			const unsigned n16 = (deep_dirty ? G::WAVE_BYTES - FK_T1 : G::T3 - FK_T1) / 16u;
 			uint4 *h = reinterpret_cast<uint4 *>(wb + FK_T1);
 			for (unsigned s = lane; s < n16; s += 64)
 				h[s] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
@@ -439,7 +454,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			const unsigned l1 = lds_addr(t1), l2 = lds_addr(t2);
 #pragma unroll
 			for (int j = 0; j < 4; j++)
-				carry[j] = insert_at(lshl_add<2>(mul24(carry[j] >> 16, HASH_C) >> 22, l1), carry[j]);
+				carry[j] = insert_at(lshl_add<2>(mul24(carry[j] >> 16, HASH_C) >> (32 - T1B), l1), carry[j]);
 #pragma unroll
 			for (int j = 0; j < 4; j++)
 				carry[j] = insert_at(lshl_add<2>(__builtin_amdgcn_ubfe(mul24(carry[j] >> 16, HASH_C), 14, 8), l2), carry[j]);
@@ -455,7 +470,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 						// keeps its minimum), so a k-mer with two of them in the tables loses nothing the reference keeps
 						// (assembler.c:94-99 drops a third position as well): tandem repeats pass here.
 						const unsigned k = carry[j] >> 16, kk = carry[j] & 0xFFFF0000u;
-						const int kept = (int) ((t1[slot1(k)] ^ kk) < 0x10000u) + (int) ((t2[slot2(k)] ^ kk) < 0x10000u) + (int) ((t3[slot3(k)] ^ kk) < 0x10000u) + (int) ((t4[slot4(k)] ^ kk) < 0x10000u);
+						const int kept = (int) ((t1[slot1<T1B>(k)] ^ kk) < 0x10000u) + (int) ((t2[slot2(k)] ^ kk) < 0x10000u) + (int) ((t3[slot3(k)] ^ kk) < 0x10000u) + (int) ((t4[slot4(k)] ^ kk) < 0x10000u);
 						lost |= ballot(carry[j] != EMPTY && kept < 2) != 0;
 					}
 				}
@@ -493,7 +508,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				xk[j] = br << (2 * j);	// this k-mer in the top half
 				ok[j] = (nw & (0x2AAAAu << (2 * j))) == 0;
 				const unsigned prod = mul24(xk[j] >> 16, HASH_C), kk = xk[j] & 0xFFFF0000u;
-				const unsigned e1 = lds_read_u32(lshl_add<2>(prod >> 22, l1)) ^ kk;
+				const unsigned e1 = lds_read_u32(lshl_add<2>(prod >> (32 - T1B), l1)) ^ kk;
 				const unsigned e2 = lds_read_u32(lshl_add<2>(__builtin_amdgcn_ubfe(prod, 14, 8), l2)) ^ kk;
 				// an entry of this k-mer reads as its bare position (< 0x10000), anything else as >= 0x10000
 				m1[j] = e1 < e2 ? e1 : e2;
@@ -561,7 +576,97 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		}
 		MARK("scan");
 		best = P.qual_nn * (double) (flen + rlen);	// assembler.c:60
-		if (all || ncand > 4) {
+		if (!counting_algo<ALGO>()) {
+			// ---- pear / rdp_mle: an overlap's score is a sum of per-base table values (algo_pear.c:32-59,
+			// algo_rdp_mle.c:43-74).  Lanes produce the terms.  Exact sums: lane 0 adds them in the reference's order.
+			// Any-order sums: every lane adds its own, the wave adds the lanes (|error| < 1e-9), and a comparison closer
+			// than 1e-6 -- or a min_overlapbits verdict that close -- sends the pair to the general kernel, which sums in
+			// reference order.  Pairs with many candidates go there too (a candidate per lane, each summed in order).
+			if (all || ncand > 4) {
+				note(P, 3, lane);
+				status = PAMD_ST_DEFER;
+				break;
+			}
+			const unsigned lF = lds_addr(wb + FK_F), lR = lds_addr(wb + FK_R), lT = lds_addr(ltab);
+			double *const ps = reinterpret_cast<double *>(wb + FK_T1);	// the terms of one candidate, where the k-mer tables were
+			deep_dirty = deep_dirty || EXACT;
+			const double nrb = -P.pear_random_base, nn = P.qual_nn;
+			bool ambiguous = false;
+			for (int c = 0; c < ncand; c++) {
+				const int ov = c == 0 ? ov0 : (c == 1 ? ov1 : (c == 2 ? ov2 : ov3));
+				double part = 0.0;
+#pragma unroll
+				for (int r = 0; r < ROUNDS; r++) {
+					const int i = 64 * r + lane;
+					if (64 * r < ov && i < ov) {
+						const int fi = flen - ov + i, ri = rlen - 1 - i;
+						const unsigned ef = lds_read_u16(lF + 2u * (unsigned) fi), er = lds_read_u16(lR + 2u * (unsigned) ri);
+						const unsigned a = ef & 0xFFu, b = er & 0xFFu, qa = ef >> 8;
+						const unsigned base = (a & b) != 0 ? PAMD_LT_A : PAMD_LT_B;
+						double term;
+						if (ALGO == PAMD_ALGO_PEAR) {
+							// the second index is the FORWARD read's quality at the reverse index (algo_pear.c:52,54, sic);
+							// past the forward read the reference reads beyond the array: defined as quality 0 here
+							const unsigned qb = ri < flen ? lds_read_u16(lF + 2u * (unsigned) ri) >> 8 : 0u;
+							term = (a == 15u || b == 15u) ? nrb : lds_read_f64(lT + 8u * (base + qa * PAMD_NQ + qb));
+						} else {
+							term = lds_read_f64(lT + 8u * (base + qa * PAMD_NQ + (er >> 8))) - nn;
+						}
+						if (EXACT)
+							ps[i] = term;
+						else
+							part += term;
+					}
+				}
+				double pr;
+				if (EXACT) {
+					wave_sync();
+					double acc = 0.0;
+					if (lane == 0) {	// the reference's own order, eight reads in flight
+						int i = 0;
+						for (; i + 8 <= ov; i += 8) {
+							const double v0 = ps[i], v1 = ps[i + 1], v2 = ps[i + 2], v3 = ps[i + 3];
+							const double v4 = ps[i + 4], v5 = ps[i + 5], v6 = ps[i + 6], v7 = ps[i + 7];
+							acc += v0;
+							acc += v1;
+							acc += v2;
+							acc += v3;
+							acc += v4;
+							acc += v5;
+							acc += v6;
+							acc += v7;
+						}
+						for (; i < ov; i++)
+							acc += ps[i];
+					}
+					wave_sync();
+					pr = uni_f64(acc);
+					if (pr > best) {	// strict: the ascending scan keeps the smallest overlap on ties
+						best = pr;
+						bo = ov;
+					}
+				} else {
+					pr = wave_sum_any_order(part);
+					if (pr > best + 1e-6) {
+						best = pr;
+						bo = ov;
+					} else if (!(pr < best - 1e-6)) {
+						ambiguous = true;
+					}
+				}
+			}
+			if (!EXACT) {
+				for (int mi = 0; mi < P.n_modules; mi++)	// plugin_min_overlapbits.c:17-23 reads this sum
+					ambiguous |= P.modules[mi].kind == 2 && fabs(P.modules[mi].nats - best) <= 1e-6;
+				if (ambiguous) {
+					note(P, 2, lane);
+					status = PAMD_ST_DEFER;
+					break;
+				}
+			}
+			bo = uni(bo);
+			best = uni_f64(best);
+		} else if (all || ncand > 4) {
 			// ---- pairs without a seeded overlap, tandem repeats: a candidate per lane (three pairs in a hundred) ----
 			const ManyResult mr = scan_many<ALGO>(wb, all ? 1 : 0, size, minov, flen, rlen, P.qual_nn, P.sb_pmatch, P.sb_pmismatch, best, lane);
 			best = uni_f64(mr.best);	// a function's results come back in vector registers
@@ -646,6 +751,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		uint8_t *const row_nt = k_nt + (store ? off : 0);
 		double *const row_p = k_p + (store ? off : 0);
 		double qacc = 0.0;	// this lane's share of the quality sum, any order
+		double pmin = 0.0;	// PHRED: this lane's smallest log-p (every log-p is <= 0)
 		// ROUNDS rounds of 64 bases per region, straight-line: forward-only bases [0, A) (assembler.c:162-173), overlapping
 		// bases [A, A + novl) (assembler.c:181-228), reverse-only bases [A + novl, seqlen) (assembler.c:231-243), in two
 		// batches (forward-only + overlap, then reverse-only) of three passes each -- read the staged bases, read the
@@ -699,7 +805,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				} else if (ALGO == PAMD_ALGO_FLASH) {	// algo_flash.c:63-80
 					const unsigned d = fq > rq ? fq - rq : rq - fq;
 					qi = PAMD_LT_SCORE + (match ? (fq > rq ? fq : rq) : (d < 2 ? 2 : d));
-				} else {	// algo_simple_bayes.c:68-75, algo_uparse.c:68-75, algo_stitch.c:59-67
+				} else if (ALGO == PAMD_ALGO_RDP_MLE) {	// algo_rdp_mle.c:29-41
+					qi = match ? PAMD_LT_SCORE + (fq > rq ? fq : rq) : PAMD_LT_C + fq * PAMD_NQ + rq;
+				} else {	// algo_simple_bayes.c:68-75, algo_pear.c:61-68, algo_uparse.c:68-75, algo_stitch.c:59-67
 					qi = (match ? PAMD_LT_A : PAMD_LT_B) + fq * PAMD_NQ + rq;
 				}
 				if (cliff) {
@@ -721,6 +829,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				if (lane < sA - 64 * r) {
 					gA[64 * r] = qa[r];
 					qacc += qa[r];
+					if (PHRED)
+						pmin = qa[r] < pmin ? qa[r] : pmin;
 				}
 				degen += __popcll(lanes_below(A - 64 * r) & ballot((ea[r] & 0xFFu) == 15u));	// PANDA_NT_IS_DEGN: only N here
 			}
@@ -732,6 +842,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				if (lane < sO - 64 * r) {
 					gO[64 * r] = qo[r];
 					qacc += qo[r];
+					if (PHRED)
+						pmin = qo[r] < pmin ? qo[r] : pmin;
 				}
 				degen += __popcll(lanes_below(novl - 64 * r) & ballot((nto[r] & 0xFFu) == 15u));
 			}
@@ -764,6 +876,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				if (lane < sB - 64 * r) {
 					gB[64 * r] = qb[r];
 					qacc += qb[r];
+					if (PHRED)
+						pmin = qb[r] < pmin ? qb[r] : pmin;
 				}
 				degen += __popcll(lanes_below(Bn - 64 * r) & ballot((eb[r] & 0xFFu) == 15u));
 			}
@@ -775,6 +889,16 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		// the nt row leaves LDS in 16-byte stores (rows are 16-base aligned)
 		if (store && lane * 16 < seqlen)
 			reinterpret_cast<uint4 *>(row_nt)[lane] = reinterpret_cast<const uint4 *>(nts)[lane];
+		if (PHRED) {
+			// panda_result_phred (nt.c:126-150) is 1 at or below qual_score[0] and does not decrease above it, so the row's
+			// smallest phred is that of its smallest log-p: one bisection per pair instead of one per base
+			for (int o = 32; o > 0; o >>= 1) {
+				const double other = __shfl_xor(pmin, o);
+				pmin = other < pmin ? other : pmin;
+			}
+			const double lowest = uni_f64(pmin);
+			phmin = seqlen > 0 ? result_phred(ltab + PAMD_LT_SCORE, lowest) : 127;	// an empty row passes any threshold
+		}
 		if (!EXACT) {
 			qsum = wave_sum_any_order(qacc);	// divided by len in finish64() ...
 			// ... unless the quotient could land within 1e-9 of the LOWQ threshold (tested without dividing): the general
@@ -809,11 +933,12 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	pd.len_bo = put_lane(pd.len_bo, (unsigned) seqlen | ((unsigned) (bo < 0 ? 0 : bo) << 16), mine);
 	pd.ex_mm = put_lane(pd.ex_mm, (unsigned) examined | ((unsigned) mism << 16), mine);
 	pd.dg_fo = put_lane(pd.dg_fo, (unsigned) degen | (EXACT ? (unsigned) (seqlen - rlen) << 16 : 0u), mine);	// exact sums: + the forward-only bases
-	pd.ro_st = put_lane(pd.ro_st, ((unsigned) status << 16) | ((unsigned) slow << 24) | (63u << 26), mine);
+	pd.ro_st = put_lane(pd.ro_st, ((unsigned) status << 16) | ((unsigned) slow << 24) | ((unsigned) (phmin > 63 ? 63 : phmin) << 26), mine);
 }
 
 // ROUNDS: rounds of 64 bases a read can span (rows of at most 64 * ROUNDS bases)
-template <int ALGO, int ROUNDS, bool EXACT>
+// PHRED: a min_phred module is loaded, the merge tracks the row's smallest log-p (plugin_min_phred.c:8-22)
+template <int ALGO, int ROUNDS, bool EXACT, bool PHRED>
 __global__ __launch_bounds__(1024) void pamd_fast_kernel(const PamdKernelParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	double *ltab = reinterpret_cast<double *>(lds);
@@ -829,7 +954,7 @@ __global__ __launch_bounds__(1024) void pamd_fast_kernel(const PamdKernelParams 
 		lctr[i] = 0;
 	__syncthreads();
 
-	unsigned char *wb = lds + P.lds_primer_off + (size_t) wave * FK_WAVE_BYTES;	// (no primers here: the per-wave regions start where the general kernel keeps them)
+	unsigned char *wb = lds + P.lds_primer_off + (size_t) wave * Geo<t1_bits<ALGO>()>::WAVE_BYTES;	// (no primers here: the per-wave regions start where the general kernel keeps them)
 	WaveArena arena;
 	arena.cur = 0;
 	arena.end = 0;
@@ -858,7 +983,7 @@ __global__ __launch_bounds__(1024) void pamd_fast_kernel(const PamdKernelParams 
 		nxt.f = load_row(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
 		nxt.r = load_row(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
-		fast_pair<ALGO, ROUNDS, EXACT>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane, flen, rlen, cur, nxt);
+		fast_pair<ALGO, ROUNDS, EXACT, PHRED>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane, flen, rlen, cur, nxt);
 		MARK("loop");
 		npend++;
 		if (npend == 64) {
@@ -884,9 +1009,7 @@ __global__ __launch_bounds__(1024) void pamd_fast_kernel(const PamdKernelParams 
 
 // ---- host side: does the lean kernel serve this configuration, and its launch ---------------------------------
 int pamd_fast_supports(const PamdKernelParams &p) {
-	if (p.algo == PAMD_ALGO_PEAR || p.algo == PAMD_ALGO_RDP_MLE)
-		return 0;	// per-base scores: the general kernel
-	if (p.smax > 256 || p.post_primers || p.has_min_phred)
+	if (p.smax > 256 || p.post_primers)
 		return 0;
 	if (p.fprimer_len > 0 || p.rprimer_len > 0 || p.ftrim != 0 || p.rtrim != 0 || p.maxoverlap != 0)
 		return 0;
@@ -896,7 +1019,7 @@ int pamd_fast_supports(const PamdKernelParams &p) {
 }
 
 size_t pamd_fast_lds_bytes(const PamdKernelParams &p, int waves_per_wg) {
-	return (size_t) p.lds_primer_off + (size_t) waves_per_wg * FK_WAVE_BYTES;
+	return (size_t) p.lds_primer_off + (size_t) waves_per_wg * (p.algo == PAMD_ALGO_RDP_MLE ? Geo<9>::WAVE_BYTES : Geo<10>::WAVE_BYTES);
 }
 
 int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg, size_t lds_bytes, void *stream) {
@@ -904,11 +1027,18 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	void (*kern)(const PamdKernelParams) = nullptr;
 	const int rounds = p.smax <= 128 ? 2 : (p.smax <= 192 ? 3 : 4);
-#define FK_PICK2(A, E) (rounds == 2 ? pamd_fast_kernel<A, 2, E> : (rounds == 3 ? pamd_fast_kernel<A, 3, E> : pamd_fast_kernel<A, 4, E>))
+#define FK_PICK3(A, E, PH) (rounds == 2 ? pamd_fast_kernel<A, 2, E, PH> : (rounds == 3 ? pamd_fast_kernel<A, 3, E, PH> : pamd_fast_kernel<A, 4, E, PH>))
+#define FK_PICK2(A, E) (p.has_min_phred ? FK_PICK3(A, E, true) : FK_PICK3(A, E, false))
 #define FK_PICK(A) (p.exact_sums ? FK_PICK2(A, true) : FK_PICK2(A, false))
 	switch (p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
 		kern = FK_PICK(PAMD_ALGO_SIMPLE_BAYES);
+		break;
+	case PAMD_ALGO_PEAR:
+		kern = FK_PICK(PAMD_ALGO_PEAR);
+		break;
+	case PAMD_ALGO_RDP_MLE:
+		kern = FK_PICK(PAMD_ALGO_RDP_MLE);
 		break;
 	case PAMD_ALGO_UPARSE:
 		kern = FK_PICK(PAMD_ALGO_UPARSE);
@@ -928,6 +1058,7 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 	}
 #undef FK_PICK
 #undef FK_PICK2
+#undef FK_PICK3
 	hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 	if (e0 != hipSuccess) {
 		pamd_set_error("hipFuncSetAttribute(%zu bytes LDS, lean kernel): %s", lds_bytes, hipGetErrorString(e0));
