@@ -221,18 +221,18 @@ def main():
     algo_bytes = 2 * lens + 9 * merged_bases + 64 * n
     achieved = algo_bytes / avg_kernel_s / 1e9
 
-    # HBM bytes per launch from the PMC passes (tools/traffic_probe.py -> profiles/r01_traffic_config*.json):
+    # HBM bytes per launch from the PMC passes (tools/traffic_probe.py -> profiles/r02_traffic_config*.json):
     # FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, units calibrated on a 1 GiB copy in the same
     # process (gfx950: FETCH_SIZE counts 2 KiB per unit for wide reads).  Measured per pair on the same
     # workload; scaled to this launch's pair count.
     traffic = args.traffic_bytes
     traffic_src = "--traffic-bytes" if traffic is not None else None
-    tpath = os.path.join(ROOT, "profiles", f"r01_traffic_config{cfg_index}_{args.sums}.json")
+    tpath = os.path.join(ROOT, "profiles", f"r02_traffic_config{cfg_index}_{args.sums}.json")
     if traffic is None and os.path.exists(tpath):
         with open(tpath) as fh:
             tj = json.load(fh)
         traffic = tj["hbm_bytes_per_pair"] * n
-        traffic_src = f"profiles/r01_traffic_config{cfg_index}_{args.sums}.json ({tj['pairs']} pairs per launch)"
+        traffic_src = f"profiles/r02_traffic_config{cfg_index}_{args.sums}.json ({tj['pairs']} pairs per launch)"
 
     value = n * world * args.steps / elapsed
     out = {
@@ -266,7 +266,7 @@ def main():
         "stat": {k: ctr[k] for k in ("count", "ok", "noalgn", "lowq", "badr", "nofp", "norp", "slow")},
         "roofline": {
             "bound": "hbm",
-            "kernel": "pamd_assemble_kernel",
+            "kernel": "pamd_fast_kernel + pamd_assemble_kernel over the pairs it deferred (both inside the HIP events)" if asm.last_deferred() >= 0 else "pamd_assemble_kernel",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

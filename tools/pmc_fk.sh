@@ -1,4 +1,5 @@
 #!/bin/bash
+# (SQ counters only: a pass with TA_* counters aborted inside rocprofv3 on this pool and hung until killed.)
 # Hardware counters of the two assemble kernels of a default (two-kernel) launch, one rocprofv3 pass per group, plus the
 # kernel-trace split (development aid; GPU box only).   bash tools/pmc_fk.sh [pairs] [config]
 export TMPDIR=/tmp
@@ -15,10 +16,7 @@ for group in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INST
              "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM" \
              "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_FLAT SQ_INSTS_BRANCH SQ_INSTS_SMEM" \
              "SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL" \
-             "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL" \
-             "TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES" \
-             "TCP_PENDING_STALL_CYCLES TCP_TCC_WRITE_REQ_LATENCY TCP_TCC_WRITE_REQ" \
-             "TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT"; do
+             "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL"; do
 	i=$((i + 1))
 	(cd /tmp && timeout 150 rocprofv3 --pmc $group --output-format csv -d "$OUT/g$i" -o p -- python3 "$ROOT/tools/fk_probe.py" --only $MODE --pairs $PAIRS --config $CONFIG --reps 1 > "$OUT/g$i.log" 2>&1)
 done
