@@ -52,7 +52,7 @@ struct Geo {
 static_assert(FK_NT % 16 == 0 && FK_T1 % 16 == 0 && FK_FLAGS % 16 == 0, "16-byte LDS accesses");
 template <int ALGO>
 __device__ __host__ constexpr int t1_bits() {
-	return ALGO == PAMD_ALGO_RDP_MLE ? 9 : 10;
+	return ALGO == PAMD_ALGO_RDP_MLE ? 9 : 10;	// (512 slots for every scorer: measured 2 % slower on config 1)
 }
 
 // k-mer -> slot of table 1..4: bit fields of one 24-bit multiplicative hash (a second one for the rarely used last table)
