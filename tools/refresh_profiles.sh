@@ -27,5 +27,7 @@ traffic 2 fast 20000000
 traffic 3 fast 20000000
 traffic 4 fast 40000000
 bash tools/pmc_fk.sh 8000000 1 > "$OUT/pmc_config1_fast.txt" 2>&1
+bash tools/fk_phases.sh build > "$OUT/phases_build.log" 2>&1 && bash tools/fk_phases.sh 8000000 > "$OUT/phases_config1_fast.txt" 2>&1
+rm -rf "$ROOT"/pandaseq_amd/libpandaseq_amd_fkstop*
 for f in "$OUT"/bench_*.json; do python3 -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1].split('/')[-1], round(d['value']/1e6,1), 'M pairs/s', round(d['roofline']['frac'],4))" $f; done
 for f in "$OUT"/traffic_config*.json; do python3 -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1].split('/')[-1], round(d['hbm_bytes_per_pair'],1), 'B/pair')" $f; done
