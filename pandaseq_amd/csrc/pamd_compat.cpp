@@ -23,6 +23,7 @@
 static_assert(sizeof(panda_qual) == 2, "panda_qual ABI");
 static_assert(sizeof(panda_result) == 16 && offsetof(panda_result, p) == 8, "panda_result ABI");
 static_assert(sizeof(panda_seq_identifier) == 368, "panda_seq_identifier ABI");
+static_assert(offsetof(panda_seq_identifier, tag) - offsetof(panda_seq_identifier, lane) == 16, "lane, tile, x, y are four adjacent ints");
 static_assert(sizeof(panda_result_seq) == 480 && offsetof(panda_result_seq, sequence) == 384 && offsetof(panda_result_seq, overlap) == 464, "panda_result_seq ABI");
 static_assert(sizeof(panda_qual) == sizeof(pamd_qual), "panda_qual == pamd_qual");
 
@@ -818,7 +819,12 @@ struct pamd_slot {
 	hipStream_t stream = nullptr;
 	size_t cap = 0;		// pairs all of the above are sized for (rows of ROW bases in, OUT_ROW bases out)
 	// the batch
-	std::vector<panda_result_seq> res;	// one record per pair pulled from the source; the source writes .name itself
+	// what is remembered of every pair pulled from the source, compactly (the caller's thread streams through all of
+	// it twice, once pulling and once replaying: a 480-byte record per pair was most of what it moved): the identifier's
+	// four numbers and four strings back to back, the read lengths
+	std::vector<char> ids;
+	std::vector<uint32_t> id_at;
+	std::vector<uint16_t> len_f, len_r;
 	std::vector<int> pre;			// -1 short read, >= 0 rejected by precheck module k, <= -3: device pair -(k+3)
 	panda_result *rows = nullptr;		// panda_result[] of the pairs the kernel accepted, back to back (never zero-filled)
 	size_t rows_cap = 0;
@@ -1021,13 +1027,17 @@ void slot_fill_and_submit(PandaAssembler a, pamd_slot *s) {
 		fprintf(stderr, "pandaseq_amd: cannot allocate the staging buffers of a %zu-pair batch\n", want);
 		abort();
 	}
-	if (s->res.size() < want) {
-		s->res.resize(want);
+	if (s->pre.size() < want) {
 		s->pre.resize(want);
+		s->id_at.resize(want);
+		s->len_f.resize(want);
+		s->len_r.resize(want);
 	}
+	s->ids.clear();
+	s->ids.reserve(want * 40);
 	s->stride = 256;
+	panda_result_seq &r = a->result;	// the source fills in the identifier here (cache-hot); it is packed away below
 	while (s->n < want) {
-		panda_result_seq &r = s->res[s->n];
 		const panda_qual *f = nullptr, *rv = nullptr;
 		size_t fl = 0, rl = 0;
 		if (!a->next(&r.name, &f, &fl, &rv, &rl, a->next_data)) {
@@ -1065,8 +1075,30 @@ void slot_fill_and_submit(PandaAssembler a, pamd_slot *s) {
 			s->h_rlen[k] = (uint16_t) rl;
 			pre = -(int) k - 3;
 		}
-		r.forward_length = fl;
-		r.reverse_length = rl;
+		{	// pack the identifier: lane, tile, x, y, then the four strings with their terminators
+			const panda_seq_identifier &id = r.name;
+			const size_t li = strnlen(id.instrument, sizeof id.instrument - 1), lr = strnlen(id.run, sizeof id.run - 1);
+			const size_t lc = strnlen(id.flowcell, sizeof id.flowcell - 1), lt = strnlen(id.tag, sizeof id.tag - 1);
+			const size_t at = s->ids.size();
+			s->ids.resize(at + 16 + li + lr + lc + lt + 4);
+			char *o = s->ids.data() + at;
+			memcpy(o, &id.lane, 16);	// lane, tile, x, y are adjacent ints (pandaseq-common.h:248-262)
+			o += 16;
+			memcpy(o, id.instrument, li);
+			o[li] = 0;
+			o += li + 1;
+			memcpy(o, id.run, lr);
+			o[lr] = 0;
+			o += lr + 1;
+			memcpy(o, id.flowcell, lc);
+			o[lc] = 0;
+			o += lc + 1;
+			memcpy(o, id.tag, lt);
+			o[lt] = 0;
+			s->id_at[s->n] = (uint32_t) at;
+		}
+		s->len_f[s->n] = (uint16_t) fl;
+		s->len_r[s->n] = (uint16_t) rl;
 		s->pre[s->n] = pre;
 		s->n++;
 	}
@@ -1103,7 +1135,25 @@ const panda_result_seq *slot_replay(PandaAssembler a, pamd_slot *s, size_t i) {
 	}
 	const size_t k = (size_t) (-pre - 3);
 	const pamd_pair_result &d = s->h_res[k];
-	panda_result_seq &res = s->res[i];
+	panda_result_seq &res = a->result;	// one record, valid until the next call (pandaseq-assembler.h:172-173)
+	{	// unpack the identifier
+		const char *o = s->ids.data() + s->id_at[i];
+		memcpy(&res.name.lane, o, 16);
+		o += 16;
+		size_t l = strlen(o);
+		memcpy(res.name.instrument, o, l + 1);
+		o += l + 1;
+		l = strlen(o);
+		memcpy(res.name.run, o, l + 1);
+		o += l + 1;
+		l = strlen(o);
+		memcpy(res.name.flowcell, o, l + 1);
+		o += l + 1;
+		l = strlen(o);
+		memcpy(res.name.tag, o, l + 1);
+	}
+	res.forward_length = s->len_f[i];
+	res.reverse_length = s->len_r[i];
 	res.forward = reinterpret_cast<const panda_qual *>(s->h_fwd + k * s->stride);
 	res.reverse = reinterpret_cast<const panda_qual *>(s->h_rev + k * s->stride);
 	res.forward_offset = d.fwd_offset;

@@ -958,30 +958,34 @@ __global__ __launch_bounds__(1024) void pamd_fast_kernel(const PamdKernelParams 
 	WaveArena arena;
 	arena.cur = 0;
 	arena.end = 0;
-	const u64 total_waves = (u64) gridDim.x * (u64) nwaves;
+	// (pair indices are 32-bit here -- pamd_fast_supports() keeps the batch below 2^31 pairs -- and the arena is counted in
+	// units of 16 bases: scalar registers are what this kernel runs out of, and every spilled one costs vector
+	// instructions, v_writelane / v_readlane, on the way out and back)
+	const unsigned total_waves = gridDim.x * (unsigned) nwaves;
+	const unsigned n_pairs = (unsigned) P.n_pairs;
 	// Persistent loop with a one-pair software prefetch: the four loads of pair k+1 (two lengths, two rows) are
 	// issued, branch-free, before pair k is assembled and are first touched when k is done.
-	u64 pair = (u64) blockIdx.x * (u64) nwaves + (u64) wave;
-	const u64 last = P.n_pairs - 1;
-	u64 q = pair < P.n_pairs ? pair : last;
+	unsigned pair = blockIdx.x * (unsigned) nwaves + (unsigned) wave;
+	const unsigned last = n_pairs - 1u;
+	unsigned q = pair < n_pairs ? pair : last;
 	Carry cur;
 	cur.flen_v = P.flen[q];
 	cur.rlen_v = P.rlen[q];
-	cur.f = load_row(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
-	cur.r = load_row(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
+	cur.f = load_row(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+	cur.r = load_row(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
 	settle(cur);
 	int npend = 0;
 	bool deep_dirty = true;	// the first pair clears all four tables
 	Pend64 pd = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
-	u64 group_first = pair;
-	while (pair < P.n_pairs) {
-		const u64 next = pair + total_waves;
-		q = next < P.n_pairs ? next : last;
+	unsigned group_first = pair;
+	while (pair < n_pairs) {
+		const unsigned next = pair + total_waves;
+		q = next < n_pairs ? next : last;
 		Carry nxt;
 		nxt.flen_v = P.flen[q];
 		nxt.rlen_v = P.rlen[q];
-		nxt.f = load_row(P.fwd + q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
-		nxt.r = load_row(P.rev + q * P.rev_row_bytes, P.rev_row_bytes, lane);
+		nxt.f = load_row(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+		nxt.r = load_row(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
 		fast_pair<ALGO, ROUNDS, EXACT, PHRED>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane, flen, rlen, cur, nxt);
 		MARK("loop");
@@ -1013,8 +1017,8 @@ int pamd_fast_supports(const PamdKernelParams &p) {
 		return 0;
 	if (p.fprimer_len > 0 || p.rprimer_len > 0 || p.ftrim != 0 || p.rtrim != 0 || p.maxoverlap != 0)
 		return 0;
-	if (p.n_pairs > 0xFFFFFFFFull)
-		return 0;	// the deferred list holds 32-bit pair indices
+	if (p.n_pairs > 0x7FFFFFFFull)
+		return 0;	// 32-bit pair indices in the kernel and in the deferred list
 	return 1;
 }
 
