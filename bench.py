@@ -266,7 +266,9 @@ def main():
         "stat": {k: ctr[k] for k in ("count", "ok", "noalgn", "lowq", "badr", "nofp", "norp", "slow")},
         "roofline": {
             "bound": "hbm",
-            "kernel": "pamd_fast_kernel + pamd_assemble_kernel over the pairs it deferred (both inside the HIP events)" if asm.last_deferred() >= 0 else "pamd_assemble_kernel",
+            "kernel": ("pamd_fast_kernel + pamd_assemble_kernel over the pairs it deferred (both inside the HIP events)" if asm.last_deferred() >= 0
+                       else "pamd_primer_kernel + pamd_assemble_kernel (both inside the HIP events)" if cfg_index == 2 and not args.primers_after
+                       else "pamd_assemble_kernel"),
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

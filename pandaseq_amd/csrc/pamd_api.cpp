@@ -65,6 +65,8 @@ struct pamd_assembler {
 	int exact_sums = 1;
 	int post_primers = 0;
 	int fast_path = 1;		// ordinary pairs go through the lean kernel when the configuration allows (pamd_fast.hip)
+	uint32_t *d_primer_off = nullptr;	// `-p` / `-q`: the primer kernel's word per pair ...
+	size_t primer_cap = 0;	// ... and how many pairs it has room for
 	uint32_t *d_defer = nullptr;	// the pairs it leaves to the general kernel ...
 	size_t defer_cap = 0;
 	unsigned *d_defer_count = nullptr;	// ... and how many
@@ -198,6 +200,8 @@ void pamd_assembler_destroy(pamd_assembler *a) {
 		(void) hipFree(a->d_scratch);
 	if (a->d_defer)
 		(void) hipFree(a->d_defer);
+	if (a->d_primer_off)
+		(void) hipFree(a->d_primer_off);
 	if (a->d_defer_count)
 		(void) hipFree(a->d_defer_count);
 	for (void *q : a->hb_ptr)
@@ -617,7 +621,23 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 		HIP_TRY(hipMalloc(&a->d_defer, b->n_pairs * sizeof(uint32_t)));
 		a->defer_cap = b->n_pairs;
 	}
+	// `-p` / `-q`: the primers are found by a kernel of their own, first (pamd_primer.hip)
+	const bool primers_first = !a->post_primers && (a->fprimer_len > 0 || a->rprimer_len > 0);
+	if (primers_first && a->primer_cap < b->n_pairs) {
+		if (a->d_primer_off)
+			HIP_TRY(hipFree(a->d_primer_off));
+		a->d_primer_off = nullptr;
+		a->primer_cap = 0;
+		HIP_TRY(hipMalloc(&a->d_primer_off, (2 * b->n_pairs + 4) * sizeof(uint32_t)));	// a word per pair, the list of pairs to redo, its count
+		a->primer_cap = b->n_pairs;
+	}
+	p.primer_offsets = primers_first ? a->d_primer_off : nullptr;
 	HIP_TRY(hipEventRecord(a->ev_start, st));
+	if (primers_first) {
+		rc = pamd_launch_primers(p, a->cu_count, stream);
+		if (rc != PAMD_OK)
+			return rc;
+	}
 	if (two) {
 		HIP_TRY(hipMemsetAsync(a->d_defer_count, 0, sizeof(unsigned), st));
 		PamdKernelParams pf = p;

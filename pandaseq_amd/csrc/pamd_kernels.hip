@@ -193,120 +193,6 @@ __device__ __forceinline__ int stage_read(const uint4 v, int len, int lane, uint
 	return __builtin_amdgcn_readlane(mine, top);
 }
 
-// ---- primer offset (offset.c:47-112) ---------------------------------------------------------
-// Lane s owns the alignment of the primer starting at read position s and accumulates its
-// log-probability in primer order x = 0..plen-1, which is the order in which offset.c:79-87 adds
-// into bucket s.  That bucket is judged at index = s + plen (offset.c:72-77).
-// Returns what computeoffset() returns: 0 = not found, else 1 + number of bases to clip.
-// logdomain: compare the values before exp() (zero penalty only, where exp is the last, monotone step); `near` then
-// reports whether a comparison was so close that exp() might have decided it otherwise.
-__device__ __forceinline__ int primer_offset_scan(const PamdKernelParams &P, const double *ltab, const uint16_t *S, int len, const uint8_t *primer, int plen, int lane, const bool logdomain, bool &near) {
-	bool close = false;
-	// bestpr = exp(primerlen * threshold); with a zero penalty every candidate is exp(x) of some x
-	// and exp is monotone, so we compare x (see DESIGN.md "exp in the primer scan").
-	double best = logdomain ? (double) plen * P.threshold : exp((double) plen * P.threshold);
-	int besti = 0;
-	// Pruning (zero penalty only): every term is a log-probability <= 0, so an alignment's partial sum only
-	// falls; once it is clearly below bound * (index + 1), where bound is the best value any lane has found,
-	// its final value cannot exceed bound and it can stop.  The wave leaves a block of 64 starts as soon as
-	// no lane can still win -- after the real primer has been seen (normally in the first block) that is
-	// after the first mismatching base or two instead of all `plen`.
-	double bound = best;
-	for (int base = 0; base + plen <= len - 1; base += 64) {
-		const int s = base + lane;
-		const int index = s + plen;
-		const bool have = index <= len - 1;
-		const int ss = have ? s : 0;	// lanes past the end walk the first alignment and are ignored
-		const double floor_acc = bound * (double) (index + 1) - 1e-6;
-		double acc = 0.0;
-		// same order as offset.c:79-87 (x ascending); the loads of eight steps are issued together
-		int x = 0;
-		bool live = true;
-		for (; x + 8 <= plen && live; x += 8) {
-			unsigned e[8], pn[8];
-			double t[8];
-#pragma unroll
-			for (int u = 0; u < 8; u++) {
-				e[u] = S[ss + x + u];
-				pn[u] = primer[x + u];
-			}
-#pragma unroll
-			for (int u = 0; u < 8; u++) {
-				const int q = clampq(qual_of(e[u]));
-				t[u] = ltab[(((nt_of(e[u]) & pn[u]) != 0) ? PAMD_LT_SCORE : PAMD_LT_ERR) + q];
-			}
-#pragma unroll
-			for (int u = 0; u < 8; u++)
-				if (pn[u] != NT_N)
-					acc += t[u];
-			live = !logdomain || ballot(have && !(acc < floor_acc)) != 0;
-		}
-		if (!live)
-			continue;	// no start of this block can beat what has been found
-		for (; x < plen; x++) {
-			const unsigned pn = primer[x];
-			if (pn != NT_N) {
-				const unsigned e = S[ss + x];
-				const int q = clampq(qual_of(e));
-				acc += ((nt_of(e) & pn) != 0) ? ltab[PAMD_LT_SCORE + q] : ltab[PAMD_LT_ERR + q];
-			}
-		}
-		double v = acc / (double) (index + 1);
-		if (!logdomain)
-			v = exp(v) - (double) index * P.primer_penalty;
-		const bool better = have && v > best;	// strict: the earliest index wins ties (offset.c:74)
-		// Compared before exp(), two values may differ and their exponentials not: exp'(x) <= 1 here, so a difference
-		// below an ulp of 1 can vanish in rounding, and the reference then keeps the earlier index.  Such a scan is
-		// repeated with the comparisons made after exp(), as the reference makes them (primer_offset below).
-		close |= logdomain && better && v - best <= 4.5e-16;
-		if (better) {
-			best = v;
-			besti = index + 1;
-		}
-		if (logdomain && ballot(better) != 0) {
-			double m = besti != 0 ? best : bound;
-			for (int off = 32; off > 0; off >>= 1) {
-				const double o = __shfl_xor(m, off);
-				m = o > m ? o : m;
-			}
-			bound = uni_f64(m);
-		}
-	}
-	// first-maximum across lanes: larger value wins, equal values -> smaller index (values whose exponentials may
-	// coincide are ordered by their exponentials, as above)
-	for (int off = 32; off > 0; off >>= 1) {
-		const double ob = __shfl_xor(best, off);
-		const int oi = __shfl_xor(besti, off);
-		const bool greater = ob > best, equal = ob == best;
-		close |= logdomain && oi != 0 && besti != 0 && ob != best && fabs(ob - best) <= 4.5e-16;
-		const bool take = (oi != 0) && (besti == 0 || greater || (equal && oi < besti));
-		if (take) {
-			best = ob;
-			besti = oi;
-		}
-	}
-	near = ballot(close) != 0;
-	return uni(besti);
-}
-
-__device__ int primer_offset(const PamdKernelParams &P, const double *ltab, const uint16_t *S, int len, const uint8_t *primer, int plen, int lane) {
-	if (plen > len)
-		return 0;
-	// First with the comparisons made before exp() when there is no penalty; again with every comparison made after exp(),
-	// as offset.c:59,72-74 makes them, if two alignments came so close that exp() may not tell them apart (once in 1e13
-	// pairs).  One body, a run-time switch: an out-of-line second copy costs the hot scan 6 % through its call site.
-	bool logdomain = P.primer_penalty == 0.0;
-	int r;
-	while (true) {
-		bool near = false;
-		r = primer_offset_scan(P, ltab, S, len, primer, plen, lane, logdomain, near);
-		if (!near)
-			break;
-		logdomain = false;
-	}
-	return r;
-}
-
 // ---- primer offset in the MERGED sequence (`-a`: panda_compute_offset_result, offset.c:114-133) --------
 // The same scan as primer_offset() over the merged bases staged in LDS: a base that agrees with the primer
 // adds its log-probability p, one that does not adds log(1 - exp(p)) (panda_log1mexp, offset.c:35-38).
@@ -946,7 +832,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		if (post) {
 			fo = 0;
 		} else if (P.fprimer_len > 0) {
-			const int r = primer_offset(P, ltab, L.F, flen, lprimers, P.fprimer_len, lane);
+			const int r = (int) (uni((int) P.primer_offsets[pair]) & 0xFFFF);	// found by the primer kernel (pamd_primer.hip)
 			if (r == 0) {
 				status = PAMD_ST_NOFP;
 				break;
@@ -959,7 +845,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		if (post) {
 			ro = 0;
 		} else if (P.rprimer_len > 0) {
-			const int r = primer_offset(P, ltab, L.R, rlen, lprimers + 456, P.rprimer_len, lane);
+			const int r = (int) ((unsigned) uni((int) P.primer_offsets[pair]) >> 16);
 			if (r == 0) {
 				status = PAMD_ST_NORP;
 				break;

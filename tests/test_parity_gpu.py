@@ -499,3 +499,58 @@ def test_primer_scan_when_exp_collapses_two_alignments(built):
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
         compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=exact)
         compare_counters(b.counters_dict(), o[3])
+
+
+def _plant(rng, rows, lens, primer, where, subst, lowq):
+    """Writes one member of every primer base's code set into each read at its offset, with a few wrong bases and a few
+    low qualities (rows: u8[n, stride, 2] = nt, qual)."""
+    members = [[b for b in (1, 2, 4, 8) if b & c] for c in primer]
+    for i in range(len(rows)):
+        if where[i] < 0 or where[i] + len(primer) > lens[i]:
+            continue
+        for x, m in enumerate(members):
+            p = where[i] + x
+            rows[i, p, 0] = rng.choice(m)
+            if rng.random() < subst:
+                rows[i, p, 0] = rng.choice([1, 2, 4, 8])
+            if rng.random() < lowq:
+                rows[i, p, 1] = rng.choice([0, 1, 2, 5, 9, 14])
+
+
+@pytest.mark.parametrize("plen,penalty", [(1, 0.0), (3, 0.0), (8, 0.0), (17, 0.0), (17, 0.02), (23, 0.0), (40, 0.0), (64, 0.0), (65, 0.0), (100, 0.0), (100, 0.01)])
+def test_primer_kernel_on_planted_primers(built, plen, penalty):
+    """pamd_primer.hip against offset.c:47-112 as the oracle restates it: primers of every length class (the eight-base
+    filter, the whole-wave sums, the walk in step, primers longer than a wave), with ambiguity codes and N among their
+    first bases, planted anywhere in the read or nowhere, damaged and on poor qualities; with and without a penalty."""
+    from pandaseq_amd import synth
+    import pandaseq_amd as pa
+    rng = np.random.default_rng(100 + plen)
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 31000, 3000)
+    n = len(flen)
+    codes = np.array([1, 2, 4, 8, 1, 2, 4, 8, 3, 5, 10, 12, 7, 14, 15], np.uint8)   # mostly plain bases, some ambiguity codes, N
+    fp = rng.choice(codes, plen)
+    rp = rng.choice(codes, plen)
+    if plen >= 8:
+        fp[rng.integers(0, 8)] = 15     # an N among the first eight bases of one primer, none in the other's
+        rp[:8] = rng.choice(np.array([1, 2, 4, 8], np.uint8), 8)
+    room = max(1, 250 - plen)
+    wf = np.where(rng.random(n) < 0.9, rng.integers(0, room, n) * (rng.random(n) < 0.5), -1)   # half at the start, the rest anywhere, a tenth nowhere
+    wr = np.where(rng.random(n) < 0.9, rng.integers(0, room, n) * (rng.random(n) < 0.5), -1)
+    _plant(rng, fwd, flen, fp, wf, 0.04, 0.15)
+    _plant(rng, rev, rlen, rp, wr, 0.04, 0.15)
+    flen[5] = max(1, plen - 1)          # a read shorter than its primer
+    rlen[6] = plen                      # and one exactly as long
+    asm = pa.Assembler(0)
+    asm.set_algorithm("simple_bayesian")
+    asm.set_forward_primer(fp)
+    asm.set_reverse_primer(rp)
+    asm.set_primer_penalty(penalty)
+    b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
+    o = _oracle("simple_bayesian", fwd, rev, flen, rlen, fprimer=fp, rprimer=rp, primer_penalty=penalty)
+    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+    compare_counters(b.counters_dict(), o[3])
+    # (the reference finds "a primer" in nearly every read: offset.c:72 divides by index + 1, so late weak hits pass)
+    ok = o[0]["status"] == 0
+    if penalty == 0.0 and plen >= 8:
+        assert len(np.unique(o[0]["fwd_offset"][ok])) > 8 and len(np.unique(o[0]["rev_offset"][ok])) > 8, "the case must spread its primers over the reads"
