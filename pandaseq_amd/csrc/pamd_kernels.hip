@@ -758,6 +758,7 @@ __device__ __forceinline__ double fast_quality(const double *row, double qacc, d
 // the registers a wave carries from one pair to the next (software prefetch)
 struct Carry {
 	int flen_v, rlen_v;
+	unsigned primers_v;	// `-p` / `-q`: what the primer kernel found in this pair (pamd_primer.hip)
 	uint4 f, r;
 };
 
@@ -766,9 +767,9 @@ struct Carry {
 template <int BPL>
 __device__ __forceinline__ void settle_carry(Carry &c) {
 	if (BPL == 8) {
-		asm volatile("" : "+v"(c.flen_v), "+v"(c.rlen_v), "+v"(c.f.x), "+v"(c.f.y), "+v"(c.f.z), "+v"(c.f.w), "+v"(c.r.x), "+v"(c.r.y), "+v"(c.r.z), "+v"(c.r.w));
+		asm volatile("" : "+v"(c.flen_v), "+v"(c.rlen_v), "+v"(c.primers_v), "+v"(c.f.x), "+v"(c.f.y), "+v"(c.f.z), "+v"(c.f.w), "+v"(c.r.x), "+v"(c.r.y), "+v"(c.r.z), "+v"(c.r.w));
 	} else {
-		asm volatile("" : "+v"(c.flen_v), "+v"(c.rlen_v), "+v"(c.f.x), "+v"(c.f.y), "+v"(c.r.x), "+v"(c.r.y));
+		asm volatile("" : "+v"(c.flen_v), "+v"(c.rlen_v), "+v"(c.primers_v), "+v"(c.f.x), "+v"(c.f.y), "+v"(c.r.x), "+v"(c.r.y));
 		c.f.z = c.f.w = c.r.z = c.r.w = 0u;
 	}
 }
@@ -781,6 +782,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 #endif
 ) {
 	const uint4 fregs = cur.f, rregs = cur.r;
+	const unsigned primers_found = (unsigned) uni((int) cur.primers_v);
 	PH_DECL;
 	bool rotated = false;
 	double quality_fast = 0.0;
@@ -832,7 +834,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		if (post) {
 			fo = 0;
 		} else if (P.fprimer_len > 0) {
-			const int r = (int) (uni((int) P.primer_offsets[pair]) & 0xFFFF);	// found by the primer kernel (pamd_primer.hip)
+			const int r = (int) (primers_found & 0xFFFFu);	// found by the primer kernel (pamd_primer.hip), prefetched with the reads
 			if (r == 0) {
 				status = PAMD_ST_NOFP;
 				break;
@@ -845,7 +847,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		if (post) {
 			ro = 0;
 		} else if (P.rprimer_len > 0) {
-			const int r = (int) ((unsigned) uni((int) P.primer_offsets[pair]) >> 16);
+			const int r = (int) (primers_found >> 16);
 			if (r == 0) {
 				status = PAMD_ST_NORP;
 				break;
@@ -1526,6 +1528,8 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	Carry cur;
 	cur.flen_v = P.flen[pid];
 	cur.rlen_v = P.rlen[pid];
+	const uint32_t *const found = P.primer_offsets != nullptr ? P.primer_offsets : reinterpret_cast<const uint32_t *>(P.tables);	// (else any readable word)
+	cur.primers_v = found[P.primer_offsets != nullptr ? pid : 0];
 	cur.f = load_read<BPL>(P.fwd + pid * P.fwd_row_bytes, P.fwd_row_bytes, lane);
 	cur.r = load_read<BPL>(P.rev + pid * P.rev_row_bytes, P.rev_row_bytes, lane);
 	// settle the prologue loads before the loop so that, at the loop header, the carried registers
@@ -1541,6 +1545,7 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		Carry nxt;
 		nxt.flen_v = P.flen[npid];
 		nxt.rlen_v = P.rlen[npid];
+		nxt.primers_v = found[P.primer_offsets != nullptr ? npid : 0];
 		nxt.f = load_read<BPL>(P.fwd + npid * P.fwd_row_bytes, P.fwd_row_bytes, lane);
 		nxt.r = load_read<BPL>(P.rev + npid * P.rev_row_bytes, P.rev_row_bytes, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);

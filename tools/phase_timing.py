@@ -31,7 +31,7 @@ import bench
 asm, spec = bench.setup_assembler(pa, synth, args.config, 0, exact_sums=os.environ.get("PAMD_SUMS", "exact") == "exact")
 n = args.pairs
 f, r, fl, rl = synth.generate_device(spec, 0, n)
-outs = pa.alloc_outputs(n, n * 420 + (1 << 27), "cuda:0")
+outs = pa.alloc_outputs(n, n * (620 if args.config == 2 else 440) + (1 << 28), "cuda:0")
 b = pa.DeviceBatch(n=n, fwd=f, rev=r, flen=fl, rlen=rl, **outs)
 asm.assemble_device(b)
 torch.cuda.synchronize()
