@@ -9,7 +9,7 @@ CONFIG=${2:-1}
 MODE=${MODE:-two-kernel}
 OUT=$ROOT/gpurun_out/pmc_fk
 rm -rf "$OUT"; mkdir -p "$OUT"
-(cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o p -- python3 "$ROOT/tools/fk_probe.py" --only $MODE --pairs $PAIRS --config $CONFIG --reps 3 > "$OUT/trace.log" 2>&1)
+(cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o p -- python3 "$ROOT/tools/fk_probe.py" --only $MODE --pairs $PAIRS --config $CONFIG --sums ${SUMS:-fast} --reps 3 > "$OUT/trace.log" 2>&1)
 i=0
 for group in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
              "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS" \
@@ -18,7 +18,7 @@ for group in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INST
              "SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL" \
              "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL"; do
 	i=$((i + 1))
-	(cd /tmp && timeout 150 rocprofv3 --pmc $group --output-format csv -d "$OUT/g$i" -o p -- python3 "$ROOT/tools/fk_probe.py" --only $MODE --pairs $PAIRS --config $CONFIG --reps 1 > "$OUT/g$i.log" 2>&1)
+	(cd /tmp && timeout 150 rocprofv3 --pmc $group --output-format csv -d "$OUT/g$i" -o p -- python3 "$ROOT/tools/fk_probe.py" --only $MODE --pairs $PAIRS --config $CONFIG --sums ${SUMS:-fast} --reps 1 > "$OUT/g$i.log" 2>&1)
 done
 python3 - "$OUT" "$PAIRS" <<'PY'
 import csv, glob, sys
