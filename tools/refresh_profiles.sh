@@ -2,7 +2,8 @@
 # Everything profiles/ holds for one build, in one go on the GPU box (writes gpurun_out/<tag>/; copy what is to be
 # kept into profiles/):   bash tools/refresh_profiles.sh r02
 # bench lines of configs 1 (fast sums with the CPU baseline and the end-to-end leg; exact sums), 2, 3, 4; rocprofv3
-# --kernel-trace --stats of the default bench command; SQ counters and the per-phase ablation of the lean kernel; the HBM
+# --kernel-trace --stats of the default bench command; SQ counters and the per-phase ablation of the lean kernel, SQ counters of
+# config 2's two kernels; the HBM
 # traffic passes of tools/traffic_probe.py (FETCH_SIZE and WRITE_SIZE in separate passes, calibrated on a 1 GiB copy).
 TAG=${1:-run}
 export TMPDIR=/tmp
@@ -27,6 +28,7 @@ traffic 2 fast 20000000
 traffic 3 fast 20000000
 traffic 4 fast 40000000
 bash tools/pmc_fk.sh 8000000 1 > "$OUT/pmc_config1_fast.txt" 2>&1
+bash tools/pmc_primer.sh 4000000 > "$OUT/pmc_config2.txt" 2>&1
 bash tools/fk_phases.sh build > "$OUT/phases_build.log" 2>&1 && bash tools/fk_phases.sh 8000000 > "$OUT/phases_config1_fast.txt" 2>&1
 rm -rf "$ROOT"/pandaseq_amd/libpandaseq_amd_fkstop*
 for f in "$OUT"/bench_*.json; do python3 -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1].split('/')[-1], round(d['value']/1e6,1), 'M pairs/s', round(d['roofline']['frac'],4))" $f; done
