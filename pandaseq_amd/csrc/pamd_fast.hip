@@ -938,10 +938,16 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 
 // ROUNDS: rounds of 64 bases a read can span (rows of at most 64 * ROUNDS bases)
 // PHRED: a min_phred module is loaded, the merge tracks the row's smallest log-p (plugin_min_phred.c:8-22)
+#ifdef FK_NO_W4	/* A/B builds only */
+#define FK_WAVES_ATTR
+#else
+#define FK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 // (one 16-wave workgroup fills a CU's LDS: four waves per SIMD whatever the registers allow, so the compiler is told to
-// spend all 128 vector registers on scheduling instead of saving them for waves that cannot come -- 1 % on config 1)
+// spend all 128 vector registers on scheduling instead of saving them for waves that cannot come -- 1 % on a 16 M-pair
+// launch, nothing measurable at 50 M)
 template <int ALGO, int ROUNDS, bool EXACT, bool PHRED>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void pamd_fast_kernel(const PamdKernelParams P) {
+__global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const PamdKernelParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	double *ltab = reinterpret_cast<double *>(lds);
 	unsigned *lctr = reinterpret_cast<unsigned *>(lds + P.lds_ctr_off);
