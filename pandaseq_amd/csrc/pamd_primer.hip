@@ -11,6 +11,7 @@
 // One wave per pair: both rows are loaded with one 16-byte load per lane, staged in LDS as the u16-per-base rows they are,
 // and the rows of the wave's next pair are in flight while this one is scanned.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -402,14 +403,16 @@ int pamd_launch_primers(const PamdKernelParams &p, int cu_count, void *stream) {
 	if (p.n_pairs == 0)
 		return PAMD_OK;
 	// every wave walks its share of the batch: exactly as many workgroups as are resident at once
-	static int per_cu[2] = { 0, 0 };
+	static std::atomic<int> per_cu[2];	// (assemblers launch from their own threads: the cached answer is the same for all)
 	const int which = p.primer_penalty != 0.0 ? 0 : 1;
-	if (per_cu[which] == 0) {
+	int resident = per_cu[which].load(std::memory_order_relaxed);
+	if (resident == 0) {
 		int nb = 0;
 		const hipError_t oe = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pamd_primer_kernel<true>, PK_WAVES * 64, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pamd_primer_kernel<false>, PK_WAVES * 64, 0);
-		per_cu[which] = (oe == hipSuccess && nb > 0) ? nb : 4;
+		resident = (oe == hipSuccess && nb > 0) ? nb : 4;
+		per_cu[which].store(resident, std::memory_order_relaxed);
 	}
-	size_t blocks = (size_t) (cu_count > 0 ? cu_count : 256) * (size_t) per_cu[which];
+	size_t blocks = (size_t) (cu_count > 0 ? cu_count : 256) * (size_t) resident;
 	const size_t want = (p.n_pairs + PK_WAVES - 1) / PK_WAVES;
 	if (blocks > want)
 		blocks = want;
