@@ -503,34 +503,51 @@ __device__ __forceinline__ double score_overlap(const PamdKernelParams &P, const
 	}
 }
 
-// ---- pear / rdp_mle with many candidates: one candidate per lane ---------------------------------
-// Each lane walks ITS candidate's overlap in index order and adds the terms as the reference does
-// (algo_pear.c:42-56, algo_rdp_mle.c:55-72), so 64 ordered sums advance together instead of one.
-template <int ALGO>
-__device__ __forceinline__ double score_overlap_serial(const PamdKernelParams &P, const double *ltab, const WaveLds &L, int flen, int rlen, int ov, double neg_random_base, double qual_nn) {
-	double acc = 0.0;
-	for (int i = 0; i < ov; i++) {
-		const int fi = flen + i - ov;
-		const int ri = rlen - i - 1;
-		if (fi >= 0 && ri >= 0) {
-			const unsigned ef = L.F[fi];
-			const unsigned er = L.R[ri];
-			const unsigned a = ef & 0xFFu, b = er & 0xFFu;
-			const int qa = clampq(qual_of(ef));
-			if (ALGO == PAMD_ALGO_PEAR) {
-				if (a == NT_N || b == NT_N) {
-					acc += neg_random_base;
-				} else {
-					const int qb = ri < flen ? clampq(qual_of(L.F[ri])) : 0;	// sic: forward quality at rindex
-					acc += ltab[((a & b) != 0 ? PAMD_LT_A : PAMD_LT_B) + qa * PAMD_NQ + qb];
-				}
-			} else {
-				const int qb = clampq(qual_of(er));
-				acc += ltab[((a & b) != 0 ? PAMD_LT_A : PAMD_LT_B) + qa * PAMD_NQ + qb] - qual_nn;
-			}
+// ---- pear / rdp_mle with many candidates: a short and a long candidate per lane -------------------------------
+// A pair without a seeded overlap has every overlap as a candidate (assembler.c:111-117): some thirty thousand table
+// lookups, each candidate an ordered f64 chain (algo_pear.c:42-56, algo_rdp_mle.c:55-72).  Every lane walks its own
+// candidates' overlaps in index order and adds the terms as the reference does -- first candidate `ova`, then candidate `ovb`
+// (0 = none) -- and the candidates are dealt so that the lanes finish together: of 128 candidates in ascending order lane l
+// gets numbers l and 127 - l, a short overlap with a long one.  The walk reads a digest of the reads made once per pair
+// (clamped qualities, the forward quality already times 47): `sf[i]` = nt | 47 q << 8 | q << 20 of forward base i, `sr[i]` =
+// nt | q << 8 of reverse base i.  INSIDE: no candidate is longer than either read (always, unless a maximum overlap is
+// configured), so no position falls outside a read.
+template <int ALGO, bool INSIDE>
+__device__ __forceinline__ void score_two_overlaps_serial(const double *ltab, const uint32_t *sf, const uint16_t *sr, int flen, int rlen, int ova, int ovb, double neg_random_base, double qual_nn, double &pra, double &prb) {
+	double acc = 0.0, first = 0.0;
+	int fi = flen - ova, ri = rlen - 1;
+	int rem = ova;
+	bool second = false;
+	const int steps = ova + ovb;
+	for (int t = 0; t < steps; t++) {
+		const bool ok = INSIDE || (fi >= 0 && ri >= 0);
+		const unsigned wf = sf[INSIDE || ok ? fi : 0];
+		const unsigned wr = sr[INSIDE || ok ? ri : 0];
+		const unsigned a = wf & 0xFFu, b = wr & 0xFFu;
+		const unsigned base = (a & b) != 0 ? PAMD_LT_A : PAMD_LT_B;
+		double term;
+		if (ALGO == PAMD_ALGO_PEAR) {
+			const unsigned qb = ((INSIDE || ok) && ri < flen) ? sf[ri] >> 20 : 0u;	// sic: the forward quality at rindex (0 past the read)
+			const double v = ltab[base + ((wf >> 8) & 0xFFFu) + qb];
+			term = (a == NT_N || b == NT_N) ? neg_random_base : v;
+		} else {
+			term = ltab[base + ((wf >> 8) & 0xFFFu) + (wr >> 8)] - qual_nn;
+		}
+		acc += (INSIDE || ok) ? term : 0.0;	// (a position outside a read adds 0.0: no sum here is -0.0)
+		fi++;
+		ri--;
+		rem--;
+		if (rem == 0 && !second) {	// on to this lane's second candidate
+			first = acc;
+			acc = 0.0;
+			second = true;
+			rem = ovb;
+			fi = flen - ovb;
+			ri = rlen - 1;
 		}
 	}
-	return acc;
+	pra = second ? first : acc;
+	prb = second ? acc : 0.0;
 }
 
 struct WaveArena {
@@ -1047,7 +1064,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			}
 		} else if (!counting_algo<ALGO>() && ncand > 4) {
 			// Many candidates: list them in ascending order (u16 overlaps in the staging area), then
-			// 64 at a time, one per lane, each lane summing its own candidate in reference order.
+			// 128 at a time, two per lane, each lane summing its own candidates in reference order.
 			uint16_t *cand = reinterpret_cast<uint16_t *>(L.ps);
 			int total = 0;
 			u64 words = ballot(mybits != 0);
@@ -1059,17 +1076,37 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 					cand[total + __popc(m & ((1u << lane) - 1u))] = (uint16_t) (w * 32 + lane + minov);
 				total += __popc(m);
 			}
+			// the reads' digest for the walk, behind the list (score_two_overlaps_serial)
+			uint32_t *const sf = reinterpret_cast<uint32_t *>(cand + ((total + 1) & ~1));
+			uint16_t *const sr = reinterpret_cast<uint16_t *>(sf + flen);
+			for (int i = lane; i < flen; i += 64) {
+				const unsigned e = L.F[i];
+				const unsigned q = (unsigned) clampq(qual_of(e));
+				sf[i] = (e & 0xFFu) | ((q * PAMD_NQ) << 8) | (q << 20);
+			}
+			for (int i = lane; i < rlen; i += 64) {
+				const unsigned e = L.R[i];
+				sr[i] = (uint16_t) ((e & 0xFFu) | ((unsigned) clampq(qual_of(e)) << 8));
+			}
 			wave_sync();
 			double nrb = -P.pear_random_base, nn = P.qual_nn;
 			asm volatile("" : "+v"(nrb), "+v"(nn));	// register copies: keep the table reads pure LDS loads
-			for (int c0 = 0; c0 < total; c0 += 64) {
-				const bool have = c0 + lane < total;
-				const int ov = have ? (int) cand[c0 + lane] : 0;
-				double pr = score_overlap_serial<ALGO>(P, ltab, L, flen, rlen, ov, nrb, nn);
-				// first maximum of this batch: larger score wins, equal scores -> smaller overlap
-				int bov = have ? ov : 0x7FFFFFFF;
-				if (!have)
-					pr = -__builtin_inf();
+			const bool inside = (int) cand[total - 1] <= (flen < rlen ? flen : rlen);	// the longest candidate
+			for (int c0 = 0; c0 < total; c0 += 128) {
+				const int ja = c0 + lane, jb = c0 + 127 - lane;
+				const int ova = ja < total ? (int) cand[ja] : 0, ovb = jb < total ? (int) cand[jb] : 0;
+				double pra, prb;
+				if (inside)
+					score_two_overlaps_serial<ALGO, true>(ltab, sf, sr, flen, rlen, ova, ovb, nrb, nn, pra, prb);
+				else
+					score_two_overlaps_serial<ALGO, false>(ltab, sf, sr, flen, rlen, ova, ovb, nrb, nn, pra, prb);
+				// first maximum of these 128: larger score wins, equal scores -> smaller overlap
+				double pr = ova != 0 ? pra : -__builtin_inf();
+				int bov = ova != 0 ? ova : 0x7FFFFFFF;
+				if (ovb != 0 && prb > pr) {	// (its own second candidate is the longer one)
+					pr = prb;
+					bov = ovb;
+				}
 				for (int o = 32; o > 0; o >>= 1) {
 					const double opr = __shfl_xor(pr, o);
 					const int oov = __shfl_xor(bov, o);
@@ -1080,7 +1117,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				}
 				pr = uni_f64(pr);
 				bov = uni(bov);
-				if (pr > best) {	// batches are in ascending overlap order, strict > keeps the earlier one
+				if (pr > best) {	// groups are in ascending overlap order, strict > keeps the earlier one
 					best = pr;
 					bo = bov;
 				}
