@@ -69,7 +69,9 @@ struct pamd_assembler {
 	size_t primer_cap = 0;	// ... and how many pairs it has room for
 	uint32_t *d_defer = nullptr;	// the pairs it leaves to the general kernel ...
 	size_t defer_cap = 0;
-	unsigned *d_defer_count = nullptr;	// ... and how many
+	unsigned *d_defer_count = nullptr;	// ... and how many; the word behind it: how many of them the general kernel's waves have taken
+	uint32_t *d_wave_pids = nullptr;	// general kernel over the list: the pairs behind each wave's parked records ...
+	size_t wave_pids_cap = 0;	// ... for this many waves
 	bool last_two_kernels = false;
 	double *d_notp = nullptr;
 	std::vector<double> h_image;	// host copy of the table image on the device (pamd_table_image)
@@ -172,7 +174,7 @@ pamd_assembler *pamd_assembler_create(int device) {
 	a->pear_random_base = std::log(0.25);	// algo_pear.c:106
 	a->threshold = std::log(0.6);	// assembler_support.c:76
 	memset(a->primers, 0, sizeof a->primers);
-	if (hipMalloc(&a->d_tables, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_notp, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_primers, sizeof a->primers) != hipSuccess || hipMalloc(&a->d_slots, PAMD_ENCODE_SLOTS * sizeof(uint16_t)) != hipSuccess || hipMalloc(&a->d_error, sizeof(unsigned long long)) != hipSuccess || hipMalloc(&a->d_defer_count, sizeof(unsigned)) != hipSuccess || hipMemset(a->d_defer_count, 0, sizeof(unsigned)) != hipSuccess || hipMalloc(&a->d_phase, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_phase, 0, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_error, 0, sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&a->ev_start) != hipSuccess || hipEventCreate(&a->ev_stop) != hipSuccess) {
+	if (hipMalloc(&a->d_tables, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_notp, sizeof(double) * (PAMD_LT_C + PAMD_TAB)) != hipSuccess || hipMalloc(&a->d_primers, sizeof a->primers) != hipSuccess || hipMalloc(&a->d_slots, PAMD_ENCODE_SLOTS * sizeof(uint16_t)) != hipSuccess || hipMalloc(&a->d_error, sizeof(unsigned long long)) != hipSuccess || hipMalloc(&a->d_defer_count, 2 * sizeof(unsigned)) != hipSuccess || hipMemset(a->d_defer_count, 0, 2 * sizeof(unsigned)) != hipSuccess || hipMalloc(&a->d_phase, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_phase, 0, 10 * sizeof(unsigned long long)) != hipSuccess || hipMemset(a->d_error, 0, sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&a->ev_start) != hipSuccess || hipEventCreate(&a->ev_stop) != hipSuccess) {
 		pamd_set_error("device allocation failed on device %d", device);
 		pamd_assembler_destroy(a);
 		return nullptr;
@@ -204,6 +206,8 @@ void pamd_assembler_destroy(pamd_assembler *a) {
 		(void) hipFree(a->d_primer_off);
 	if (a->d_defer_count)
 		(void) hipFree(a->d_defer_count);
+	if (a->d_wave_pids)
+		(void) hipFree(a->d_wave_pids);
 	for (void *q : a->hb_ptr)
 		if (q)
 			(void) hipFree(q);
@@ -639,7 +643,15 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 			return rc;
 	}
 	if (two) {
-		HIP_TRY(hipMemsetAsync(a->d_defer_count, 0, sizeof(unsigned), st));
+		HIP_TRY(hipMemsetAsync(a->d_defer_count, 0, 2 * sizeof(unsigned), st));
+		if ((size_t) wgs * (size_t) waves > a->wave_pids_cap) {
+			if (a->d_wave_pids)
+				HIP_TRY(hipFree(a->d_wave_pids));
+			a->d_wave_pids = nullptr;
+			a->wave_pids_cap = 0;
+			HIP_TRY(hipMalloc(&a->d_wave_pids, (size_t) wgs * (size_t) waves * 64u * sizeof(uint32_t)));
+			a->wave_pids_cap = (size_t) wgs * (size_t) waves;
+		}
 		PamdKernelParams pf = p;
 		pf.defer_list = a->d_defer;
 		pf.defer_count = a->d_defer_count;
@@ -660,6 +672,8 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 		a->last_lds = (int) pamd_fast_lds_bytes(pf, fwaves);
 		p.pair_list = a->d_defer;
 		p.pair_count = a->d_defer_count;
+		p.pair_cursor = a->d_defer_count + 1;
+		p.wave_pids = a->d_wave_pids;
 		p.arena_chunk = b->n_pairs >= 262144 ? 4096 : 1024;
 	}
 	a->last_two_kernels = two;

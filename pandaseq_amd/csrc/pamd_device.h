@@ -200,14 +200,16 @@ __device__ __forceinline__ double ordered_row_sum(const double *row, int lo, int
 // the three chains of its own pair's row (which this wave wrote; dg_fo carries the number of forward-only bases in its
 // upper half instead of a forward offset, which the lean kernel does not have).
 template <bool LIST, bool DEFER, bool EXACTQ = false>
-__device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64 &pd, int npend, u64 first_pair, u64 pair_step, int lane) {
+__device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64 &pd, int npend, u64 first_pair, u64 pair_step, int lane, const uint32_t *list = nullptr) {
 	int status = -1, reject = -1;
 	bool slow = false;
 	if (EXACTQ)
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// this wave's row stores have reached L2
 	u64 pair = first_pair + (u64) lane * pair_step;
 	if (LIST && lane < npend)
-		pair = P.pair_list[pair];
+		pair = list != nullptr ? __hip_atomic_load(list + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)	// the wave's own record of what it
+												// took from the queue, rewritten every 64 pairs: read past the L1
+				       : P.pair_list[pair];
 	bool deferred = false;
 	if (DEFER) {
 		deferred = lane < npend && ((pd.ro_st >> 16) & 0xFFu) == (unsigned) PAMD_ST_DEFER;

@@ -1558,7 +1558,17 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	// pairs the lean kernel deferred (P.pair_list, *P.pair_count of them); `pid` is the pair index itself.
 	const uint32_t *const plist = P.pair_list;
 	const u64 n_work = plist != nullptr ? (u64) *P.pair_count : P.n_pairs;
-	u64 pair = (u64) blockIdx.x * (u64) nwaves + (u64) wave;
+	// (a list is handed out pair by pair from a device counter -- what the lean kernel leaves behind is mostly pairs that
+	// scan every overlap, a hundred times the cost of the rest, and a fixed share per wave would leave the launch waiting
+	// for its unluckiest wave: 46 % over the mean with 58 pairs per wave)
+	const bool queued = plist != nullptr && P.pair_cursor != nullptr;
+	auto take = [&]() -> u64 {
+		unsigned got = 0;
+		if (lane == 0)
+			got = atomicAdd(P.pair_cursor, 1u);
+		return (u64) (unsigned) uni((int) got);
+	};
+	u64 pair = queued ? take() : (u64) blockIdx.x * (u64) nwaves + (u64) wave;
 	const u64 last = n_work != 0 ? n_work - 1 : 0;	// an empty list: the prologue reads pair 0 and the loop does not run
 	u64 q = pair < n_work ? pair : last;
 	u64 pid = (plist != nullptr && n_work != 0) ? (u64) plist[q] : q;
@@ -1576,9 +1586,11 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	Pend64 pd = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
 	u64 group_first = pair;	// fast sums: the pair parked in lane 0 of the pending registers
 	while (pair < n_work) {
-		const u64 next = pair + total_waves;
+		const u64 next = queued ? take() : pair + total_waves;
 		q = next < n_work ? next : last;
 		const u64 npid = plist != nullptr ? (u64) plist[q] : q;
+		if (!EXACT && queued && lane == 0)	// (exact sums park the pair's index with its record)
+			P.wave_pids[(u64) wave_gid * 64u + (u64) npend] = (uint32_t) pid;
 		Carry nxt;
 		nxt.flen_v = P.flen[npid];
 		nxt.rlen_v = P.rlen[npid];
@@ -1594,7 +1606,9 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		pid = npid;
 		npend++;
 		if (!EXACT && npend == 64) {
-			if (plist != nullptr)
+			if (queued)
+				finish64<true, false>(P, lctr, pd, npend, (u64) wave_gid * 64u, 1, lane, P.wave_pids);
+			else if (plist != nullptr)
 				finish64<true, false>(P, lctr, pd, npend, group_first, total_waves, lane);
 			else
 				finish64<false, false>(P, lctr, pd, npend, group_first, total_waves, lane);
@@ -1616,7 +1630,9 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	if (EXACT && npend > 0)
 		finish_group<ALGO>(P, ltab, lctr, pend, npend, wave_gid, lane);
 	if (!EXACT && npend > 0) {
-		if (plist != nullptr)
+		if (queued)
+			finish64<true, false>(P, lctr, pd, npend, (u64) wave_gid * 64u, 1, lane, P.wave_pids);
+		else if (plist != nullptr)
 			finish64<true, false>(P, lctr, pd, npend, group_first, total_waves, lane);
 		else
 			finish64<false, false>(P, lctr, pd, npend, group_first, total_waves, lane);
