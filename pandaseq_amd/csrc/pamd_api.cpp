@@ -636,22 +636,26 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 		a->primer_cap = b->n_pairs;
 	}
 	p.primer_offsets = primers_first ? a->d_primer_off : nullptr;
+	// the general kernel's work queue (a counter) and its waves' records of what they took
+	if ((size_t) wgs * (size_t) waves > a->wave_pids_cap) {
+		if (a->d_wave_pids)
+			HIP_TRY(hipFree(a->d_wave_pids));
+		a->d_wave_pids = nullptr;
+		a->wave_pids_cap = 0;
+		HIP_TRY(hipMalloc(&a->d_wave_pids, (size_t) wgs * (size_t) waves * 64u * sizeof(uint32_t)));
+		a->wave_pids_cap = (size_t) wgs * (size_t) waves;
+	}
+	p.pair_cursor = b->n_pairs <= 0xFFFFFFF0ull ? a->d_defer_count + 1 : nullptr;	// (32-bit counter; beyond it fixed shares)
+	p.wave_pids = a->d_wave_pids;
 	HIP_TRY(hipEventRecord(a->ev_start, st));
+	HIP_TRY(hipMemsetAsync(a->d_defer_count, 0, 2 * sizeof(unsigned), st));
 	if (primers_first) {
 		rc = pamd_launch_primers(p, a->cu_count, stream);
 		if (rc != PAMD_OK)
 			return rc;
 	}
 	if (two) {
-		HIP_TRY(hipMemsetAsync(a->d_defer_count, 0, 2 * sizeof(unsigned), st));
-		if ((size_t) wgs * (size_t) waves > a->wave_pids_cap) {
-			if (a->d_wave_pids)
-				HIP_TRY(hipFree(a->d_wave_pids));
-			a->d_wave_pids = nullptr;
-			a->wave_pids_cap = 0;
-			HIP_TRY(hipMalloc(&a->d_wave_pids, (size_t) wgs * (size_t) waves * 64u * sizeof(uint32_t)));
-			a->wave_pids_cap = (size_t) wgs * (size_t) waves;
-		}
+
 		PamdKernelParams pf = p;
 		pf.defer_list = a->d_defer;
 		pf.defer_count = a->d_defer_count;
@@ -672,8 +676,6 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 		a->last_lds = (int) pamd_fast_lds_bytes(pf, fwaves);
 		p.pair_list = a->d_defer;
 		p.pair_count = a->d_defer_count;
-		p.pair_cursor = a->d_defer_count + 1;
-		p.wave_pids = a->d_wave_pids;
 		p.arena_chunk = b->n_pairs >= 262144 ? 4096 : 1024;
 	}
 	a->last_two_kernels = two;

@@ -1558,15 +1558,24 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 	// pairs the lean kernel deferred (P.pair_list, *P.pair_count of them); `pid` is the pair index itself.
 	const uint32_t *const plist = P.pair_list;
 	const u64 n_work = plist != nullptr ? (u64) *P.pair_count : P.n_pairs;
-	// (a list is handed out pair by pair from a device counter -- what the lean kernel leaves behind is mostly pairs that
-	// scan every overlap, a hundred times the cost of the rest, and a fixed share per wave would leave the launch waiting
-	// for its unluckiest wave: 46 % over the mean with 58 pairs per wave)
-	const bool queued = plist != nullptr && P.pair_cursor != nullptr;
+	// Work is handed out from a device counter, not dealt in fixed shares: a pair that scans every overlap costs twenty to a
+	// hundred times an ordinary one, and a fixed share per wave leaves the launch waiting for its unluckiest wave (46 % over
+	// the mean on the lean kernel's list, 58 mostly such pairs per wave; 5 % on a whole 50 M-pair batch).  A list goes out
+	// pair by pair, a whole batch sixteen pairs at a time (one same-address atomic per pair would be the bottleneck).
+	const bool queued = P.pair_cursor != nullptr;
+	const unsigned take_n = plist != nullptr ? 1u : 16u;
+	u64 took = 0;
+	unsigned took_left = 0;
 	auto take = [&]() -> u64 {
-		unsigned got = 0;
-		if (lane == 0)
-			got = atomicAdd(P.pair_cursor, 1u);
-		return (u64) (unsigned) uni((int) got);
+		if (took_left == 0) {
+			unsigned got = 0;
+			if (lane == 0)
+				got = atomicAdd(P.pair_cursor, take_n);
+			took = (u64) (unsigned) uni((int) got);
+			took_left = take_n;
+		}
+		took_left--;
+		return took++;
 	};
 	u64 pair = queued ? take() : (u64) blockIdx.x * (u64) nwaves + (u64) wave;
 	const u64 last = n_work != 0 ? n_work - 1 : 0;	// an empty list: the prologue reads pair 0 and the loop does not run
@@ -1606,7 +1615,7 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		pid = npid;
 		npend++;
 		if (!EXACT && npend == 64) {
-			if (queued)
+			if (queued)	// (the wave's own record says which pair is behind which parked record)
 				finish64<true, false>(P, lctr, pd, npend, (u64) wave_gid * 64u, 1, lane, P.wave_pids);
 			else if (plist != nullptr)
 				finish64<true, false>(P, lctr, pd, npend, group_first, total_waves, lane);
