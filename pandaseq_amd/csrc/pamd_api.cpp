@@ -632,7 +632,7 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 			HIP_TRY(hipFree(a->d_primer_off));
 		a->d_primer_off = nullptr;
 		a->primer_cap = 0;
-		HIP_TRY(hipMalloc(&a->d_primer_off, (2 * b->n_pairs + 4) * sizeof(uint32_t)));	// a word per pair, the list of pairs to redo, its count
+		HIP_TRY(hipMalloc(&a->d_primer_off, (2 * b->n_pairs + 4) * sizeof(uint32_t)));	// a word per pair, the list of pairs to redo, its count, the work counter
 		a->primer_cap = b->n_pairs;
 	}
 	p.primer_offsets = primers_first ? a->d_primer_off : nullptr;

@@ -41,6 +41,7 @@ struct PrimerParams {
 	uint32_t *primer_offsets;
 	uint32_t *redo_list;	// the pairs the fast kernel leaves to the careful one ...
 	unsigned *redo_count;	// ... and how many (device word)
+	unsigned *cursor;	// work counter (device word, zeroed per kernel): the batch goes out sixteen pairs at a time
 	uint64_t n_pairs;
 	uint32_t fwd_row_bytes;
 	uint32_t rev_row_bytes;
@@ -334,8 +335,21 @@ __global__ __launch_bounds__(PK_WAVES * 64) void pamd_primer_kernel(const Primer
 		lprimers[i] = P.primers[i];
 	__syncthreads();
 	const u64 n_work = listed ? (u64) *P.redo_count : P.n_pairs;
-	const u64 step = (u64) gridDim.x * PK_WAVES;
-	u64 at = (u64) blockIdx.x * PK_WAVES + (u64) wave;
+	// (work from a counter, not in fixed shares: a read without its primer costs five times one with it)
+	u64 took = 0;
+	unsigned took_left = 0;
+	auto take = [&]() -> u64 {
+		if (took_left == 0) {
+			unsigned got = 0;
+			if (lane == 0)
+				got = atomicAdd(P.cursor, 16u);
+			took = (u64) (unsigned) uni((int) got);
+			took_left = 16;
+		}
+		took_left--;
+		return took++;
+	};
+	u64 at = take();
 	const uint16_t *F = reinterpret_cast<const uint16_t *>(rows[wave][0]), *R = reinterpret_cast<const uint16_t *>(rows[wave][1]);
 	const bool in_f = (unsigned) lane * 16u < P.fwd_row_bytes, in_r = (unsigned) lane * 16u < P.rev_row_bytes;
 	uint4 fv = make_uint4(0, 0, 0, 0), rv = make_uint4(0, 0, 0, 0);
@@ -357,7 +371,7 @@ __global__ __launch_bounds__(PK_WAVES * 64) void pamd_primer_kernel(const Primer
 			reinterpret_cast<uint4 *>(rows[wave][1])[lane] = rv;
 		const int fl = uni(flen), rl = uni(rlen);
 		const u64 this_pair = pair;
-		at += step;
+		at = take();
 		if (at < n_work) {	// the next pair's rows travel while this one is scanned
 			pair = listed ? (u64) P.redo_list[at] : at;
 			flen = P.flen[pair];
@@ -426,6 +440,7 @@ int pamd_launch_primers(const PamdKernelParams &p, int cu_count, void *stream) {
 	q.primer_offsets = p.primer_offsets;
 	q.redo_list = p.primer_offsets + p.n_pairs;	// the buffer holds 2 n words + the count (pamd_api.cpp)
 	q.redo_count = reinterpret_cast<unsigned *>(p.primer_offsets + 2 * p.n_pairs);
+	q.cursor = q.redo_count + 1;
 	q.n_pairs = p.n_pairs;
 	q.fwd_row_bytes = p.fwd_row_bytes;
 	q.rev_row_bytes = p.rev_row_bytes;
@@ -435,13 +450,21 @@ int pamd_launch_primers(const PamdKernelParams &p, int cu_count, void *stream) {
 	q.primer_penalty = p.primer_penalty;
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	if (p.primer_penalty != 0.0) {
+		if (hipMemsetAsync(q.cursor, 0, sizeof(unsigned), st) != hipSuccess) {
+			pamd_set_error("primer kernel: hipMemsetAsync failed");
+			return PAMD_ENODEVICE;
+		}
 		hipLaunchKernelGGL(pamd_primer_kernel<false>, dim3((unsigned) blocks), dim3(PK_WAVES * 64), 0, st, q, false);
 	} else {
-		if (hipMemsetAsync(q.redo_count, 0, sizeof(unsigned), st) != hipSuccess) {
+		if (hipMemsetAsync(q.redo_count, 0, 2 * sizeof(unsigned), st) != hipSuccess) {
 			pamd_set_error("primer kernel: hipMemsetAsync failed");
 			return PAMD_ENODEVICE;
 		}
 		hipLaunchKernelGGL(pamd_primer_kernel<true>, dim3((unsigned) blocks), dim3(PK_WAVES * 64), 0, st, q, false);
+		if (hipMemsetAsync(q.cursor, 0, sizeof(unsigned), st) != hipSuccess) {
+			pamd_set_error("primer kernel: hipMemsetAsync failed");
+			return PAMD_ENODEVICE;
+		}
 		hipLaunchKernelGGL(pamd_primer_kernel<false>, dim3(8), dim3(PK_WAVES * 64), 0, st, q, true);	// next to nothing to do
 	}
 #ifdef PK_DEBUG
