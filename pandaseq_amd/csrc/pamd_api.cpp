@@ -645,7 +645,7 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 		HIP_TRY(hipMalloc(&a->d_wave_pids, (size_t) wgs * (size_t) waves * 64u * sizeof(uint32_t)));
 		a->wave_pids_cap = (size_t) wgs * (size_t) waves;
 	}
-	p.pair_cursor = b->n_pairs <= 0xFFFFFFF0ull ? a->d_defer_count + 1 : nullptr;	// (32-bit counter; beyond it fixed shares)
+	p.pair_cursor = b->n_pairs <= 0xFF000000ull ? a->d_defer_count + 1 : nullptr;	// (a 32-bit counter that every wave overshoots by up to sixteen; beyond it fixed shares)
 	p.wave_pids = a->d_wave_pids;
 	HIP_TRY(hipEventRecord(a->ev_start, st));
 	HIP_TRY(hipMemsetAsync(a->d_defer_count, 0, 2 * sizeof(unsigned), st));

@@ -416,6 +416,10 @@ __global__ __launch_bounds__(PK_WAVES * 64) void pamd_primer_kernel(const Primer
 int pamd_launch_primers(const PamdKernelParams &p, int cu_count, void *stream) {
 	if (p.n_pairs == 0)
 		return PAMD_OK;
+	if (p.n_pairs > 0xFF000000ull) {	// (the work counter is 32 bits wide)
+		pamd_set_error("primer kernel: more than 2^32 - 2^24 pairs in one launch");
+		return PAMD_EINVAL;
+	}
 	// every wave walks its share of the batch: exactly as many workgroups as are resident at once
 	static std::atomic<int> per_cu[2];	// (assemblers launch from their own threads: the cached answer is the same for all)
 	const int which = p.primer_penalty != 0.0 ? 0 : 1;
