@@ -517,6 +517,27 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.sb_pmismatch = a->algo == PAMD_ALGO_UPARSE ? a->up_pmismatch : a->sb_pmismatch;
 	p.pear_random_base = a->pear_random_base;
 	p.exact_sums = a->exact_sums;
+	if (a->algo == PAMD_ALGO_PEAR || a->algo == PAMD_ALGO_RDP_MLE) {
+		// upper bounds of one term of an overlap's score (PamdKernelParams::many_*): algo_pear.c:47-55 adds -random_base
+		// for an N and a table entry otherwise, algo_rdp_mle.c:60-70 a table entry minus qual_nn
+		const bool pear = a->algo == PAMD_ALGO_PEAR;
+		const double *tm = pear ? a->tabs.match_pear : a->tabs.match_sb, *tx = pear ? a->tabs.mismatch_pear : a->tabs.mismatch_rdp;
+		const double off = pear ? 0.0 : a->tabs.qual_nn;
+		double mm = -INFINITY, mx = -INFINITY, ms = -INFINITY;
+		for (int qa = 0; qa < PAMD_NQ; qa++)
+			for (int qb = 0; qb < PAMD_NQ; qb++) {
+				const double vm = tm[qa * PAMD_NQ + qb] - off, vx = tx[qa * PAMD_NQ + qb] - off;
+				mm = vm > mm ? vm : mm;
+				mx = vx > mx ? vx : mx;
+				if (qa >= PAMD_STRONG_Q && qb >= PAMD_STRONG_Q)
+					ms = vx > ms ? vx : ms;
+			}
+		p.many_match = mm;
+		p.many_strong = ms;
+		p.many_all = mm > mx ? mm : mx;
+		if (pear && -a->pear_random_base > p.many_all)
+			p.many_all = -a->pear_random_base;
+	}
 	memcpy(p.modules, a->modules, sizeof p.modules);
 	for (int m = 0; m < a->n_modules; m++)
 		if (a->modules[m].kind == 1)

@@ -1088,13 +1088,74 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const unsigned e = L.R[i];
 				sr[i] = (uint16_t) ((e & 0xFFu) | ((unsigned) clampq(qual_of(e)) << 8));
 			}
+			// Copies of the special-base maps in which a base of low quality counts as an N (behind the digest, a word of
+			// slack either side as code_word_counts reads): what they call "unknown" is then a position whose term is bounded
+			// by many_all only, a match among the rest by many_match, a mismatch among the rest by many_strong.  The quality
+			// that counts is the one the term is looked up with: the reverse base's for rdp_mle, the FORWARD read's at the
+			// reverse index for pear (algo_pear.c:52,54; 0 past the read).
+			uint32_t *const fnw = reinterpret_cast<uint32_t *>(sr + ((rlen + 1) & ~1)) + 1;
+			uint32_t *const rnw = fnw + 34;
+			wave_sync();	// (the digest is read below)
+			{
+				const int w = lane & 31;
+				const bool fwd = lane < 32;
+				unsigned v = fwd ? L.fn[w] : L.rn[w];
+#pragma unroll
+				for (int k = 0; k < 16; k++) {
+					const int at = 16 * w + k;
+					unsigned q = 0;	// (past the read: nothing there counts anyway)
+					if (fwd || ALGO == PAMD_ALGO_PEAR)
+						q = at < flen ? sf[at] >> 20 : 0u;
+					else
+						q = at < rlen ? (unsigned) sr[at] >> 8 : 0u;
+					if (q < (unsigned) PAMD_STRONG_Q)
+						v |= 3u << (2 * k);
+				}
+				(fwd ? fnw : rnw)[w] = v;
+				if (w == 0) {
+					(fwd ? fnw : rnw)[-1] = 0xFFFFFFFFu;
+					(fwd ? fnw : rnw)[32] = 0xFFFFFFFFu;
+				}
+			}
+			WaveLds LW = L;
+			LW.fn = fnw;
+			LW.rn = rnw;
 			wave_sync();
 			double nrb = -P.pear_random_base, nn = P.qual_nn;
 			asm volatile("" : "+v"(nrb), "+v"(nn));	// register copies: keep the table reads pure LDS loads
 			const bool inside = (int) cand[total - 1] <= (flen < rlen ? flen : rlen);	// the longest candidate
+			const double nothing_yet = best;
+			// an upper bound of candidate ov's score from three counts (16 positions per step, whole-word arithmetic)
+			auto bound_of = [&](int ov) -> double {
+				int lo_i = ov - flen;
+				lo_i = lo_i < 0 ? 0 : lo_i;
+				const int hi_i = ov < rlen ? ov : rlen;
+				unsigned packed = 0;
+				bool any_odd = false;
+				for (int i0 = lo_i & ~15; i0 < hi_i; i0 += 16) {
+					bool o;
+					packed += code_word_counts(LW, flen, rlen, ov, i0, true, o);
+					any_odd |= o;
+				}
+				const int unknowns = (int) (packed & 1023u), matches = (int) (packed >> 10);
+				const int walked = hi_i > lo_i ? hi_i - lo_i : 0;
+				const double b = (double) unknowns * P.many_all + (double) matches * P.many_match + (double) (walked - unknowns - matches) * P.many_strong;
+				return any_odd ? __builtin_inf() : b;	// (an ambiguity code: the codes say nothing about agreement)
+			};
 			for (int c0 = 0; c0 < total; c0 += 128) {
 				const int ja = c0 + lane, jb = c0 + 127 - lane;
-				const int ova = ja < total ? (int) cand[ja] : 0, ovb = jb < total ? (int) cand[jb] : 0;
+				int ova = ja < total ? (int) cand[ja] : 0, ovb = jb < total ? (int) cand[jb] : 0;
+				if (best != nothing_yet) {
+					// something has been found: a candidate whose bound is clearly below it cannot win, nor tie
+					if (ovb != 0 && bound_of(ovb) < best - 1e-6)
+						ovb = 0;
+					if (ova != 0 && bound_of(ova) < best - 1e-6) {
+						ova = ovb;
+						ovb = 0;
+					}
+				}
+				if (ballot(ova != 0) == 0)
+					continue;
 				double pra, prb;
 				if (inside)
 					score_two_overlaps_serial<ALGO, true>(ltab, sf, sr, flen, rlen, ova, ovb, nrb, nn, pra, prb);

@@ -554,3 +554,42 @@ def test_primer_kernel_on_planted_primers(built, plen, penalty):
     ok = o[0]["status"] == 0
     if penalty == 0.0 and plen >= 8:
         assert len(np.unique(o[0]["fwd_offset"][ok])) > 8 and len(np.unique(o[0]["rev_offset"][ok])) > 8, "the case must spread its primers over the reads"
+
+
+@pytest.mark.parametrize("algo", ["pear", "rdp_mle"])
+def test_pairs_that_scan_every_overlap(built, algo, sums):
+    """pear / rdp_mle pairs without a seeded overlap: every overlap is a candidate (assembler.c:111-117).  The kernel bounds
+    most of them from above by counts and walks the rest; the winner, its score, `examined` and `slow` must be the
+    reference's -- on unrelated reads of every quality mix, with Ns, ambiguity codes, repeats and ragged lengths."""
+    import pandaseq_amd as pa
+    rng = np.random.default_rng(77)
+    n, stride = 900, 256
+    fwd = np.zeros((n, stride, 2), np.uint8)
+    rev = np.zeros((n, stride, 2), np.uint8)
+    flen = rng.integers(20, 251, n).astype(np.uint16)
+    rlen = rng.integers(20, 251, n).astype(np.uint16)
+    for i in range(n):
+        kind = i % 6
+        for row, ln in ((fwd, flen[i]), (rev, rlen[i])):
+            row[i, :ln, 0] = rng.choice(np.array([1, 2, 4, 8], np.uint8), ln)
+            if kind == 0:       # good qualities throughout
+                row[i, :ln, 1] = rng.integers(30, 42, ln)
+            elif kind == 1:     # poor qualities throughout
+                row[i, :ln, 1] = rng.integers(0, 15, ln)
+            else:               # anything
+                row[i, :ln, 1] = rng.integers(0, 47, ln)
+            if kind == 3:       # Ns and ambiguity codes
+                at = rng.integers(0, ln, max(1, ln // 12))
+                row[i, at, 0] = rng.choice(np.array([15, 3, 5, 6, 9, 10, 12, 7, 14], np.uint8), len(at))
+        if kind == 4:           # a two-base repeat in both reads: many good overlaps, ties
+            fwd[i, :flen[i], 0] = np.tile(np.array([1, 4], np.uint8), 126)[:flen[i]]
+            rev[i, :rlen[i], 0] = np.tile(np.array([4, 1], np.uint8), 126)[:rlen[i]]
+        if kind == 5:           # the same quality everywhere: equal scores wherever the counts are equal
+            fwd[i, :flen[i], 1] = 30
+            rev[i, :rlen[i], 1] = 30
+    asm = _asm_for(algo, exact=sums == "exact")
+    b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
+    o = _oracle(algo, fwd, rev, flen, rlen)
+    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+    compare_counters(b.counters_dict(), o[3])
+    assert (o[0]["slow"] != 0).sum() > n // 3, "the case must hold pairs that scan every overlap"
