@@ -1064,7 +1064,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 			}
 		} else if (!counting_algo<ALGO>() && ncand > 4) {
 			// Many candidates: list them in ascending order (u16 overlaps in the staging area), then
-			// 128 at a time, two per lane, each lane summing its own candidates in reference order.
+			// up to 128 at a time, two per lane, each lane summing its own candidates in reference order.
 			uint16_t *cand = reinterpret_cast<uint16_t *>(L.ps);
 			int total = 0;
 			u64 words = ballot(mybits != 0);
@@ -1142,9 +1142,12 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 				const double b = (double) unknowns * P.many_all + (double) matches * P.many_match + (double) (walked - unknowns - matches) * P.many_strong;
 				return any_odd ? __builtin_inf() : b;	// (an ambiguity code: the codes say nothing about agreement)
 			};
-			for (int c0 = 0; c0 < total; c0 += 128) {
-				const int ja = c0 + lane, jb = c0 + 127 - lane;
-				int ova = ja < total ? (int) cand[ja] : 0, ovb = jb < total ? (int) cand[jb] : 0;
+			// (the sixteen shortest candidates first, by themselves: they cost next to nothing, and what they find is what
+			// the bounds of all the others are held against)
+			for (int c0 = 0, group = 16; c0 < total; c0 += group, group = 128) {
+				const bool mine = 2 * lane < group;
+				const int ja = c0 + lane, jb = c0 + group - 1 - lane;
+				int ova = (mine && ja < total) ? (int) cand[ja] : 0, ovb = (mine && jb < total) ? (int) cand[jb] : 0;
 				if (best != nothing_yet) {
 					// something has been found: a candidate whose bound is clearly below it cannot win, nor tie
 					if (ovb != 0 && bound_of(ovb) < best - 1e-6)
