@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 #include <atomic>
 #include <cctype>
+#include <emmintrin.h>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -840,8 +841,9 @@ struct pamd_slot {
 
 namespace {
 
-// A read into its pinned staging row.  (Plain memcpy: streaming stores into hipHostMalloc'ed memory were measured six
-// times slower on this platform.)
+// A read into its pinned staging row.  (Plain memcpy: streaming stores, 16 and 32 bytes wide, are faster in isolation --
+// 16 ns against 25 ns per pair on the GPU box, tools/probe/stage_copy_probe.cpp -- and twice as slow in the pipeline, where
+// the rows' odd tails and the other threads' traffic break their write combining: measured twice, 8.3 M pairs/s against 15.)
 void stage_copy(pamd_qual *dst, const panda_qual *src, size_t bases) {
 	memcpy(dst, src, bases * sizeof(panda_qual));
 }
@@ -985,6 +987,7 @@ int slot_run(PandaAssembler a, pamd_slot *s) {
 	if (n < 4096)
 		helpers = 1;
 	std::atomic<int> bad{0};
+	static const bool plain_rows = getenv("PAMD_COMPAT_PLAIN_ROWS") != nullptr;
 	auto expand = [&](size_t lo, size_t hi) {
 		for (size_t k = lo; k < hi; k++) {
 			const pamd_pair_result &d = s->h_res[k];
@@ -998,15 +1001,29 @@ int slot_run(PandaAssembler a, pamd_slot *s) {
 					bad.store(1);
 					continue;
 				}
-				out[j].nt = (panda_nt) nt[j];
-				out[j].p = image[ix[j]];
+				// one 16-byte streaming store per base (nt, padding, p): the rows are written once, 6 KB per pair, and read --
+				// if at all -- much later by another thread; through the caches they would cost a read of every line first
+				// and evict what the caller's thread is working with
+				long long bits;
+				memcpy(&bits, &image[ix[j]], sizeof bits);
+				if (plain_rows) {	// (PAMD_COMPAT_PLAIN_ROWS=1: A/B measurements only)
+					out[j].nt = (panda_nt) nt[j];
+					out[j].p = image[ix[j]];
+				} else {
+					_mm_stream_si128(reinterpret_cast<__m128i *>(out + j), _mm_set_epi64x(bits, (long long) nt[j]));
+				}
 			}
 		}
 	};
+	static_assert(sizeof(panda_result) == 16 && offsetof(panda_result, nt) == 0 && offsetof(panda_result, p) == 8, "panda_result layout (pandaseq-common.h:221-230)");
 	std::vector<std::thread> team;
 	for (unsigned t = 1; t < helpers; t++)
-		team.emplace_back(expand, n * t / helpers, n * (t + 1) / helpers);
+		team.emplace_back([&expand, n, t, helpers] {
+			expand(n * t / helpers, n * (t + 1) / helpers);
+			_mm_sfence();
+		});
 	expand(0, n / helpers);
+	_mm_sfence();
 	for (std::thread &t : team)
 		t.join();
 	if (bad.load()) {
