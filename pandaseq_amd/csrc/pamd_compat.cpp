@@ -823,7 +823,8 @@ struct pamd_slot {
 	// what is remembered of every pair pulled from the source, compactly (the caller's thread streams through all of
 	// it twice, once pulling and once replaying: a 480-byte record per pair was most of what it moved): the identifier's
 	// four numbers and four strings back to back, the read lengths
-	std::vector<char> ids;
+	std::vector<char> ids;	// the batch's packed identifiers ...
+	size_t ids_used = 0;	// ... and how much of the buffer they take
 	std::vector<uint32_t> id_at;
 	std::vector<uint16_t> len_f, len_r;
 	std::vector<int> pre;			// -1 short read, >= 0 rejected by precheck module k, <= -3: device pair -(k+3)
@@ -1050,8 +1051,9 @@ void slot_fill_and_submit(PandaAssembler a, pamd_slot *s) {
 		s->len_f.resize(want);
 		s->len_r.resize(want);
 	}
-	s->ids.clear();
-	s->ids.reserve(want * 40);
+	s->ids_used = 0;
+	if (s->ids.size() < want * 40)
+		s->ids.resize(want * 40);
 	s->stride = 256;
 	panda_result_seq &r = a->result;	// the source fills in the identifier here (cache-hot); it is packed away below
 	while (s->n < want) {
@@ -1092,26 +1094,31 @@ void slot_fill_and_submit(PandaAssembler a, pamd_slot *s) {
 			s->h_rlen[k] = (uint16_t) rl;
 			pre = -(int) k - 3;
 		}
-		{	// pack the identifier: lane, tile, x, y, then the four strings with their terminators
+		{	// pack the identifier: lane, tile, x, y, then the four strings with their terminators (straight into the
+			// buffer: room for the longest identifier is kept ahead of the write position)
 			const panda_seq_identifier &id = r.name;
-			const size_t li = strnlen(id.instrument, sizeof id.instrument - 1), lr = strnlen(id.run, sizeof id.run - 1);
-			const size_t lc = strnlen(id.flowcell, sizeof id.flowcell - 1), lt = strnlen(id.tag, sizeof id.tag - 1);
-			const size_t at = s->ids.size();
-			s->ids.resize(at + 16 + li + lr + lc + lt + 4);
-			char *o = s->ids.data() + at;
+			constexpr size_t LONGEST = 16 + sizeof id.instrument + sizeof id.run + sizeof id.flowcell + sizeof id.tag;
+			const size_t at = s->ids_used;
+			if (s->ids.size() < at + LONGEST)
+				s->ids.resize((at + LONGEST) * 2);
+			char *const base = s->ids.data() + at;
+			char *o = base;
 			memcpy(o, &id.lane, 16);	// lane, tile, x, y are adjacent ints (pandaseq-common.h:248-262)
 			o += 16;
-			memcpy(o, id.instrument, li);
-			o[li] = 0;
-			o += li + 1;
-			memcpy(o, id.run, lr);
-			o[lr] = 0;
-			o += lr + 1;
-			memcpy(o, id.flowcell, lc);
-			o[lc] = 0;
-			o += lc + 1;
-			memcpy(o, id.tag, lt);
-			o[lt] = 0;
+			auto put = [&o](const char *from, size_t room) {	// a string and its terminator (at most room - 1 characters)
+				size_t k = 0;
+				while (k + 1 < room && from[k] != 0) {
+					o[k] = from[k];
+					k++;
+				}
+				o[k] = 0;
+				o += k + 1;
+			};
+			put(id.instrument, sizeof id.instrument);
+			put(id.run, sizeof id.run);
+			put(id.flowcell, sizeof id.flowcell);
+			put(id.tag, sizeof id.tag);
+			s->ids_used = at + (size_t) (o - base);
 			s->id_at[s->n] = (uint32_t) at;
 		}
 		s->len_f[s->n] = (uint16_t) fl;
