@@ -90,11 +90,13 @@ __device__ __forceinline__ double primer_alignment_sum(const double *ltab, const
 // and when it does not -- low_e): the alignments with at least K of their first eight terms below that part, bit s for the
 // alignment that starts at the block's position s.  HASN: one of the primer's first eight bases is N (no term).
 template <int K, bool HASN>
-__device__ __forceinline__ u64 low_terms(const unsigned nt, const unsigned (&pn8)[8], const u64 low_s, const u64 low_e) {
+__device__ __forceinline__ u64 low_terms(const unsigned nt, const unsigned (&pn8)[8], const u64 low_s, const u64 low_e, const u64 valid) {
 	const u64 either = low_s ^ low_e;
 	u64 ge1 = 0, ge2 = 0, ge3 = 0;
 #pragma unroll
 	for (int x = 0; x < 8; x++) {
+		if (x == 4 && (valid & ~(K == 1 ? ge1 : (K == 2 ? ge2 : ge3))) == 0)
+			break;	// four bases were enough: nothing of the block is left (four blocks in five)
 		if (HASN && pn8[x] == NT_N)
 			continue;
 		const u64 low = (low_e ^ (ballot((nt & pn8[x]) != 0) & either)) >> x;
@@ -203,9 +205,9 @@ __device__ __forceinline__ int primer_offset_scan(const double threshold, const 
 			const u64 low_s = ballot(ltab[PAMD_LT_SCORE + q] < part), low_e = ballot(ltab[PAMD_LT_ERR + q] < part);
 			u64 killed;
 			if (!has_n)
-				killed = k == 1 ? low_terms<1, false>(nt, pn8, low_s, low_e) : (k == 2 ? low_terms<2, false>(nt, pn8, low_s, low_e) : low_terms<3, false>(nt, pn8, low_s, low_e));
+				killed = k == 1 ? low_terms<1, false>(nt, pn8, low_s, low_e, valid) : (k == 2 ? low_terms<2, false>(nt, pn8, low_s, low_e, valid) : low_terms<3, false>(nt, pn8, low_s, low_e, valid));
 			else
-				killed = k == 1 ? low_terms<1, true>(nt, pn8, low_s, low_e) : (k == 2 ? low_terms<2, true>(nt, pn8, low_s, low_e) : low_terms<3, true>(nt, pn8, low_s, low_e));
+				killed = k == 1 ? low_terms<1, true>(nt, pn8, low_s, low_e, valid) : (k == 2 ? low_terms<2, true>(nt, pn8, low_s, low_e, valid) : low_terms<3, true>(nt, pn8, low_s, low_e, valid));
 			const u64 alive = valid & ~killed;
 			PK_COUNT(2 + k);
 			if (alive == 0)
