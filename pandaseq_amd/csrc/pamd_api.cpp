@@ -65,6 +65,8 @@ struct pamd_assembler {
 	int exact_sums = 1;
 	int post_primers = 0;
 	int fast_path = 1;		// ordinary pairs go through the lean kernel when the configuration allows (pamd_fast.hip)
+	double *d_count_table = nullptr;	// ea_util / stitch: every value an overlap's score can take (PamdKernelParams::count_table) ...
+	int count_table_algo = -1;	// ... built for this scorer
 	uint32_t *d_primer_off = nullptr;	// `-p` / `-q`: the primer kernel's word per pair ...
 	size_t primer_cap = 0;	// ... and how many pairs it has room for
 	uint32_t *d_defer = nullptr;	// the pairs it leaves to the general kernel ...
@@ -204,6 +206,8 @@ void pamd_assembler_destroy(pamd_assembler *a) {
 		(void) hipFree(a->d_defer);
 	if (a->d_primer_off)
 		(void) hipFree(a->d_primer_off);
+	if (a->d_count_table)
+		(void) hipFree(a->d_count_table);
 	if (a->d_defer_count)
 		(void) hipFree(a->d_defer_count);
 	if (a->d_wave_pids)
@@ -429,6 +433,30 @@ static int upload_tables(pamd_assembler *a, hipStream_t st) {
 		HIP_TRY(hipMemcpy(a->d_slots, slots.data(), slots.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
 		a->d_tables_algo = a->algo;
 	}
+	if ((a->algo == PAMD_ALGO_EA_UTIL || a->algo == PAMD_ALGO_STITCH) && a->count_table_algo != a->algo) {
+		// algo_ea_util.c:55, algo_stitch.c:56 for every argument they can meet, with this host's libm
+		std::vector<double> t;
+		if (a->algo == PAMD_ALGO_EA_UTIL) {
+			t.resize((size_t) PAMD_CT_EA * PAMD_CT_EA);
+			for (size_t real_overlap = 0; real_overlap < PAMD_CT_EA; real_overlap++)
+				for (size_t mismatches = 0; mismatches < PAMD_CT_EA; mismatches++)
+					t[real_overlap * PAMD_CT_EA + mismatches] = log((((double) mismatches) * mismatches + 1) / real_overlap);
+		} else {
+			t.resize((size_t) PAMD_CT_ST * PAMD_CT_ST);
+			for (long long d = -450; d <= 450; d++)
+				for (size_t len = 0; len < PAMD_CT_ST; len++) {
+					const size_t score = (size_t) d;	// matches - mismatches in size_t: wraps when negative
+					t[(size_t) (d + 450) * PAMD_CT_ST + len] = log(score / (double) len);
+				}
+		}
+		if (a->d_count_table)
+			HIP_TRY(hipFree(a->d_count_table));
+		a->d_count_table = nullptr;
+		a->count_table_algo = -1;
+		HIP_TRY(hipMalloc(&a->d_count_table, t.size() * sizeof(double)));
+		HIP_TRY(hipMemcpy(a->d_count_table, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+		a->count_table_algo = a->algo;
+	}
 	if (a->primers_dirty) {
 		HIP_TRY(hipMemcpy(a->d_primers, a->primers, sizeof a->primers, hipMemcpyHostToDevice));
 		a->primers_dirty = false;
@@ -490,6 +518,7 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 		p.debug_pair = strtoull(dp, nullptr, 10);
 	}
 	p.tables = a->d_tables;
+	p.count_table = a->d_count_table;
 	p.notp = a->d_notp;
 	p.post_primers = a->post_primers;
 	p.primers = a->d_primers;

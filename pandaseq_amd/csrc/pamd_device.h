@@ -96,7 +96,7 @@ __device__ __forceinline__ constexpr bool counting_algo() {
 
 // walked = bases present on both reads (the reference's real_overlap)
 template <int ALGO>
-__device__ __forceinline__ double count_score(double qual_nn, double pmatch, double pmismatch, int flen, int rlen, int ov, int unknowns, int matches, int walked) {
+__device__ __forceinline__ double count_score(double qual_nn, double pmatch, double pmismatch, const double *count_table, int flen, int rlen, int ov, int unknowns, int matches, int walked) {
 	const int mismatches = walked - unknowns - matches;
 	if (ALGO == PAMD_ALGO_FLASH) {
 		// log(mismatches / real_overlap) with an INTEGER quotient (sic): 1 when nothing matches, else 0;
@@ -106,13 +106,13 @@ __device__ __forceinline__ double count_score(double qual_nn, double pmatch, dou
 		return walked - matches == walked ? 0.0 : -__builtin_inf();
 	}
 	if (ALGO == PAMD_ALGO_EA_UTIL) {
-		const double bad = (double) (walked - matches);
-		return log((bad * bad + 1.0) / (double) walked);
+		// log((mismatches^2 + 1) / real_overlap), an N counting as a mismatch: looked up (PamdKernelParams::count_table)
+		return count_table[walked * PAMD_CT_EA + (walked - matches)];
 	}
 	if (ALGO == PAMD_ALGO_STITCH) {
 		// the score is a size_t: more mismatches than matches wraps to just under 2^64
-		const u64 sc = (u64) (long long) (matches - mismatches);
-		return log((double) sc / (double) (flen + rlen));
+		// log(score / (flen + rlen)), looked up likewise (the table holds the wrapped scores too)
+		return count_table[(matches - mismatches + 450) * PAMD_CT_ST + flen + rlen];
 	}
 	// simple_bayesian / uparse: size_t arithmetic inside the parenthesis (algo_simple_bayes.c:61-65), wrap
 	// included: when flen + rlen - 2*ov + unknowns is negative the reference's unsigned value is

@@ -181,7 +181,7 @@ struct ManyResult {
 };
 
 template <int ALGO>
-__device__ __attribute__((noinline)) ManyResult scan_many(unsigned char *wb, int all, int size, int minov, int flen, int rlen, double qual_nn, double pmatch, double pmismatch, double best, int lane) {
+__device__ __attribute__((noinline)) ManyResult scan_many(unsigned char *wb, int all, int size, int minov, int flen, int rlen, double qual_nn, double pmatch, double pmismatch, const double *count_table, double best, int lane) {
 	// the candidates in ascending order, one byte each (overlap - minov < 256), where the k-mer tables were
 	uint8_t *list = wb + FK_T1;
 	int total = size;
@@ -241,7 +241,7 @@ __device__ __attribute__((noinline)) ManyResult scan_many(unsigned char *wb, int
 	int bov = 0x7FFFFFFF;
 #pragma unroll
 	for (int k = 0; k < 4; k++) {
-		const double sc = count_score<ALGO>(qual_nn, pmatch, pmismatch, flen, rlen, ov[k], (int) (acc[k] & 1023u), (int) (acc[k] >> 10), ov[k]);
+		const double sc = count_score<ALGO>(qual_nn, pmatch, pmismatch, count_table, flen, rlen, ov[k], (int) (acc[k] & 1023u), (int) (acc[k] >> 10), ov[k]);
 		if (ov[k] != 0 && sc > pr) {
 			pr = sc;
 			bov = ov[k];
@@ -668,7 +668,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			best = uni_f64(best);
 		} else if (all || ncand > 4) {
 			// ---- pairs without a seeded overlap, tandem repeats: a candidate per lane (three pairs in a hundred) ----
-			const ManyResult mr = scan_many<ALGO>(wb, all ? 1 : 0, size, minov, flen, rlen, P.qual_nn, P.sb_pmatch, P.sb_pmismatch, best, lane);
+			const ManyResult mr = scan_many<ALGO>(wb, all ? 1 : 0, size, minov, flen, rlen, P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.count_table, best, lane);
 			best = uni_f64(mr.best);	// a function's results come back in vector registers
 			bo = uni(mr.bo);
 			ncand = uni(mr.examined);
@@ -683,7 +683,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x122, 0xF, 0xF, false);	// row_ror:2
 			packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x121, 0xF, 0xF, false);	// row_ror:1
 			const int unknowns = (int) (packed & 1023u), matches = (int) (packed >> 10);
-			const double sc = count_score<ALGO>(P.qual_nn, P.sb_pmatch, P.sb_pmismatch, flen, rlen, myov, unknowns, matches, myov);
+			const double sc = count_score<ALGO>(P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.count_table, flen, rlen, myov, unknowns, matches, myov);
 #pragma unroll
 			for (int r = 0; r < 4; r++) {
 				if (r < ncand) {

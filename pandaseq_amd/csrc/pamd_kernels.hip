@@ -317,7 +317,7 @@ __device__ __forceinline__ double score_sb_codes(const PamdKernelParams &P, cons
 	lo_i = lo_i < 0 ? 0 : lo_i;
 	const int hi_i = ov < rlen ? ov : rlen;
 	const int walked = hi_i > lo_i ? hi_i - lo_i : 0;
-	return count_score<ALGO>(P.qual_nn, P.sb_pmatch, P.sb_pmismatch, flen, rlen, ov, unknowns, matches, walked);
+	return count_score<ALGO>(P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.count_table, flen, rlen, ov, unknowns, matches, walked);
 }
 
 // ---- counting scorers with many candidates: one candidate per LANE -------------------------------------
@@ -333,7 +333,7 @@ struct ManyScan {
 // Kept out of line on purpose: inlined into the pair loop it pushed the whole kernel over its register budget
 // (spills on the common path); as a call it only costs the 1.5 % of pairs that take it.
 template <int ALGO>
-__device__ __attribute__((noinline, cold)) ManyScan scan_many_counting(const uint32_t *fc, const uint32_t *rc, const uint32_t *fn, const uint32_t *rn, uint16_t *cand, unsigned mybits, int minov, int flen, int rlen, double qual_nn, double pmatch, double pmismatch, double best, int lane) {
+__device__ __attribute__((noinline, cold)) ManyScan scan_many_counting(const uint32_t *fc, const uint32_t *rc, const uint32_t *fn, const uint32_t *rn, uint16_t *cand, unsigned mybits, int minov, int flen, int rlen, double qual_nn, double pmatch, double pmismatch, const double *count_table, double best, int lane) {
 	WaveLds L;
 	L.fc = const_cast<uint32_t *>(fc);
 	L.rc = const_cast<uint32_t *>(rc);
@@ -376,7 +376,7 @@ __device__ __attribute__((noinline, cold)) ManyScan scan_many_counting(const uin
 		}
 		const int unknowns = (int) (packed & 1023u), matches = (int) (packed >> 10);
 		const int walked = hi_i > lo_i ? hi_i - lo_i : 0;
-		double pr = count_score<ALGO>(qual_nn, pmatch, pmismatch, flen, rlen, ov, unknowns, matches, walked);
+		double pr = count_score<ALGO>(qual_nn, pmatch, pmismatch, count_table, flen, rlen, ov, unknowns, matches, walked);
 		// first maximum of this batch: larger score wins, equal scores -> smaller overlap
 		int bov = have ? ov : 0x7FFFFFFF;
 		if (!have)
@@ -494,7 +494,7 @@ __device__ __forceinline__ double score_overlap(const PamdKernelParams &P, const
 			matches += __popcll(ballot(ina && !n0 && m0)) + __popcll(ballot(inb && !n1 && m1));
 			mismatches += __popcll(ballot(ina && !n0 && !m0)) + __popcll(ballot(inb && !n1 && !m1));
 		}
-		return count_score<ALGO>(P.qual_nn, P.sb_pmatch, P.sb_pmismatch, flen, rlen, ov, unknowns, matches, unknowns + matches + mismatches);
+		return count_score<ALGO>(P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.count_table, flen, rlen, ov, unknowns, matches, unknowns + matches + mismatches);
 	} else {
 		// algo_pear.c:32-59 / algo_rdp_mle.c:43-74: a sequential f64 sum over i = 0..ov-1.
 		// Lanes produce the terms, lane 0 adds them in order.
@@ -998,7 +998,7 @@ __device__ void assemble_pair(const PamdKernelParams &P, const double *ltab, con
 		if (counting_algo<ALGO>() && ncand > MANY) {
 			// Many candidates: 64 at a time, one per lane (scan_many_counting).  An IUPAC ambiguity code inside
 			// a compared range abandons that path: the pair is then scanned by the step path below.
-			const ManyScan ms = scan_many_counting<ALGO>(L.fc, L.rc, L.fn, L.rn, reinterpret_cast<uint16_t *>(L.ps), mybits, minov, flen, rlen, P.qual_nn, P.sb_pmatch, P.sb_pmismatch, best, lane);
+			const ManyScan ms = scan_many_counting<ALGO>(L.fc, L.rc, L.fn, L.rn, reinterpret_cast<uint16_t *>(L.ps), mybits, minov, flen, rlen, P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.count_table, best, lane);
 			if (uni(ms.done)) {	// a function's results come back in vector registers: make them wave-uniform again
 				per_lane_done = true;
 				best = uni_f64(ms.best);

@@ -31,7 +31,7 @@ def _oracle(algo, fwd, rev, flen, rlen, **kw):
 def test_lean_kernel_matches_oracle_and_general(built, algo, exact):
     import pandaseq_amd as pa
     from pandaseq_amd import synth
-    est_tol = 1e-14 if algo in ("ea_util", "stitch") else 0.0
+    est_tol = 0.0   # (ea_util and stitch too: their log() comes from a table the host filled)
     for cfg, n, weird in ((1, 6000, False), (4, 4000, False), (1, 4000, True)):
         spec = synth.config_spec(cfg)
         if weird:
@@ -89,7 +89,7 @@ def test_lean_kernel_many_candidates_and_repeats(built):
         asm.set_algorithm(algo)
         asm.set_exact_sums(False)
         b = _run(asm, fwd, rev, flen, rlen)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=False, est_rel_tol=1e-14 if algo == "stitch" else 0.0)
+        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=False, est_rel_tol=0.0)
         compare_counters(b.counters_dict(), o[3])
         assert o[3]["slow"] > n // 4
         assert asm.last_deferred() < n // 50, "these pairs are the lean kernel's own"
