@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""A wide randomized parity campaign (development aid, GPU only; not collected by pytest): many seeds x configurations x
+scorers x both summation modes, the device path against the oracle on every record, row and counter.
+
+    python tests/parity_sweep.py [rounds]        # ~20 s per round on one MI355X + the oracle on the host's cores
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import pandaseq_amd as pa
+from oracle import pyoracle as po
+from pandaseq_amd import synth
+from util import adversarial_pairs, compare_counters, compare_results
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+ALGOS = ["simple_bayesian", "pear", "rdp_mle", "uparse", "flash", "ea_util", "stitch"]
+bad = 0
+done = 0
+for rnd in range(rounds):
+    rng = np.random.default_rng(1000 + rnd)
+    for cfg in (0, 1, 2, 4):
+        spec = synth.config_spec(cfg)
+        n = 3000
+        start = int(rng.integers(0, 40_000_000))
+        if rnd % 2 == 0:
+            f, r, fl, rl = synth.generate_numpy(spec, start, n)
+        else:
+            f, r, fl, rl = adversarial_pairs(spec, n, seed=int(rng.integers(1, 1 << 30)))
+        primers = cfg == 2
+        for algo in (ALGOS if not primers else ["pear", "simple_bayesian", "rdp_mle"]):
+            fl2, rl2 = fl, rl
+            if algo == "pear":
+                rl2 = np.minimum(rl, fl)    # (past the forward read pear reads beyond the array in the reference: kept defined)
+            kw = {}
+            if primers:
+                kw = dict(fprimer=synth.nt_codes(spec.fprimer), rprimer=synth.nt_codes(spec.rprimer, complement=True))
+            if rnd % 3 == 2:
+                kw["minoverlap"] = int(rng.integers(2, 12))
+            o = po.assemble_batch(po.make_config(algo, **kw), f, r, fl2, rl2)
+            for exact in (True, False):
+                asm = pa.Assembler(0)
+                asm.set_algorithm(algo)
+                asm.set_exact_sums(exact)
+                if primers:
+                    asm.set_forward_primer(kw["fprimer"])
+                    asm.set_reverse_primer(kw["rprimer"])
+                if "minoverlap" in kw:
+                    asm.set_minimum_overlap(kw["minoverlap"])
+                b = pa.upload_batch(f, r, fl2, rl2, device="cuda:0", seq_stride=0)
+                asm.assemble_device(b)
+                torch.cuda.synchronize()
+                done += 1
+                try:
+                    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=exact)
+                    compare_counters(b.counters_dict(), o[3])
+                except AssertionError as e:
+                    bad += 1
+                    print(f"MISMATCH round {rnd} config {cfg} {algo} exact={exact} start={start}: {str(e)[:300]}")
+    print(f"round {rnd}: {done} launches compared, {bad} mismatches", flush=True)
+sys.exit(1 if bad else 0)
