@@ -16,6 +16,8 @@ python3 bench.py --steps 5 --warmup 1 --sums exact --no-cpu --no-e2e 2> /dev/nul
 for c in 2 3 4; do python3 bench.py --steps 3 --warmup 1 --config $c --no-cpu --no-e2e 2> /dev/null | tail -1 > "$OUT/bench_config$c.json"; done
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o t -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu --no-e2e > "$OUT/prof.log" 2>&1)
 python3 profiles/summarize_rocprof.py --like '%pamd_%' $(find "$OUT/prof" -name '*_results.db' | head -1) > "$OUT/rocprof.txt"
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof2" -o t -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --config 2 --no-cpu --no-e2e > "$OUT/prof2.log" 2>&1)
+python3 profiles/summarize_rocprof.py --like '%pamd_%' $(find "$OUT/prof2" -name '*_results.db' | head -1) > "$OUT/rocprof_config2.txt"
 traffic() {	# config sums pairs
 	export PAMD_CONFIG=$1 PAMD_SUMS=$2 PAMD_PAIRS=$3
 	(cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/traffic_rd_$1_$2" -o t -- python3 "$ROOT/tools/traffic_probe.py" > "$OUT/traffic_rd_$1_$2.log" 2>&1)
