@@ -593,3 +593,19 @@ def test_pairs_that_scan_every_overlap(built, algo, sums):
     compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
     compare_counters(b.counters_dict(), o[3])
     assert (o[0]["slow"] != 0).sum() > n // 3, "the case must hold pairs that scan every overlap"
+
+
+@pytest.mark.parametrize("cfg,algo", [(1, "simple_bayesian"), (1, "rdp_mle"), (2, "pear")])
+def test_batch_sizes_around_the_work_queues_grain(built, cfg, algo, sums):
+    """The kernels hand out work sixteen pairs at a time (one at a time over the lean kernel's list) and finish parked pairs
+    64 at a time: batches just below, at and above those grains, against the oracle."""
+    from pandaseq_amd import synth
+    spec = synth.config_spec(cfg)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 123456, 1100)
+    kw = dict(fprimer=synth.nt_codes(spec.fprimer), rprimer=synth.nt_codes(spec.rprimer, complement=True)) if cfg == 2 else {}
+    for n in (1, 2, 15, 16, 17, 31, 63, 64, 65, 127, 129, 255, 1024, 1025, 1100):
+        asm = _asm_for(algo, spec, primers=cfg == 2, exact=sums == "exact")
+        b = _run(asm, fwd[:n], rev[:n], flen[:n], rlen[:n], seq_stride=0)
+        o = _oracle(algo, fwd[:n], rev[:n], flen[:n], rlen[:n], **kw)
+        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+        compare_counters(b.counters_dict(), o[3])
