@@ -24,6 +24,7 @@
 // Compiled with -ffp-contract=off like the rest (no FMA contraction: Makefile.am:62-66 builds the reference without).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "pamd_internal.h"
 #include "pamd_device.h"
 
@@ -271,6 +272,9 @@ __device__ __attribute__((noinline)) ManyResult scan_many(unsigned char *wb, int
 typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
 typedef __attribute__((address_space(3))) const double lds_cf64;
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(1))) double gbl_f64;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4 gbl_u128;
 __device__ __forceinline__ unsigned lds_read_u16(unsigned addr) {
 	return *reinterpret_cast<lds_cu16 *>(addr);
 }
@@ -378,7 +382,7 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 #define DEBUG_DUMP(...)
 #endif
 
-template <int ALGO, int ROUNDS, bool EXACT, bool PHRED>
+template <int ALGO, bool EXACT, bool PHRED>
 __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt) {
 	const uint2 fv = cur.f, rv = cur.r;
 	bool rotated = false;
@@ -596,7 +600,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				const int ov = c == 0 ? ov0 : (c == 1 ? ov1 : (c == 2 ? ov2 : ov3));
 				double part = 0.0;
 #pragma unroll
-				for (int r = 0; r < ROUNDS; r++) {
+				for (int r = 0; r < 4; r++) {	// reads of at most 256 bases
 					const int i = 64 * r + lane;
 					if (64 * r < ov && i < ov) {
 						const int fi = flen - ov + i, ri = rlen - 1 - i;
@@ -752,134 +756,114 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		double *const row_p = k_p + (store ? off : 0);
 		double qacc = 0.0;	// this lane's share of the quality sum, any order
 		double pmin = 0.0;	// PHRED: this lane's smallest log-p (every log-p is <= 0)
-		// ROUNDS rounds of 64 bases per region, straight-line: forward-only bases [0, A) (assembler.c:162-173), overlapping
-		// bases [A, A + novl) (assembler.c:181-228), reverse-only bases [A + novl, seqlen) (assembler.c:231-243), in two
-		// batches (forward-only + overlap, then reverse-only) of three passes each -- read the staged bases, read the
-		// tables, write -- so that every pass waits for the LDS once for all its rounds.  A lane past the end of its region
-		// (a whole round, often) reads whatever lies there, inside the wave's own LDS, and is masked when it stores; its nt
-		// byte lands where a later region writes again or in the staging slack.
+		// One pass over the output row, 64 bases per round: lane l of round r makes base j = 64r + l, from forward base j
+		// (j < flen: the forward-only bases [0, A), assembler.c:162-173, and the overlap [A, A + novl), assembler.c:181-228) and
+		// from reverse base rlen - 1 - (j - A) (j >= A: the overlap and the reverse-only bases [A + novl, seqlen),
+		// assembler.c:231-243): the same two index formulas in all three regions, so a 380-base row takes six rounds and every
+		// round writes 512 aligned bytes of log-p.  The staged bases of all rounds are read first (one wait); then, two rounds
+		// per trip, each round by its kind -- wave-uniform: all forward-only, all reverse-only (a shift and an add), or mixed
+		// (the overlap's table index and base, with per-lane selects at the region borders) -- table reads, then the writes.
+		// A lane past the end of the row reads whatever lies there, inside the LDS, and its base is forced to 0.
 		const unsigned lF = lds_addr(wb + FK_F), lR = lds_addr(wb + FK_R), lT = lds_addr(ltab), lN = lds_addr(nts);
 		// a pair whose row does not fit stores nothing (it ends as NOSPACE whatever its sums are)
 #ifdef FK_NO_PSTORE	/* experiment: what do the log-p stores cost? (results are wrong) */
-		const int sA = 0, sO = 0, sB = 0;
+		const int lim = 0;
 		qacc = -1.0;
 #else
-		const int sA = store ? A : 0, sO = store ? novl : 0, sB = store ? Bn : 0;
+		const int lim = store ? seqlen : 0;
 #endif
-		auto lanes_below = [](int n) -> u64 {	// lanes 0 .. n-1 as a mask (scalar arithmetic)
-			return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
-		};
-		// the fourth round only when a region is that long (one pair in six)
-		const bool last_round = ROUNDS < 4 || A > 192 || novl > 192;
-		MARK("merge-1");
+		// the B-cliff cases (assembler.c:192-207) only when a read ends in a run of quality 2
+		const bool cliff = uf < flen || ur < rlen;
+		const int AF = A + novl;	// forward bases end here
+		const unsigned nN = lN + (unsigned) lane;
+		// (explicitly global: through a generic pointer these would be flat_store, which every later LDS wait waits for as well)
+		gbl_f64 *const gP = (gbl_f64 *) (row_p + lane);
+		MARK("merge");
+		unsigned ef[8], er[8];
 		{
-			const unsigned aF = lF + 2u * (unsigned) lane;					// forward-only round r: F[64r + lane]
-			const unsigned aOF = lF + 2u * (unsigned) (A + lane);				// overlap round r: F[A + 64r + lane] ...
-			const unsigned aOR = lR + 2u * (unsigned) (rlen - 1 - lane) - 128u * (ROUNDS - 1);	// ... against R[rlen - 1 - 64r - lane]
-			unsigned ea[ROUNDS], eof[ROUNDS], eor[ROUNDS];
+			const unsigned aF = lF + 2u * (unsigned) lane;					// round r: F[64r + lane] ...
+			const unsigned aR = lR + 2u * (unsigned) (rlen - 1 + A - lane) - 128u * 7u;	// ... and R[rlen - 1 - (64r + lane - A)]
 #pragma unroll
-			for (int r = 0; r < ROUNDS; r++) {
-				if (r == 3 && !last_round)
-					break;
-				ea[r] = lds_read_u16(aF + 128u * r);
-				eof[r] = lds_read_u16(aOF + 128u * r);
-				eor[r] = lds_read_u16(aOR + 128u * (ROUNDS - 1 - r));
-			}
-			double qa[ROUNDS], qo[ROUNDS];
-			unsigned nto[ROUNDS];
-			// the B-cliff cases (assembler.c:192-207) only when a read ends in a run of quality 2
-			const bool cliff = uf < flen || ur < rlen;
-#pragma unroll
-			for (int r = 0; r < ROUNDS; r++) {
-				if (r == 3 && !last_round)
-					break;
-				qa[r] = lds_read_f64(lT + 8u * PAMD_LT_SCORE + ((ea[r] >> 5) & 0x7F8u));
-				const unsigned ef = eof[r], er = eor[r];
-				const unsigned ab = ef & er;	// low byte: the bases the two reads agree on
-				const unsigned fq = ef >> 8, rq = er >> 8;
-				const bool match = (ab & 0xFFu) != 0;
-				nto[r] = match ? ab : (fq < rq ? er : ef);	// assembler.c:212-220 (low byte)
-				unsigned qi;
-				if (ALGO == PAMD_ALGO_EA_UTIL) {	// algo_ea_util.c:58-67
-					qi = PAMD_LT_SCORE + (fq > rq ? fq : rq);
-				} else if (ALGO == PAMD_ALGO_FLASH) {	// algo_flash.c:63-80
-					const unsigned d = fq > rq ? fq - rq : rq - fq;
-					qi = PAMD_LT_SCORE + (match ? (fq > rq ? fq : rq) : (d < 2 ? 2 : d));
-				} else if (ALGO == PAMD_ALGO_RDP_MLE) {	// algo_rdp_mle.c:29-41
-					qi = match ? PAMD_LT_SCORE + (fq > rq ? fq : rq) : PAMD_LT_C + fq * PAMD_NQ + rq;
-				} else {	// algo_simple_bayes.c:68-75, algo_pear.c:61-68, algo_uparse.c:68-75, algo_stitch.c:59-67
-					qi = (match ? PAMD_LT_A : PAMD_LT_B) + fq * PAMD_NQ + rq;
-				}
-				if (cliff) {
-					const int i = 64 * r + lane;
-					const bool fmask = A + i >= uf, rmask = rlen - 1 - i >= ur;
-					qi = rmask ? PAMD_LT_SCORE + fq : qi;
-					qi = fmask ? PAMD_LT_SCORE + (rmask ? 47u : rq) : qi;	// slot 47 of the score block holds qual_nn
-				}
-				qo[r] = lds_read_f64(lT + 8u * qi);
-				mism += __popcll(lanes_below(novl - 64 * r) & ~ballot(match));
-			}
-			const unsigned nA = lN + (unsigned) lane, nO = nA + (unsigned) A;
-			double *const gA = row_p + lane, *const gO = gA + A;
-#pragma unroll
-			for (int r = 0; r < ROUNDS; r++) {
-				if (r == 3 && !last_round)
-					break;
-				lds_write_u8(nA + 64u * r, ea[r]);
-				if (lane < sA - 64 * r) {
-					gA[64 * r] = qa[r];
-					qacc += qa[r];
-					if (PHRED)
-						pmin = qa[r] < pmin ? qa[r] : pmin;
-				}
-				degen += __popcll(lanes_below(A - 64 * r) & ballot((ea[r] & 0xFFu) == 15u));	// PANDA_NT_IS_DEGN: only N here
-			}
-#pragma unroll
-			for (int r = 0; r < ROUNDS; r++) {
-				if (r == 3 && !last_round)
-					break;
-				lds_write_u8(nO + 64u * r, nto[r]);
-				if (lane < sO - 64 * r) {
-					gO[64 * r] = qo[r];
-					qacc += qo[r];
-					if (PHRED)
-						pmin = qo[r] < pmin ? qo[r] : pmin;
-				}
-				degen += __popcll(lanes_below(novl - 64 * r) & ballot((nto[r] & 0xFFu) == 15u));
+			for (int r = 0; r < 8; r++) {
+				ef[r] = lds_read_u16(aF + 128u * r);
+				er[r] = lds_read_u16(aR + 128u * (7 - r));
 			}
 		}
-		MARK("merge-2");
-		{
-			const unsigned aB = lR + 2u * (unsigned) (Bn - 1 - lane) - 128u * (ROUNDS - 1);	// reverse-only round r: R[Bn - 1 - 64r - lane]
-			const bool last_b = ROUNDS < 4 || Bn > 192;
-			unsigned eb[ROUNDS];
-#pragma unroll
-			for (int r = 0; r < ROUNDS; r++) {
-				if (r == 3 && !last_b)
-					break;
-				eb[r] = lds_read_u16(aB + 128u * (ROUNDS - 1 - r));
+		// one round: table index and base of output base 64 R + lane
+		auto round = [&](auto rc, unsigned &qi_out, unsigned &nt_out) __attribute__((always_inline)) {
+			constexpr int R = decltype(rc)::value;
+			const unsigned e_f = ef[R], e_r = er[R];
+			if (64 * (R + 1) <= A) {	// all forward-only (assembler.c:162-173)
+				qi_out = PAMD_LT_SCORE + (e_f >> 8);
+				nt_out = e_f;
+				return;
 			}
-			double qb[ROUNDS];
-#pragma unroll
-			for (int r = 0; r < ROUNDS; r++) {
-				if (r == 3 && !last_b)
-					break;
-				qb[r] = lds_read_f64(lT + 8u * PAMD_LT_SCORE + ((eb[r] >> 5) & 0x7F8u));
+			const bool ok = lane < lim - 64 * R;
+			if (64 * R >= AF) {	// all reverse-only (assembler.c:231-243)
+				qi_out = PAMD_LT_SCORE + (e_r >> 8);
+				nt_out = ok ? e_r : 0u;
+				return;
 			}
-			const unsigned nB = lN + (unsigned) (lane + A + novl);
-			double *const gB = row_p + lane + A + novl;
+			const int j = 64 * R + lane;
+			const bool inF = j < AF, inR = j >= A;
+			const unsigned ab = e_f & e_r;	// low byte: the bases the two reads agree on
+			const unsigned fq = e_f >> 8, rq = e_r >> 8;
+			const bool match = (ab & 0xFFu) != 0;
+			unsigned nt = match ? ab : (fq < rq ? e_r : e_f);	// assembler.c:212-220 (low byte)
+			unsigned qi;
+			if (ALGO == PAMD_ALGO_EA_UTIL) {	// algo_ea_util.c:58-67
+				qi = PAMD_LT_SCORE + (fq > rq ? fq : rq);
+			} else if (ALGO == PAMD_ALGO_FLASH) {	// algo_flash.c:63-80
+				const unsigned d = fq > rq ? fq - rq : rq - fq;
+				qi = PAMD_LT_SCORE + (match ? (fq > rq ? fq : rq) : (d < 2 ? 2 : d));
+			} else if (ALGO == PAMD_ALGO_RDP_MLE) {	// algo_rdp_mle.c:29-41
+				qi = match ? PAMD_LT_SCORE + (fq > rq ? fq : rq) : PAMD_LT_C + fq * PAMD_NQ + rq;
+			} else {	// algo_simple_bayes.c:68-75, algo_pear.c:61-68, algo_uparse.c:68-75, algo_stitch.c:59-67
+				qi = (match ? PAMD_LT_A : PAMD_LT_B) + fq * PAMD_NQ + rq;
+			}
+			if (cliff) {
+				asm volatile("; B-cliff");	// (keeps this a branch: as selects it would cost every pair six instructions a round)
+				const bool fmask = j >= uf, rmask = rlen - 1 + A - j >= ur;
+				qi = rmask ? PAMD_LT_SCORE + fq : qi;
+				qi = fmask ? PAMD_LT_SCORE + (rmask ? 47u : rq) : qi;	// slot 47 of the score block holds qual_nn
+			}
+			qi = inR ? qi : PAMD_LT_SCORE + fq;	// forward-only
+			qi = inF ? qi : PAMD_LT_SCORE + rq;	// reverse-only
+			nt = inR ? nt : e_f;
+			nt = inF ? nt : e_r;
+			qi_out = qi;
+			nt_out = ok ? nt : 0u;
+			mism += __popcll(ballot(inF) & ballot(inR) & ~ballot(match));
+		};
+		// two rounds per trip, straight-line; trips nest so that nothing but the accumulators lives across them
+		auto trip = [&](auto r0c) __attribute__((always_inline)) {
+			constexpr int R0 = decltype(r0c)::value;
+			unsigned qi[2], ntv[2];
+			round(std::integral_constant<int, R0>(), qi[0], ntv[0]);
+			round(std::integral_constant<int, R0 + 1>(), qi[1], ntv[1]);
+			double pv[2];
 #pragma unroll
-			for (int r = 0; r < ROUNDS; r++) {
-				if (r == 3 && !last_b)
-					break;
-				lds_write_u8(nB + 64u * r, eb[r]);
-				if (lane < sB - 64 * r) {
-					gB[64 * r] = qb[r];
-					qacc += qb[r];
+			for (int k = 0; k < 2; k++)
+				pv[k] = lds_read_f64(lT + 8u * qi[k]);
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				lds_write_u8(nN + 64u * (R0 + k), ntv[k]);
+				if (lane < lim - 64 * (R0 + k)) {
+					gP[64 * (R0 + k)] = pv[k];
+					qacc += pv[k];
 					if (PHRED)
-						pmin = qb[r] < pmin ? qb[r] : pmin;
+						pmin = pv[k] < pmin ? pv[k] : pmin;
 				}
-				degen += __popcll(lanes_below(Bn - 64 * r) & ballot((eb[r] & 0xFFu) == 15u));
+				degen += __popcll(ballot((ntv[k] & 0xFFu) == 15u));	// PANDA_NT_IS_DEGN: only N here
+			}
+		};
+		trip(std::integral_constant<int, 0>());
+		if (seqlen > 128) {
+			trip(std::integral_constant<int, 2>());
+			if (seqlen > 256) {
+				trip(std::integral_constant<int, 4>());
+				if (seqlen > 384)
+					trip(std::integral_constant<int, 6>());
 			}
 		}
 		wave_sync();
@@ -888,7 +872,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		MARK("row-out+sum");
 		// the nt row leaves LDS in 16-byte stores (rows are 16-base aligned)
 		if (store && lane * 16 < seqlen)
-			reinterpret_cast<uint4 *>(row_nt)[lane] = reinterpret_cast<const uint4 *>(nts)[lane];
+			((gbl_u128 *) row_nt)[lane] = reinterpret_cast<const u32x4 *>(nts)[lane];
 		if (PHRED) {
 			// panda_result_phred (nt.c:126-150) is 1 at or below qual_score[0] and does not decrease above it, so the row's
 			// smallest phred is that of its smallest log-p: one bisection per pair instead of one per base
@@ -936,7 +920,6 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	pd.ro_st = put_lane(pd.ro_st, ((unsigned) status << 16) | ((unsigned) slow << 24) | ((unsigned) (phmin > 63 ? 63 : phmin) << 26), mine);
 }
 
-// ROUNDS: rounds of 64 bases a read can span (rows of at most 64 * ROUNDS bases)
 // PHRED: a min_phred module is loaded, the merge tracks the row's smallest log-p (plugin_min_phred.c:8-22)
 #ifdef FK_NO_W4	/* A/B builds only */
 #define FK_WAVES_ATTR
@@ -946,7 +929,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 // (one 16-wave workgroup fills a CU's LDS: four waves per SIMD whatever the registers allow, so the compiler is told to
 // spend all 128 vector registers on scheduling instead of saving them for waves that cannot come -- 1 % on a 16 M-pair
 // launch, nothing measurable at 50 M)
-template <int ALGO, int ROUNDS, bool EXACT, bool PHRED>
+template <int ALGO, bool EXACT, bool PHRED>
 __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const PamdKernelParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	double *ltab = reinterpret_cast<double *>(lds);
@@ -995,7 +978,7 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 		nxt.f = load_row(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
 		nxt.r = load_row(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
-		fast_pair<ALGO, ROUNDS, EXACT, PHRED>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane, flen, rlen, cur, nxt);
+		fast_pair<ALGO, EXACT, PHRED>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane, flen, rlen, cur, nxt);
 		MARK("loop");
 		npend++;
 		if (npend == 64) {
@@ -1038,9 +1021,7 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 	const dim3 grid((unsigned) workgroups), block((unsigned) waves_per_wg * 64u);
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	void (*kern)(const PamdKernelParams) = nullptr;
-	const int rounds = p.smax <= 128 ? 2 : (p.smax <= 192 ? 3 : 4);
-#define FK_PICK3(A, E, PH) (rounds == 2 ? pamd_fast_kernel<A, 2, E, PH> : (rounds == 3 ? pamd_fast_kernel<A, 3, E, PH> : pamd_fast_kernel<A, 4, E, PH>))
-#define FK_PICK2(A, E) (p.has_min_phred ? FK_PICK3(A, E, true) : FK_PICK3(A, E, false))
+#define FK_PICK2(A, E) (p.has_min_phred ? pamd_fast_kernel<A, E, true> : pamd_fast_kernel<A, E, false>)
 #define FK_PICK(A) (p.exact_sums ? FK_PICK2(A, true) : FK_PICK2(A, false))
 	switch (p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
@@ -1070,7 +1051,6 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 	}
 #undef FK_PICK
 #undef FK_PICK2
-#undef FK_PICK3
 	hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 	if (e0 != hipSuccess) {
 		pamd_set_error("hipFuncSetAttribute(%zu bytes LDS, lean kernel): %s", lds_bytes, hipGetErrorString(e0));
