@@ -567,6 +567,20 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 		if (pear && -a->pear_random_base > p.many_all)
 			p.many_all = -a->pear_random_base;
 	}
+	// the lean kernel's primer scan (pamd_fast.hip): the primers as 4-bit masks, and what a disagreement costs at least
+	for (int which = 0; which < 2; which++) {
+		const int plen = which == 0 ? a->fprimer_len : a->rprimer_len;
+		const uint8_t *pr = a->primers + (which == 0 ? 0 : 456);
+		for (int w = 0; w < 3; w++) {
+			uint32_t m = 0;
+			for (int k = 0; k < 8; k++)
+				m |= (uint32_t) (8 * w + k < plen ? (pr[8 * w + k] & 0xFu) : 0xFu) << (4 * k);
+			p.primer_masks[which].pm[w] = m;
+		}
+	}
+	p.primer_qthr = 22;
+	p.primer_err_t = a->tabs.score_err[22];
+	p.primer_inv_err_t = 1.0 / p.primer_err_t;
 	memcpy(p.modules, a->modules, sizeof p.modules);
 	for (int m = 0; m < a->n_modules; m++)
 		if (a->modules[m].kind == 1)
@@ -666,7 +680,8 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	// Two kernels (pamd_fast.hip): the lean one takes every pair and hands the unusual ones, by index, to the general
 	// one, which runs second on the same stream and reads how many there are from device memory.
 	const char *nofast = getenv("PAMD_NO_FAST");	// development aid
-	const bool two = a->fast_path && pamd_fast_supports(p) && !(nofast && nofast[0] == '1');
+	const int variant = (a->fast_path && !(nofast && nofast[0] == '1')) ? pamd_fast_supports(p) : 0;
+	const bool two = variant != 0;
 	if (two && a->defer_cap < b->n_pairs) {
 		if (a->d_defer)
 			HIP_TRY(hipFree(a->d_defer));
@@ -699,8 +714,10 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.wave_pids = a->d_wave_pids;
 	HIP_TRY(hipEventRecord(a->ev_start, st));
 	HIP_TRY(hipMemsetAsync(a->d_defer_count, 0, 2 * sizeof(unsigned), st));
-	if (primers_first) {
-		rc = pamd_launch_primers(p, a->cu_count, stream);
+	// (the lean kernel finds the primers of the pairs it keeps itself; the primer kernel then serves the pairs it deferred)
+	const bool lean_primers = two && variant == PAMD_FAST_PRIM;
+	if (primers_first && !lean_primers) {
+		rc = pamd_launch_primers(p, a->cu_count, stream, nullptr, nullptr);
 		if (rc != PAMD_OK)
 			return rc;
 	}
@@ -727,6 +744,11 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 		p.pair_list = a->d_defer;
 		p.pair_count = a->d_defer_count;
 		p.arena_chunk = b->n_pairs >= 262144 ? 4096 : 1024;
+		if (primers_first && lean_primers) {
+			rc = pamd_launch_primers(p, a->cu_count, stream, a->d_defer, a->d_defer_count);
+			if (rc != PAMD_OK)
+				return rc;
+		}
 	}
 	a->last_two_kernels = two;
 	rc = pamd_launch_assemble(p, wgs, waves, lds_bytes, stream);

@@ -43,14 +43,40 @@ constexpr unsigned FK_F = 0, FK_R = 512, FK_FC = 1024, FK_RC = 1088, FK_FN = 115
 // rdp_mle (54 KB: a third matrix); the other three are fixed
 constexpr unsigned FK_T2_SLOTS = 256, FK_T3_SLOTS = 64, FK_T4_SLOTS = 32;
 constexpr unsigned FK_T1 = 2128;
-template <int T1B>
+// Two geometries.  LONG = false: reads of at most 256 bases, four bases per lane (the offsets above).  LONG = true: reads of
+// at most 320 bases (2x300), primers and trims: rows arrive eight bases per lane, seeding runs five bases per lane on
+// windows of the code streams, and what is only needed before seeding (the primer scan's nibble streams and scratch) or
+// after it (the merged-nt staging) lies over the first k-mer table, which is cleared for every pair anyway.
+template <bool LONG>
+struct Lay;
+template <>
+struct Lay<false> {
+	static constexpr unsigned F = FK_F, R = FK_R, FC = FK_FC, RC = FK_RC, FN = FK_FN, RN = FK_RN, FLAGS = FK_FLAGS, NT = FK_NT, T1 = FK_T1;
+	static constexpr int BPL = 4;		// bases per lane while seeding
+	static constexpr int MAXLEN = 256;
+	static constexpr int NR = 8;		// rounds of 64 bases a merged row can span
+	static constexpr int SR = 4;		// rounds of 64 positions an overlap can span
+};
+template <>
+struct Lay<true> {
+	// (a pad word before the forward N map: what lies before a read reads as N; see the kernel's prologue)
+	static constexpr unsigned F = 0, R = 640, FC = 1280, RC = 1376, PAD0 = 1472, FN = 1488, RN = 1584, PAD1 = 1680, FLAGS = 1696, T1 = 2080;
+	static constexpr unsigned NT = T1;				// merged-nt staging: up to 640 + 64 bytes
+	static constexpr unsigned NIBF = T1, NIBR = T1 + 192, SCR = T1 + 384;	// primer scan: 4-bit nt streams, 512 bytes of f64 terms
+	static constexpr int BPL = 5;
+	static constexpr int MAXLEN = 320;
+	static constexpr int NR = 10;
+	static constexpr int SR = 5;
+};
+template <bool LONG, int T1B>
 struct Geo {
 	static constexpr unsigned T1_SLOTS = 1u << T1B;
-	static constexpr unsigned T2 = FK_T1 + 4u * T1_SLOTS, T3 = T2 + 4u * FK_T2_SLOTS, T4 = T3 + 4u * FK_T3_SLOTS;
+	static constexpr unsigned T2 = Lay<LONG>::T1 + 4u * T1_SLOTS, T3 = T2 + 4u * FK_T2_SLOTS, T4 = T3 + 4u * FK_T3_SLOTS;
 	static constexpr unsigned WAVE_BYTES = T4 + 4u * FK_T4_SLOTS;
 	static_assert(WAVE_BYTES % 16 == 0, "16-byte LDS accesses");
 };
 static_assert(FK_NT % 16 == 0 && FK_T1 % 16 == 0 && FK_FLAGS % 16 == 0, "16-byte LDS accesses");
+static_assert(Lay<true>::T1 % 16 == 0 && Lay<true>::FLAGS % 16 == 0 && Lay<true>::R % 16 == 0, "16-byte LDS accesses");
 template <int ALGO>
 __device__ __host__ constexpr int t1_bits() {
 	return ALGO == PAMD_ALGO_RDP_MLE ? 9 : 10;	// (512 slots for every scorer: measured 2 % slower on config 1)
@@ -101,6 +127,38 @@ __device__ __forceinline__ constexpr unsigned lut_word(int w) {
 	return v;
 }
 
+// LDS by byte address: the compiler then sees plain integer arithmetic (no symbolic base to add per access) and folds
+// constant steps into the instructions' offset field
+typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
+typedef __attribute__((address_space(3))) const double lds_cf64;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(1))) double gbl_f64;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4 gbl_u128;
+__device__ __forceinline__ unsigned lds_read_u16(unsigned addr) {
+	return *reinterpret_cast<lds_cu16 *>(addr);
+}
+__device__ __forceinline__ double lds_read_f64(unsigned addr) {
+	return *reinterpret_cast<lds_cf64 *>(addr);
+}
+__device__ __forceinline__ void lds_write_u8(unsigned addr, unsigned v) {
+	*reinterpret_cast<lds_u8 *>(addr) = (uint8_t) v;
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+	return (unsigned) (uintptr_t) p;	// a flat pointer into LDS carries the LDS byte address in its low half
+}
+
+// (x << S) + y in one instruction (the compiler prefers a shift, a mask and an add when it sees (x >> a) << S)
+template <int S>
+__device__ __forceinline__ unsigned lshl_add(unsigned x, unsigned y) {
+	unsigned r;
+	asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(S), "v"(y));
+	return r;
+}
+__device__ __forceinline__ unsigned lds_read_u32(unsigned addr) {
+	return *reinterpret_cast<__attribute__((address_space(3))) const unsigned *>(addr);
+}
+
 // ---- stage one read: four bases per lane -------------------------------------------------------------------
 // Writes the row, its 2-bit codes and its N map to LDS; returns the B-cliff length (read length minus the trailing
 // run of raw quality 2, assembler.c:176-177).  codes: base k of this lane at bits 2k..2k+1.  nmap: bit 2k (forward) or
@@ -147,17 +205,408 @@ __device__ __forceinline__ int stage(const uint2 v, const int len, int lane, uns
 	return __builtin_amdgcn_readlane(mine, 63 - __builtin_clzll(has));
 }
 
+// ---- LONG geometry: stage one read, eight bases per lane ------------------------------------------------------
+// Four bases of a row (x: nt0 q0 nt1 q1, y: nt2 q2 nt3 q3), of which the first `cnt` exist: their k-mer codes (2 bits each),
+// N flags (bit 2k forward, 2k+1 reverse; a base that does not exist reads as N), whether one is outside the lean domain;
+// the nt and the quality bytes for the caller.  The arithmetic of stage() above.
+template <bool FORWARD>
+__device__ __forceinline__ void pack4(unsigned x, unsigned y, int cnt, unsigned &codes, unsigned &nmap, unsigned &weird, unsigned &n4, unsigned &q4) {
+	n4 = __builtin_amdgcn_perm(y, x, 0x06040200u);
+	q4 = __builtin_amdgcn_perm(y, x, 0x07050301u);
+	const unsigned sel = n4 & 0x07070707u;
+	const unsigned b3 = (n4 >> 3) & 0x01010101u, m3 = (b3 << 8) - b3;
+	const unsigned lo = __builtin_amdgcn_perm(lut_word<FORWARD>(1), lut_word<FORWARD>(0), sel);
+	const unsigned hi = __builtin_amdgcn_perm(lut_word<FORWARD>(3), lut_word<FORWARD>(2), sel);
+	const unsigned r4 = (hi & m3) | (lo & ~m3);
+	const unsigned bm = (unsigned) ((0xFFFFFFFFull << (8 * cnt)) >> 32);
+	const unsigned wq = (((q4 & 0x7F7F7F7Fu) + 0x51515151u) | q4) & 0x80808080u;
+	weird |= ((r4 & 0x08080808u) | wq | (n4 & 0xF0F0F0F0u)) & bm;
+	const unsigned c4 = r4 & 0x03030303u, isn4 = (r4 >> 2) & 0x01010101u;
+	const unsigned cy = c4 | (c4 >> 6), ny = isn4 | (isn4 >> 6);
+	const unsigned in2 = (1u << (2 * cnt)) - 1u;
+	codes = (cy | (cy >> 12)) & in2;
+	const unsigned nb = ((ny | (ny >> 12)) | ~in2) & 0x55u;
+	nmap = FORWARD ? nb : nb << 1;
+}
+
+// the 4-bit nt codes of four bases as 16 bits; a base whose quality is below qthr reads as N (the primer scan's filter
+// counts disagreements at qualities of at least qthr only)
+__device__ __forceinline__ unsigned nibbles4(unsigned n4, unsigned q4, unsigned qadd, int cnt) {
+	const unsigned ge = ((q4 & 0x7F7F7F7Fu) + qadd) & 0x80808080u;	// 0x80 where quality >= qthr (qadd = (0x80 - qthr) in every byte)
+	const unsigned lowm = ((ge >> 7) ^ 0x01010101u) * 0x0Fu;
+	const unsigned past = ~(unsigned) ((0xFFFFFFFFull << (8 * cnt)) >> 32);	// bases past the read's end agree with anything as well
+	unsigned x = (n4 | lowm | past) & 0x0F0F0F0Fu;
+	x = (x | (x >> 4)) & 0x00FF00FFu;
+	return (x | (x >> 8)) & 0xFFFFu;
+}
+
+__device__ __forceinline__ unsigned is2_mask(unsigned q4) {	// bit k: quality byte k == 2
+	const unsigned x = q4 ^ 0x02020202u;
+	const unsigned t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);	// 0x80 where quality == 2
+	return (((t >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
+
+// Writes the row, its code stream and N map (and, PRIM, its 4-bit nt stream) to LDS; returns the B-cliff length.
+template <bool FORWARD, bool PRIM>
+__device__ __forceinline__ int stage8(const uint4 v, const int len, int lane, unsigned char *wb, unsigned &weird, unsigned qadd) {
+	typedef Lay<true> L;
+	if (lane < 40)
+		reinterpret_cast<uint4 *>(wb + (FORWARD ? L::F : L::R))[lane] = v;
+	int c0 = len - 8 * lane;
+	int c1 = c0 - 4;
+	c0 = c0 < 0 ? 0 : (c0 > 4 ? 4 : c0);
+	c1 = c1 < 0 ? 0 : (c1 > 4 ? 4 : c1);
+	unsigned ca, na, n4a, q4a, cb, nb, n4b, q4b;
+	pack4<FORWARD>(v.x, v.y, c0, ca, na, weird, n4a, q4a);
+	pack4<FORWARD>(v.z, v.w, c1, cb, nb, weird, n4b, q4b);
+	if (lane < 48) {	// (lanes past the row: all N)
+		reinterpret_cast<uint16_t *>(wb + (FORWARD ? L::FC : L::RC))[lane] = (uint16_t) (ca | (cb << 8));
+		reinterpret_cast<uint16_t *>(wb + (FORWARD ? L::FN : L::RN))[lane] = (uint16_t) (na | (nb << 8));
+		if (PRIM)
+			reinterpret_cast<unsigned *>(wb + (FORWARD ? L::NIBF : L::NIBR))[lane] = nibbles4(n4a, q4a, qadd, c0) | (nibbles4(n4b, q4b, qadd, c1) << 16);
+	}
+	// the usual read does not end in quality 2: two lane reads settle it
+	const int li = (len - 1) >> 3, lb = (len - 1) & 7;
+	const unsigned qa_l = (unsigned) __builtin_amdgcn_readlane((int) q4a, li), qb_l = (unsigned) __builtin_amdgcn_readlane((int) q4b, li);
+	if ((((lb < 4 ? qa_l : qb_l) >> (8 * (lb & 3))) & 0xFFu) != 2u)
+		return len;
+	int c8 = len - 8 * lane;
+	c8 = c8 < 0 ? 0 : (c8 > 8 ? 8 : c8);
+	const unsigned not2 = ~(is2_mask(q4a) | (is2_mask(q4b) << 4)) & ((1u << c8) - 1u);
+	const int mine = not2 ? lane * 8 + (31 - __builtin_clz(not2)) + 1 : 0;
+	const u64 has = ballot(not2 != 0);
+	if (has == 0)
+		return 0;
+	return __builtin_amdgcn_readlane(mine, 63 - __builtin_clzll(has));
+}
+
+// ---- LONG geometry: the primer scan (assembler.c:262-288 calling panda_compute_offset_qual, offset.c:47-112) ------------
+// An alignment of the primer at read position s scores v(s) = (sum of its terms) / (s + plen + 1) -- a term is qual_score[q]
+// where read and primer base agree, qual_score_err[q] where they do not, nothing for a primer N -- and the scan returns
+// 1 + s + plen of the FIRST alignment whose value is the largest above plen * threshold (zero penalty: exp() is the last,
+// monotone step of offset.c:72 and values are compared before it; a comparison so close that exp() could blur it sends the
+// pair to the careful path).  Every term is <= 0, and a disagreement at quality >= qthr costs at least -err_t =
+// -qual_score_err[qthr]: an alignment with more than K = floor(bound * len / err_t) of them cannot reach `bound`, whatever
+// else it holds.  So: (1) lanes are ALIGNMENTS; each counts the disagreements of its first eight primer bases against a
+// window of the read's 4-bit nt stream (low-quality bases already read as N there) -- a dozen instructions for 64 alignments;
+// (2) the first alignment with at most one is summed exactly, and its value (or the threshold) is the bound; (3) K follows;
+// alignments with more than K disagreements -- among the first eight bases when K <= 1, else among all -- are out;
+// (4) the few that are left are summed exactly, in the reference's order, and compared as the reference compares them.
+// Returns -1 when it cannot settle the read that cheaply (no good alignment, a bound too loose to filter, too many left).
+
+// disagreements between the primer's first 8 * NW bases (nibble masks pm; 0xF past its end and for N) and the read at s
+template <int NW>
+__device__ __forceinline__ int nib_mismatches(unsigned nib_addr, int s, const unsigned (&pm)[3]) {
+	const unsigned a = nib_addr + 4u * (unsigned) (s >> 3), sh = 4u * ((unsigned) s & 7u);
+	unsigned d[NW + 1];
+#pragma unroll
+	for (int i = 0; i <= NW; i++)
+		d[i] = lds_read_u32(a + 4u * i);
+	unsigned agree = 0;
+#pragma unroll
+	for (int i = 0; i < NW; i++) {
+		const unsigned t = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh) & pm[i];
+		const unsigned u = t | (t >> 1);
+		agree += (unsigned) __popc((u | (u >> 2)) & 0x11111111u);
+	}
+	return 8 * NW - (int) agree;
+}
+
+// the sum of one alignment's terms in primer order (offset.c:79-87): lanes look the terms up, lane 0 adds them
+__device__ __forceinline__ double primer_exact(const double *ltab, unsigned char *wb, unsigned row_off, int s, unsigned pbase, int plen, int lane) {
+	typedef Lay<true> L;
+	double t = 0.0;
+	if (lane < plen) {
+		const unsigned e = reinterpret_cast<const uint16_t *>(wb + row_off)[s + lane];
+		const double v = ltab[(((e & pbase & 0xFu) != 0) ? PAMD_LT_SCORE : PAMD_LT_ERR) + (e >> 8)];
+		t = pbase != 15u ? v : 0.0;	// (a primer N adds nothing; + 0.0 leaves the sum as it is)
+	}
+	double *scr = reinterpret_cast<double *>(wb + L::SCR);
+	wave_sync();
+	scr[lane] = t;
+	wave_sync();
+	double acc = 0.0;
+	if (lane == 0) {
+		for (int c = 0; c < plen; c += 8) {
+			const double2 v0 = *reinterpret_cast<const double2 *>(scr + c), v1 = *reinterpret_cast<const double2 *>(scr + c + 2);
+			const double2 v2 = *reinterpret_cast<const double2 *>(scr + c + 4), v3 = *reinterpret_cast<const double2 *>(scr + c + 6);
+			acc += v0.x;
+			acc += v0.y;
+			acc += v1.x;
+			acc += v1.y;
+			acc += v2.x;
+			acc += v2.y;
+			acc += v3.x;
+			acc += v3.y;
+		}
+	}
+	return uni_f64(acc);
+}
+
+// ---- the usual read, five alignments per lane ----
+// disagreements (at qualities >= qthr) among the primer's first sixteen bases for this lane's alignments s = 5 * lane + j, five
+// bits each (31: no such alignment); s0: the first alignment with at most one (-1: none)
+__device__ __forceinline__ unsigned primer_tier1(unsigned nib_addr, int nal, int lane, unsigned pm0, unsigned pm1, int &s0) {
+	const unsigned bit = 20u * (unsigned) lane;
+	const unsigned a = nib_addr + 4u * (bit >> 5), sh = bit & 31u;
+	const unsigned d0 = lds_read_u32(a), d1 = lds_read_u32(a + 4u), d2 = lds_read_u32(a + 8u), d3 = lds_read_u32(a + 12u);
+	const unsigned x0 = __builtin_amdgcn_alignbit(d1, d0, sh), x1 = __builtin_amdgcn_alignbit(d2, d1, sh), x2 = __builtin_amdgcn_alignbit(d3, d2, sh);
+	unsigned packed = 0;
+	int first = 0x7FFFFFFF;
+#pragma unroll
+	for (int j = 0; j < 5; j++) {
+		const unsigned w0 = j == 0 ? x0 : __builtin_amdgcn_alignbit(x1, x0, 4u * j), w1 = j == 0 ? x1 : __builtin_amdgcn_alignbit(x2, x1, 4u * j);
+		const unsigned t0 = w0 & pm0, t1 = w1 & pm1;
+		const unsigned u0 = t0 | (t0 << 1), u1 = t1 | (t1 << 1);
+		const unsigned v0 = u0 | (u0 << 2), v1 = u1 | (u1 << 2);	// bit 3 of a nibble: read and primer base agree
+		int mm = 16 - __popc((v0 & 0x88888888u) | ((v1 & 0x88888888u) >> 1));
+		mm = 5 * lane + j < nal ? mm : 31;
+		packed |= (unsigned) mm << (5 * j);
+		const u64 c = ballot(mm <= 1);
+		if (c != 0) {
+			const int cand = 5 * __builtin_ctzll(c) + j;
+			first = cand < first ? cand : first;
+		}
+	}
+	s0 = first == 0x7FFFFFFF ? -1 : first;
+	return packed;
+}
+
+// the exact sums (offset.c:79-87) of one alignment of each read at once: lanes 0..31 look up the terms of the forward read's
+// alignment s0f (lane x: primer base x), lanes 32..63 those of the reverse read's s0r; lanes 0 and 32 add them in primer order
+__device__ __forceinline__ void primer_exact_joint(const double *ltab, unsigned char *wb, int s0f, int s0r, int fplen, int rplen, unsigned pbj, int lane, double &sumf, double &sumr) {
+	typedef Lay<true> L;
+	const int half = lane >> 5, x = lane & 31;
+	const int s0 = half ? s0r : s0f, plen = half ? rplen : fplen;
+	double t = 0.0;
+	if (x < plen && s0 >= 0) {
+		const unsigned e = reinterpret_cast<const uint16_t *>(wb + (half ? L::R : L::F))[s0 + x];
+		const double v = ltab[(((e & pbj & 0xFu) != 0) ? PAMD_LT_SCORE : PAMD_LT_ERR) + (e >> 8)];
+		t = pbj != 15u ? v : 0.0;
+	}
+	double *scr = reinterpret_cast<double *>(wb + L::SCR);
+	wave_sync();
+	scr[lane] = t;
+	wave_sync();
+	double acc = 0.0;
+	if (x == 0) {
+		const double *q = scr + 32 * half;
+		const int n = fplen > rplen ? fplen : rplen;
+		for (int c = 0; c < n; c += 8) {
+			const double2 v0 = *reinterpret_cast<const double2 *>(q + c), v1 = *reinterpret_cast<const double2 *>(q + c + 2);
+			const double2 v2 = *reinterpret_cast<const double2 *>(q + c + 4), v3 = *reinterpret_cast<const double2 *>(q + c + 6);
+			acc += v0.x;
+			acc += v0.y;
+			acc += v1.x;
+			acc += v1.y;
+			acc += v2.x;
+			acc += v2.y;
+			acc += v3.x;
+			acc += v3.y;
+		}
+	}
+	sumf = lane_f64(acc, 0);
+	sumr = lane_f64(acc, 32);
+}
+
+// With the alignment s0 summed: if no other alignment can reach its value, the read is settled (>= 0: what the scan returns);
+// -1: more work (primer_settle)
+__device__ __forceinline__ int primer_shortcut(unsigned packed, int s0, double sum0, int len, int plen, double thr, double inv_err_t, int lane) {
+	const int n0 = s0 + plen + 1;
+	const double kv = sum0 * (double) (1.0f / (float) n0) * (1.0 + 1e-5);	// a shade below its value: a bound may be anything an alignment reaches
+	const double bound = kv > thr ? kv : thr;
+	// alignment s may hold K(s) = floor((bound * (s + plen + 1) - 1e-6) / err_t) disagreements and still reach the bound
+	const double xs = bound * inv_err_t * 1.0001, x0 = (double) (plen + 1) * xs - 1e-6 * inv_err_t + 0.001;	// all >= 0
+	if (!((double) (len - plen - 1) * xs + x0 < 8.0))
+		return -1;
+	const double y = (double) (5 * lane) * xs + x0;
+	const int s0l = s0 / 5, s0j = s0 - 5 * s0l;
+	int nleft = 0;
+	bool s0_left = false;
+#pragma unroll
+	for (int j = 0; j < 5; j++) {
+		const int K = (int) (y + (double) j * xs);
+		const u64 left = ballot((int) ((packed >> (5 * j)) & 31u) <= K);
+		nleft += __popcll(left);
+		if (j == s0j)
+			s0_left = ((left >> s0l) & 1ull) != 0;
+	}
+	if (nleft == 1 && s0_left) {
+		if (sum0 > (thr + 1e-9) * (double) n0)
+			return n0;
+		if (sum0 < (thr - 1e-9) * (double) n0)
+			return 0;
+	}
+	return -1;
+}
+
+// ---- every other read: blocks of 64 alignments ----
+// pm0..2: nibble masks of the primer's bases 0..7, 8..15, 16..23 (host-built); thr: plen * threshold (offset.c:59, before exp);
+// s0, sum0: an alignment already summed (s0 < 0: none)
+__device__ __forceinline__ int primer_settle(const double *ltab, unsigned char *wb, unsigned row_off, unsigned nib_off, int len, unsigned pbase, unsigned pm0, unsigned pm1, unsigned pm2, int plen, double thr, double inv_err_t, int lane, int s0, double sum0) {
+	const unsigned pm[3] = { pm0, pm1, pm2 };
+	const int nal = len - plen;	// alignments 0 .. nal-1 are judged (at index s + plen <= len - 1, offset.c:70-77)
+	const unsigned na = lds_addr(wb + nib_off);
+	// the bound: the value of that alignment, or the threshold every alignment has to beat
+	double bound = thr;
+	const int n0 = s0 + plen + 1;
+	if (s0 >= 0) {
+		const double kv = sum0 * (double) (1.0f / (float) n0) * (1.0 + 1e-5);
+		bound = kv > thr ? kv : thr;
+	}
+	// (3) alignment s may hold K(s) = floor((bound * (s + plen + 1) - 1e-6) / err_t) such disagreements; where that is too
+	// many to tell anything (a bound that stayed loose: no primer in the read, or one with low qualities), all are left
+	const double xs = bound * inv_err_t * 1.0001, x0 = (double) (plen + 1) * xs - 1e-6 * inv_err_t + 0.001;	// all >= 0
+	u64 left[5] = { 0, 0, 0, 0, 0 };
+	int nleft = 0;
+	bool s0_left = false;
+#pragma unroll
+	for (int k = 0; k < 5; k++) {
+		if (64 * k >= nal)
+			break;
+		const int s = 64 * k + lane;
+		const u64 valid = nal - 64 * k >= 64 ? ~0ull : ((1ull << (nal - 64 * k)) - 1ull);
+		const int last = nal - 64 * k >= 64 ? 64 * k + 63 : nal - 1;	// the block's loosest alignment
+		const double klast = (double) last * xs + x0;
+		if (klast >= 8.0) {
+			left[k] = valid;
+		} else {
+			const int K = (int) ((double) s * xs + x0);
+			const int mm = plen > 16 ? nib_mismatches<3>(na, s, pm) : (plen > 8 ? nib_mismatches<2>(na, s, pm) : nib_mismatches<1>(na, s, pm));
+			left[k] = ballot(mm <= K) & valid;
+		}
+		nleft += __popcll(left[k]);
+		if (k == (s0 >> 6))
+			s0_left = s0 >= 0 && ((left[k] >> (s0 & 63)) & 1ull) != 0;
+	}
+	// (4) what is left is summed exactly and compared as offset.c:72-77 compares (before exp)
+	if (nleft == 1 && s0_left) {	// the usual read: only the alignment already summed
+		if (sum0 > (thr + 1e-9) * (double) n0)
+			return n0;
+		if (sum0 < (thr - 1e-9) * (double) n0)
+			return 0;
+		return -1;
+	}
+	// lane l keeps the best of the alignments 64 k + l it has seen, in ascending order; the lanes are compared at the end
+	double best = thr;
+	int besti = 0;
+	bool close = false;
+#pragma unroll 1
+	for (int k = 0; k < 5; k++) {
+		const u64 lk = k == 0 ? left[0] : (k == 1 ? left[1] : (k == 2 ? left[2] : (k == 3 ? left[3] : left[4])));
+		if (lk == 0)
+			continue;
+		double v = 0.0;
+		bool mine = false;
+		if (__popcll(lk) <= 3) {	// a few: the wave sums them one after the other
+			u64 m = lk;
+			while (m != 0) {
+				const int l = __builtin_ctzll(m), s = 64 * k + l;
+				m &= m - 1;
+				const double sum = s == s0 ? sum0 : primer_exact(ltab, wb, row_off, s, pbase, plen, lane);
+				const double q = sum / (double) (s + plen + 1);
+				if (lane == l) {
+					v = q;
+					mine = true;
+				}
+			}
+		} else {
+			// many: lanes are alignments, each adds its own terms in primer order, four primer bases at a time; the block
+			// is given up once no lane can reach the bound any more (every term is <= 0)
+			const int s = 64 * k + lane;
+			const bool have = ((lk >> lane) & 1ull) != 0;
+			const uint16_t *S = reinterpret_cast<const uint16_t *>(wb + row_off) + (have ? s : 0);
+			const double floor_acc = bound * (double) (s + plen + 1) - 1e-6;
+			double acc = 0.0;
+			bool live = true;
+			int x = 0;
+			for (; x + 4 <= plen && live; x += 4) {
+				unsigned e[4], pn[4];
+				double t[4];
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					e[u] = S[x + u];
+					pn[u] = (unsigned) __builtin_amdgcn_readlane((int) pbase, x + u);
+				}
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+					t[u] = ltab[(((e[u] & pn[u] & 0xFu) != 0) ? PAMD_LT_SCORE : PAMD_LT_ERR) + (e[u] >> 8)];
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+					if (pn[u] != 15u)
+						acc += t[u];
+				live = ballot(have && !(acc < floor_acc)) != 0;
+			}
+			if (!live)
+				continue;
+			for (; x < plen; x++) {
+				const unsigned pn = (unsigned) __builtin_amdgcn_readlane((int) pbase, x);
+				if (pn != 15u) {
+					const unsigned e = S[x];
+					acc += ltab[(((e & pn & 0xFu) != 0) ? PAMD_LT_SCORE : PAMD_LT_ERR) + (e >> 8)];
+				}
+			}
+			v = acc / (double) (s + plen + 1);
+			mine = have;
+		}
+		const bool better = mine && v > best;	// strict: the earliest index wins ties (offset.c:74)
+		// two values may differ and their exponentials not: the reference then keeps the earlier index (the careful path's case)
+		close |= better && v - best <= 4.5e-16;
+		if (better) {
+			best = v;
+			besti = 64 * k + lane + plen + 1;
+		}
+		const u64 improved = ballot(better);
+		if (improved != 0 && k < 4) {	// a better bound for the blocks to come
+			double m = best;
+			if ((improved & (improved - 1)) == 0) {
+				m = lane_f64(best, __builtin_ctzll(improved));
+			} else {
+				m = besti != 0 ? best : bound;
+				for (int off = 32; off > 0; off >>= 1) {
+					const double o = __shfl_xor(m, off);
+					m = o > m ? o : m;
+				}
+				m = uni_f64(m);
+			}
+			bound = m > bound ? m : bound;
+		}
+	}
+	// first maximum across lanes: the larger value, the smaller index among equals
+	const u64 got = ballot(besti != 0);
+	if ((got & (got - 1)) == 0) {	// nobody, or one lane only
+		if (ballot(close) != 0)
+			return -1;
+		return got != 0 ? __builtin_amdgcn_readlane(besti, __builtin_ctzll(got)) : 0;
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		const double ob = __shfl_xor(best, off);
+		const int oi = __shfl_xor(besti, off);
+		const bool greater = ob > best, equal = ob == best;
+		close |= oi != 0 && besti != 0 && ob != best && fabs(ob - best) <= 4.5e-16;
+		const bool take = (oi != 0) && (besti == 0 || greater || (equal && oi < besti));
+		if (take) {
+			best = ob;
+			besti = oi;
+		}
+	}
+	if (ballot(close) != 0)
+		return -1;
+	return uni(besti);
+}
+
 // counts over the 16 overlap positions i0 .. i0+15 of candidate `ov` (ov <= both read lengths, so every position
 // below ov exists on both reads): unknowns (an N on either side) in bits 0..9, matching bases in bits 10..
 // (algo_simple_bayes.c:40-59).  Forward bases flen-ov+i ascending; reverse bases rlen-1-i descending: the reverse words
 // are taken at the mirrored position and bit-reversed.  Reads outside a stream stay inside the wave's LDS and are masked.
+template <class L>
 __device__ __forceinline__ unsigned word_counts(const unsigned char *wb, int flen, int rlen, int ov, int i0, bool active) {
 	int hi = ov - i0;
 	hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
 	const unsigned valid = active ? ((unsigned) ((1ull << (2 * hi)) - 1ull) & 0x55555555u) : 0u;
 	const int fb = 2 * (flen - ov + i0), rb = 2 * (rlen - 16 - i0);
-	const uint32_t *fcw = reinterpret_cast<const uint32_t *>(wb + FK_FC) + (fb >> 5), *fnw = reinterpret_cast<const uint32_t *>(wb + FK_FN) + (fb >> 5);
-	const uint32_t *rcw = reinterpret_cast<const uint32_t *>(wb + FK_RC) + (rb >> 5), *rnw = reinterpret_cast<const uint32_t *>(wb + FK_RN) + (rb >> 5);
+	const uint32_t *fcw = reinterpret_cast<const uint32_t *>(wb + L::FC) + (fb >> 5), *fnw = reinterpret_cast<const uint32_t *>(wb + L::FN) + (fb >> 5);
+	const uint32_t *rcw = reinterpret_cast<const uint32_t *>(wb + L::RC) + (rb >> 5), *rnw = reinterpret_cast<const uint32_t *>(wb + L::RN) + (rb >> 5);
 	const unsigned fc0 = fcw[0], fc1 = fcw[1], fn0 = fnw[0], fn1 = fnw[1];
 	const unsigned rc0 = rcw[0], rc1 = rcw[1], rn0 = rnw[0], rn1 = rnw[1];
 	const unsigned f = __builtin_amdgcn_alignbit(fc1, fc0, (unsigned) fb & 31u);
@@ -230,7 +679,7 @@ __device__ __attribute__((noinline)) ManyResult scan_many(unsigned char *wb, int
 			const bool first = s < wa;
 			const int o = first ? ova : ovb;
 			const int i0 = 16 * (first ? s : s - wa);
-			const unsigned cnt = word_counts(wb, flen, rlen, o, i0, i0 < o);
+			const unsigned cnt = word_counts<Lay<false>>(wb, flen, rlen, o, i0, i0 < o);
 			a += first ? cnt : 0u;
 			b += first ? 0u : cnt;
 		}
@@ -267,57 +716,54 @@ __device__ __attribute__((noinline)) ManyResult scan_many(unsigned char *wb, int
 	return out;
 }
 
-// LDS by byte address: the compiler then sees plain integer arithmetic (no symbolic base to add per access) and folds
-// constant steps into the instructions' offset field
-typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
-typedef __attribute__((address_space(3))) const double lds_cf64;
-typedef __attribute__((address_space(3))) uint8_t lds_u8;
-typedef __attribute__((address_space(1))) double gbl_f64;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) u32x4 gbl_u128;
-__device__ __forceinline__ unsigned lds_read_u16(unsigned addr) {
-	return *reinterpret_cast<lds_cu16 *>(addr);
-}
-__device__ __forceinline__ double lds_read_f64(unsigned addr) {
-	return *reinterpret_cast<lds_cf64 *>(addr);
-}
-__device__ __forceinline__ void lds_write_u8(unsigned addr, unsigned v) {
-	*reinterpret_cast<lds_u8 *>(addr) = (uint8_t) v;
-}
-__device__ __forceinline__ unsigned lds_addr(const void *p) {
-	return (unsigned) (uintptr_t) p;	// a flat pointer into LDS carries the LDS byte address in its low half
-}
-
-// (x << S) + y in one instruction (the compiler prefers a shift, a mask and an add when it sees (x >> a) << S)
-template <int S>
-__device__ __forceinline__ unsigned lshl_add(unsigned x, unsigned y) {
-	unsigned r;
-	asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(S), "v"(y));
-	return r;
-}
-__device__ __forceinline__ unsigned lds_read_u32(unsigned addr) {
-	return *reinterpret_cast<__attribute__((address_space(3))) const unsigned *>(addr);
-}
-
 struct WaveArena {
 	u64 cur;
 	u64 end;
 };
 
-// the registers a wave carries from one pair to the next (software prefetch)
-struct Carry {
+// the registers a wave carries from one pair to the next (software prefetch): the lengths and this lane's share of the two
+// rows -- four bases (8 bytes), or eight (16 bytes) in the LONG geometry
+template <bool LONG>
+struct Carry;
+template <>
+struct Carry<false> {
 	int flen_v, rlen_v;
 	uint2 f, r;
 };
+template <>
+struct Carry<true> {
+	int flen_v, rlen_v;
+	uint4 f, r;
+};
 
-__device__ __forceinline__ void settle(Carry &c) {	// the compiler must treat the carried registers as written here
+__device__ __forceinline__ void settle(Carry<false> &c) {	// the compiler must treat the carried registers as written here
 	asm volatile("" : "+v"(c.flen_v), "+v"(c.rlen_v), "+v"(c.f.x), "+v"(c.f.y), "+v"(c.r.x), "+v"(c.r.y));
+}
+__device__ __forceinline__ void settle(Carry<true> &c) {
+	asm volatile("" : "+v"(c.flen_v), "+v"(c.rlen_v), "+v"(c.f.x), "+v"(c.f.y), "+v"(c.f.z), "+v"(c.f.w), "+v"(c.r.x), "+v"(c.r.y), "+v"(c.r.z), "+v"(c.r.w));
 }
 
 __device__ __forceinline__ uint2 load_row(const uint8_t *row, unsigned row_bytes, int lane) {
 	unsigned off = (unsigned) lane * 8u;
 	off = off < row_bytes ? off : row_bytes - 8u;	// lanes past the row's end re-read its last bytes (rows are whole multiples of 16 B)
 	return *reinterpret_cast<const uint2 *>(row + off);
+}
+__device__ __forceinline__ uint4 load_row16(const uint8_t *row, unsigned row_bytes, int lane) {
+	unsigned off = (unsigned) lane * 16u;
+	off = off < row_bytes ? off : row_bytes - 16u;
+	return *reinterpret_cast<const uint4 *>(row + off);
+}
+template <bool LONG>
+__device__ __forceinline__ void load_pair(Carry<LONG> &c, const PamdKernelParams &P, unsigned q, int lane) {
+	c.flen_v = P.flen[q];
+	c.rlen_v = P.rlen[q];
+	if constexpr (LONG) {
+		c.f = load_row16(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+		c.r = load_row16(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
+	} else {
+		c.f = load_row(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+		c.r = load_row(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
+	}
 }
 
 // one level of the forward insert: the smaller of (slot, carry) stays in the slot, the larger one moves on
@@ -340,7 +786,9 @@ __device__ __forceinline__ unsigned insert_at(unsigned lds_byte_addr, unsigned c
 }
 
 // why pairs are deferred, counted in P.phase_cycles[0..5] (read back with pamd_debug_phase_cycles): 0 an nt or quality
-// outside the lean domain, 1 a k-mer found no slot, (2, 3: unused) 4 quality too close to the LOWQ threshold; (debug builds) 5 counts pairs that used the last two k-mer tables
+// outside the lean domain, 1 a k-mer found no slot, 2 a score comparison too close to call (pear, rdp_mle), 3 more than four
+// candidates (pear, rdp_mle, LONG), 4 quality too close to the LOWQ threshold, (debug builds) 5 counts pairs that used the
+// last two k-mer tables, 6 the primer scan did not settle a read, 7 an overlap that runs into a clipped primer
 __device__ __forceinline__ void note(const PamdKernelParams &P, int what, int lane) {
 	if (lane == 0 && P.phase_cycles != nullptr)
 		atomicAdd(&P.phase_cycles[what], 1ull);
@@ -370,7 +818,7 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 	if (P.debug_buf == nullptr || pair != P.debug_pair)
 		return;
 	unsigned char *dst = P.debug_buf + (size_t) where * 8192u;
-	for (unsigned i = lane; i < Geo<10>::WAVE_BYTES / 4; i += 64)
+	for (unsigned i = lane; i < Geo<false, 10>::WAVE_BYTES / 4; i += 64)
 		reinterpret_cast<unsigned *>(dst)[i] = reinterpret_cast<const unsigned *>(wb)[i];
 	if (lane == 0) {
 		int *s = reinterpret_cast<int *>(dst + 7680);
@@ -382,10 +830,17 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 #define DEBUG_DUMP(...)
 #endif
 
-template <int ALGO, bool EXACT, bool PHRED>
-__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry &cur, const Carry &nxt) {
-	const uint2 fv = cur.f, rv = cur.r;
+// LONG: the geometry (Lay<LONG>).  PRIM (LONG only): primers (`-p` / `-q`, found by primer_quick) or trims are configured.
+template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM>
+__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases) {
+	typedef Lay<LONG> L;
+	constexpr int BPL = L::BPL;
+	static_assert(!PRIM || LONG, "primers and trims are served by the LONG geometry");
+	static_assert(!EXACT || !LONG, "exact sums are served by the short geometry");
+	const auto fv = cur.f, rv = cur.r;
 	bool rotated = false;
+	int fo = 0, ro = 0;	// bases clipped from the reads' 5' ends (primers, trims): assembler.c:262-288
+	bool primers_known = false;
 	int status = PAMD_ST_OK;
 	u64 off = ~0ull;
 	double best = 0.0, qsum = 0.0;
@@ -393,44 +848,136 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	bool slow = false;
 	const int minov = P.minoverlap;
 	constexpr int T1B = t1_bits<ALGO>();
-	typedef Geo<T1B> G;
-	unsigned *const t1 = reinterpret_cast<unsigned *>(wb + FK_T1), *const t2 = reinterpret_cast<unsigned *>(wb + G::T2);
+	typedef Geo<LONG, T1B> G;
+	unsigned *const t1 = reinterpret_cast<unsigned *>(wb + L::T1), *const t2 = reinterpret_cast<unsigned *>(wb + G::T2);
 	unsigned *const t3 = reinterpret_cast<unsigned *>(wb + G::T3), *const t4 = reinterpret_cast<unsigned *>(wb + G::T4);
-	uint8_t *const flags = wb + FK_FLAGS;
-	uint8_t *const nts = wb + FK_NT;
+	uint8_t *const flags = wb + L::FLAGS;
+	uint8_t *const nts = wb + L::NT;
 
 	do {
 		if (flen < 2 || rlen < 2) {	// assembler.c:255-258
 			status = PAMD_ST_BADR;
 			break;
 		}
-		if ((flen < rlen ? flen : rlen) < minov) {	// assembler.c:289-292 (no primers, no trims here)
-			status = PAMD_ST_BADR;
-			break;
-		}
-		if (minov >= flen || minov >= rlen) {	// assembler.c:73-82
-			status = PAMD_ST_NOALGN;
-			break;
+		if (!PRIM) {
+			if ((flen < rlen ? flen : rlen) < minov) {	// assembler.c:289-292 (no primers, no trims here)
+				status = PAMD_ST_BADR;
+				break;
+			}
+			if (minov >= flen || minov >= rlen) {	// assembler.c:73-82
+				status = PAMD_ST_NOALGN;
+				break;
+			}
 		}
 		wave_sync();	// the previous pair's readers are done with this wave's LDS
 		MARK("stage");
-		// ---- stage; clear the k-mer tables and the candidate flags ----
-		unsigned fcodes, fnm, rcodes, rnm, weird = 0;
-		const int uf = stage<true>(fv, flen, lane, wb, fcodes, fnm, weird);
-		const int ur = stage<false>(rv, rlen, lane, wb, rcodes, rnm, weird);
-		{
-			const unsigned n16 = (deep_dirty ? G::WAVE_BYTES - FK_T1 : G::T3 - FK_T1) / 16u;
-			uint4 *h = reinterpret_cast<uint4 *>(wb + FK_T1);
-			for (unsigned s = lane; s < n16; s += 64)
-				h[s] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
-			if (lane < 16)
-				reinterpret_cast<uint4 *>(flags)[lane] = make_uint4(0u, 0u, 0u, 0u);
-			deep_dirty = false;
+		// ---- stage ----
+		unsigned fcodes = 0, fnm = 0, rcodes = 0, rnm = 0, weird = 0;
+		int uf, ur;
+		if constexpr (LONG) {
+			const unsigned qadd = (unsigned) (0x80 - P.primer_qthr) * 0x01010101u;
+			uf = stage8<true, PRIM>(fv, flen, lane, wb, weird, qadd);
+			ur = stage8<false, PRIM>(rv, rlen, lane, wb, weird, qadd);
+		} else {
+			uf = stage<true>(fv, flen, lane, wb, fcodes, fnm, weird);
+			ur = stage<false>(rv, rlen, lane, wb, rcodes, rnm, weird);
 		}
 		if (ballot(weird != 0) != 0) {	// an IUPAC ambiguity code, nt 0, a quality outside 0..46: the general kernel's pair
 			note(P, 0, lane);
 			status = PAMD_ST_DEFER;
 			break;
+		}
+		STOP(5);	// (ablation builds: stage alone; STOP(0) then adds the primers)
+		if constexpr (PRIM) {
+			// ---- primers and trims (assembler.c:262-292); the reverse primer is looked for only in pairs that have the
+			// forward one.  One copy of the scan serves both reads (everything that selects the read is wave-uniform).
+			MARK("primers");
+			wave_sync();
+			fo = P.ftrim;
+			ro = P.rtrim;
+			bool unsettled = false;
+			{
+				const int fpl = P.fprimer_len, rpl = P.rprimer_len;
+				const double thr_f = (double) fpl * P.threshold, thr_r = (double) rpl * P.threshold, inv_err_t = P.primer_inv_err_t;
+				// per read: -3 no primer configured, -2 not looked at yet, -1 not settled yet, >= 0 what the scan returns
+				// (a primer as long as the read, or longer, is not found: offset.c:55-57, :70)
+				int rf = fpl <= 0 ? -3 : (flen - fpl <= 0 ? 0 : -2), rr = rpl <= 0 ? -3 : (rlen - rpl <= 0 ? 0 : -2);
+				unsigned pkf = 0, pkr = 0;
+				int s0f = -1, s0r = -1;
+				if (rf == -2)
+					pkf = primer_tier1(lds_addr(wb + L::NIBF), flen - fpl, lane, P.primer_masks[0].pm[0], P.primer_masks[0].pm[1], s0f);
+				if (rr == -2)
+					pkr = primer_tier1(lds_addr(wb + L::NIBR), rlen - rpl, lane, P.primer_masks[1].pm[0], P.primer_masks[1].pm[1], s0r);
+				double sumf = 0.0, sumr = 0.0;
+				if (s0f >= 0 || s0r >= 0)
+					primer_exact_joint(ltab, wb, s0f, s0r, fpl, rpl, (primer_bases >> 16) & 0xFFu, lane, sumf, sumr);
+				if (rf == -2)
+					rf = s0f >= 0 ? primer_shortcut(pkf, s0f, sumf, flen, fpl, thr_f, inv_err_t, lane) : -1;
+				if (rr == -2)
+					rr = s0r >= 0 ? primer_shortcut(pkr, s0r, sumr, rlen, rpl, thr_r, inv_err_t, lane) : -1;
+				// the reads that did not settle (one copy of the code: everything that selects the read is wave-uniform);
+				// the reverse primer is looked for only in pairs that have the forward one
+#pragma unroll 1
+				for (int which = 0; which < 2; which++) {
+					if ((which == 0 ? rf : rr) != -1 || (which == 1 && rf <= 0 && rf != -3))
+						continue;
+					MARK("primers-settle");
+#ifdef PAMD_FK_DEBUG
+					note(P, (which == 0 ? s0f : s0r) < 0 ? 8 : 9, lane);
+#endif
+					const PamdPrimerMasks &pk = P.primer_masks[which];
+					const int r = primer_settle(ltab, wb, which == 0 ? L::F : L::R, which == 0 ? L::NIBF : L::NIBR, which == 0 ? flen : rlen, (which == 0 ? primer_bases : primer_bases >> 8) & 0xFFu, pk.pm[0], pk.pm[1], pk.pm[2], which == 0 ? fpl : rpl, which == 0 ? thr_f : thr_r, inv_err_t, lane, which == 0 ? s0f : s0r, which == 0 ? sumf : sumr);
+					if (which == 0)
+						rf = r;
+					else
+						rr = r;
+				}
+				if (rf == -1) {
+					unsettled = true;
+				} else if (rf == 0) {
+					status = PAMD_ST_NOFP;
+				} else {
+					if (rf > 0)
+						fo = rf - 1;
+					if (rr == -1)
+						unsettled = true;
+					else if (rr == 0)
+						status = PAMD_ST_NORP;
+					else if (rr > 0)
+						ro = rr - 1;
+				}
+			}
+			if (unsettled) {	// the primer kernel and the general kernel take it from here
+				note(P, 6, lane);
+				status = PAMD_ST_DEFER;
+				fo = ro = 0;
+				break;
+			}
+			if (status != PAMD_ST_OK) {
+				if (status == PAMD_ST_NOFP)
+					fo = 0;
+				ro = 0;
+				break;
+			}
+			if ((flen < rlen ? flen : rlen) < minov) {	// assembler.c:289-292
+				status = PAMD_ST_BADR;
+				break;
+			}
+			if (minov + fo >= flen || minov + ro >= rlen) {	// assembler.c:73-82
+				status = PAMD_ST_NOALGN;
+				break;
+			}
+			primers_known = true;
+			wave_sync();	// the scan's streams and scratch lie where the k-mer tables are cleared now
+		}
+		{	// clear the k-mer tables and the candidate flags
+			const unsigned n16 = (deep_dirty ? G::WAVE_BYTES - L::T1 : G::T3 - L::T1) / 16u;
+			uint4 *h = reinterpret_cast<uint4 *>(wb + L::T1);
+			for (unsigned s = lane; s < n16; s += 64)
+				h[s] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+			if (lane < (LONG ? 24 : 16))
+				reinterpret_cast<uint4 *>(flags)[lane] = make_uint4(0u, 0u, 0u, 0u);
+			deep_dirty = false;
 		}
 		wave_sync();
 		STOP(0);
@@ -444,27 +991,38 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		const int size = maxov - minov + 1;		// minov <= maxov here
 		bool deep = false;
 		{
-			const unsigned x0 = fcodes | (fnm << 8);
-			const unsigned x1 = from_lane_below<0x5500u>(x0), x2 = from_lane_below<0x5500u>(x1);
-			const unsigned w = (x2 & 0xFFu) | ((x1 & 0xFFu) << 8) | ((x0 & 0xFFu) << 16);		// base 4(l-2)+b at bits 2b..2b+1
-			const unsigned nw = ((x2 >> 8) & 0xFFu) | (x1 & 0xFF00u) | ((x0 & 0xFF00u) << 8);	// its N flag at bit 2b
-			unsigned carry[4];
+			unsigned w, nw;	// base BPL*l - 8 + b at bits 2b..2b+1 of w, its N flag at bit 2b of nw
+			if constexpr (LONG) {
+				// five positions per lane, p = 5*lane + j: the sixteen bases from 5*lane - 8 are one unaligned word of the code
+				// stream and of the N map (before the read: the pad word, all N)
+				const int fb = 10 * lane - 16;
+				const unsigned *cw = reinterpret_cast<const unsigned *>(wb + L::FC) + (fb >> 5), *nwp = reinterpret_cast<const unsigned *>(wb + L::FN) + (fb >> 5);
+				const unsigned c0 = cw[0], c1 = cw[1], n0 = nwp[0], n1 = nwp[1];
+				w = __builtin_amdgcn_alignbit(c1, c0, (unsigned) fb & 31u);
+				nw = __builtin_amdgcn_alignbit(n1, n0, (unsigned) fb & 31u);
+			} else {
+				const unsigned x0 = fcodes | (fnm << 8);
+				const unsigned x1 = from_lane_below<0x5500u>(x0), x2 = from_lane_below<0x5500u>(x1);
+				w = (x2 & 0xFFu) | ((x1 & 0xFFu) << 8) | ((x0 & 0xFFu) << 16);
+				nw = ((x2 >> 8) & 0xFFu) | (x1 & 0xFF00u) | ((x0 & 0xFF00u) << 8);
+			}
+			unsigned carry[BPL];
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
+			for (int j = 0; j < BPL; j++) {
 				// the k-mer's eight codes are bits 2+2j .. 17+2j of w: shifted to the top half of the table word
-				const unsigned word = ((w << (14 - 2 * j)) & 0xFFFF0000u) | (unsigned) (4 * lane + j);
+				const unsigned word = ((w << (14 - 2 * j)) & 0xFFFF0000u) | (unsigned) (BPL * lane + j);
 				carry[j] = (nw & (0x15555u << (2 * j))) == 0 ? word : EMPTY;
 			}
 			const unsigned l1 = lds_addr(t1), l2 = lds_addr(t2);
 #pragma unroll
-			for (int j = 0; j < 4; j++)
+			for (int j = 0; j < BPL; j++)
 				carry[j] = insert_at(lshl_add<2>(mul24(carry[j] >> 16, HASH_C) >> (32 - T1B), l1), carry[j]);
 #pragma unroll
-			for (int j = 0; j < 4; j++)
+			for (int j = 0; j < BPL; j++)
 				carry[j] = insert_at(lshl_add<2>(__builtin_amdgcn_ubfe(mul24(carry[j] >> 16, HASH_C), 14, 8), l2), carry[j]);
 			bool lost = false;
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
+			for (int j = 0; j < BPL; j++) {
 				if (ballot(carry[j] != EMPTY) != 0) {	// rare from here on: one or two words per pair
 					deep = true;
 					carry[j] = insert_level(t3, slot3(carry[j] >> 16), carry[j]);
@@ -498,17 +1056,26 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		// The k-mer at p covers bases p .. p+7 and is emitted iff p <= rlen-9 and none of p .. p+8 is N: the codes of
 		// lanes l, l+1, l+2.  Its two smallest forward positions are the reference's first two (kmerseen[2k], [2k+1]).
 		{
-			const unsigned x0 = rcodes | (rnm << 8);
-			const unsigned x1 = from_lane_above<0xAA00u>(x0), x2 = from_lane_above<0xAA00u>(x1);
-			const unsigned w = (x0 & 0xFFu) | ((x1 & 0xFFu) << 8) | ((x2 & 0xFFu) << 16);		// base 4l+b at bits 2b..2b+1
-			const unsigned nw = ((x0 >> 8) & 0xFFu) | (x1 & 0xFF00u) | ((x2 & 0xFF00u) << 8);	// its N flag at bit 2b+1
+			unsigned w, nw;	// base BPL*l + b at bits 2b..2b+1 of w, its N flag at bit 2b+1 of nw
+			if constexpr (LONG) {
+				const int rb = 10 * lane;
+				const unsigned *cw = reinterpret_cast<const unsigned *>(wb + L::RC) + (rb >> 5), *nwp = reinterpret_cast<const unsigned *>(wb + L::RN) + (rb >> 5);
+				const unsigned c0 = cw[0], c1 = cw[1], n0 = nwp[0], n1 = nwp[1];
+				w = __builtin_amdgcn_alignbit(c1, c0, (unsigned) rb & 31u);
+				nw = __builtin_amdgcn_alignbit(n1, n0, (unsigned) rb & 31u);
+			} else {
+				const unsigned x0 = rcodes | (rnm << 8);
+				const unsigned x1 = from_lane_above<0xAA00u>(x0), x2 = from_lane_above<0xAA00u>(x1);
+				w = (x0 & 0xFFu) | ((x1 & 0xFFu) << 8) | ((x2 & 0xFFu) << 16);
+				nw = ((x0 >> 8) & 0xFFu) | (x1 & 0xFF00u) | ((x2 & 0xFF00u) << 8);
+			}
 			const unsigned br = __builtin_bitreverse32(w);	// base b now at bits 30-2b..31-2b, codes read as forward codes
-			const unsigned top = (unsigned) (flen + rlen - minov - 1 - 4 * lane);	// assembler.c:107: index = top - j - forward position
-			unsigned m1[4], m2[4], xk[4];
-			bool ok[4];
+			const unsigned top = (unsigned) (flen + rlen - minov - 1 - BPL * lane);	// assembler.c:107: index = top - j - forward position
+			unsigned m1[BPL], m2[BPL], xk[BPL];
+			bool ok[BPL];
 			const unsigned l1 = lds_addr(t1), l2 = lds_addr(t2);
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
+			for (int j = 0; j < BPL; j++) {
 				xk[j] = br << (2 * j);	// this k-mer in the top half
 				ok[j] = (nw & (0x2AAAAu << (2 * j))) == 0;
 				const unsigned prod = mul24(xk[j] >> 16, HASH_C), kk = xk[j] & 0xFFFF0000u;
@@ -520,7 +1087,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			}
 			if (deep) {	// wave-uniform: the last two tables hold something
 #pragma unroll
-				for (int j = 0; j < 4; j++) {
+				for (int j = 0; j < BPL; j++) {
 					const unsigned kmer = xk[j] >> 16, kk = xk[j] & 0xFFFF0000u;
 					const unsigned e3 = t3[slot3(kmer)] ^ kk, e4 = t4[slot4(kmer)] ^ kk;
 					const unsigned l34 = e3 < e4 ? e3 : e4, h34 = e3 < e4 ? e4 : e3;
@@ -532,7 +1099,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			}
 			bool second = false;
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
+			for (int j = 0; j < BPL; j++) {
 				const unsigned idx = top - (unsigned) j - m1[j];	// no match: m1 >= 0x10000 wraps far beyond size
 				if (ok[j] && idx < (unsigned) size)
 					flags[idx] = 1;
@@ -540,7 +1107,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			}
 			if (ballot(second) != 0) {	// a k-mer that occurs twice in the forward read
 #pragma unroll
-				for (int j = 0; j < 4; j++) {
+				for (int j = 0; j < BPL; j++) {
 					const unsigned idx = top - (unsigned) j - m2[j];
 					if (ok[j] && idx < (unsigned) size)
 						flags[idx] = 1;
@@ -556,27 +1123,41 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		bool all = false;
 		{
 			const unsigned mine = reinterpret_cast<const unsigned *>(flags)[lane];	// overlaps minov + 4*lane + 0..3
-			u64 nz = ballot(mine != 0);
+			// (kept as scalar selects: indexed by ncand the four overlaps would live in scratch memory)
+#define FK_TAKE(NZ, MINE, BASE)                                                                  \
+	{                                                                                        \
+		u64 nz_ = (NZ);                                                                  \
+		while (nz_ != 0 && ncand <= 4) {                                                 \
+			const int w = __builtin_ctzll(nz_);                                      \
+			nz_ &= nz_ - 1;                                                          \
+			unsigned m = (unsigned) __builtin_amdgcn_readlane((int) (MINE), w);      \
+			while (m != 0 && ncand <= 4) {                                           \
+				const int k = __builtin_ctz(m) >> 3;                             \
+				m &= ~(0xFFu << (8 * k));                                        \
+				const int ov = (BASE) + 4 * w + k + minov;                       \
+				if (ncand == 0)                                                  \
+					ov0 = ov;                                                \
+				else if (ncand == 1)                                             \
+					ov1 = ov;                                                \
+				else if (ncand == 2)                                             \
+					ov2 = ov;                                                \
+				else                                                             \
+					ov3 = ov;                                                \
+				ncand++;                                                         \
+			}                                                                        \
+		}                                                                                \
+	}
+			const u64 nz = ballot(mine != 0);
 			all = nz == 0;	// ALL_BITS_IF_NONE: every overlap is a candidate
-			while (nz != 0 && ncand <= 4) {
-				const int w = __builtin_ctzll(nz);
-				nz &= nz - 1;
-				unsigned m = (unsigned) __builtin_amdgcn_readlane((int) mine, w);
-				while (m != 0 && ncand <= 4) {
-					const int k = __builtin_ctz(m) >> 3;
-					m &= ~(0xFFu << (8 * k));
-					const int ov = 4 * w + k + minov;
-					if (ncand == 0)
-						ov0 = ov;
-					else if (ncand == 1)
-						ov1 = ov;
-					else if (ncand == 2)
-						ov2 = ov;
-					else
-						ov3 = ov;
-					ncand++;
-				}
+			FK_TAKE(nz, mine, 0);
+			if constexpr (LONG) {	// overlaps beyond 256: lanes 0..15 once more
+				const unsigned mine2 = reinterpret_cast<const unsigned *>(flags + 256)[lane & 31];
+				const u64 nz2 = ballot(mine2 != 0) & 0xFFFFull;
+				all = all && nz2 == 0;
+				if (nz2 != 0)
+					FK_TAKE(nz2, mine2, 256);
 			}
+#undef FK_TAKE
 		}
 		MARK("scan");
 		best = P.qual_nn * (double) (flen + rlen);	// assembler.c:60
@@ -591,8 +1172,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				status = PAMD_ST_DEFER;
 				break;
 			}
-			const unsigned lF = lds_addr(wb + FK_F), lR = lds_addr(wb + FK_R), lT = lds_addr(ltab);
-			double *const ps = reinterpret_cast<double *>(wb + FK_T1);	// the terms of one candidate, where the k-mer tables were
+			const unsigned lF = lds_addr(wb + L::F), lR = lds_addr(wb + L::R), lT = lds_addr(ltab);
+			double *const ps = reinterpret_cast<double *>(wb + L::T1);	// the terms of one candidate, where the k-mer tables were
 			deep_dirty = deep_dirty || EXACT;
 			const double nrb = -P.pear_random_base, nn = P.qual_nn;
 			bool ambiguous = false;
@@ -600,7 +1181,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				const int ov = c == 0 ? ov0 : (c == 1 ? ov1 : (c == 2 ? ov2 : ov3));
 				double part = 0.0;
 #pragma unroll
-				for (int r = 0; r < 4; r++) {	// reads of at most 256 bases
+				for (int r = 0; r < L::SR; r++) {
 					const int i = 64 * r + lane;
 					if (64 * r < ov && i < ov) {
 						const int fi = flen - ov + i, ri = rlen - 1 - i;
@@ -670,7 +1251,11 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			}
 			bo = uni(bo);
 			best = uni_f64(best);
-		} else if (all || ncand > 4) {
+		} else if (LONG && (all || ncand > 4)) {	// (the candidate-per-lane scan below is laid out for 256 overlaps)
+			note(P, 3, lane);
+			status = PAMD_ST_DEFER;
+			break;
+		} else if (!LONG && (all || ncand > 4)) {
 			// ---- pairs without a seeded overlap, tandem repeats: a candidate per lane (three pairs in a hundred) ----
 			const ManyResult mr = scan_many<ALGO>(wb, all ? 1 : 0, size, minov, flen, rlen, P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.count_table, best, lane);
 			best = uni_f64(mr.best);	// a function's results come back in vector registers
@@ -681,7 +1266,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			// ---- scan + argmax: one candidate per 16-lane row, 16 positions per lane ----
 			const int row = lane >> 4;
 			const int myov = row == 0 ? ov0 : (row == 1 ? ov1 : (row == 2 ? ov2 : ov3));
-			unsigned packed = word_counts(wb, flen, rlen, myov, 16 * (lane & 15), row < ncand);
+			unsigned packed = word_counts<L>(wb, flen, rlen, myov, 16 * (lane & 15), row < ncand);
+			if (LONG && (ov0 > 256 || ov1 > 256 || ov2 > 256 || ov3 > 256))	// (a row of lanes covers 256 positions)
+				packed += word_counts<L>(wb, flen, rlen, myov, 256 + 16 * (lane & 15), row < ncand);
 			packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x128, 0xF, 0xF, false);	// row_ror:8
 			packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x124, 0xF, 0xF, false);	// row_ror:4
 			packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x122, 0xF, 0xF, false);	// row_ror:2
@@ -711,6 +1298,16 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			break;
 		}
 
+		// ---- merge (assembler.c:146-247): df = flen - fo - bo forward-only bases, dr = rlen - ro - bo reverse-only ones ----
+		// (with clipped reads either may be negative -- the overlap runs into what was clipped, VEEZ / WEDGEZ of
+		// assembler.c:162,181,231 --: the overlap region then starts at 0 and is that much shorter, the index formulas stay)
+		const int A = flen - fo - bo, Bn = rlen - ro - bo, novl = bo;
+		if (PRIM && A + novl + Bn < 0) {	// assembler.c:146-150: nothing is left of the pair
+			status = PAMD_ST_NOALGN;
+			best = 0.0;
+			bo = -1;	// (the record carries no overlap, as the general kernel's)
+			break;
+		}
 		STOP(3);
 		MARK("rotate+alloc");
 		// Rotate the prefetched registers in BEFORE this pair's stores are issued (vmcnt is one in-order queue for
@@ -719,9 +1316,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		settle(cur);
 		rotated = true;
 
-		// ---- merge (assembler.c:146-247): no offsets, so df = flen - bo >= 0 and dr = rlen - bo >= 0 ----
-		const int A = flen - bo, Bn = rlen - bo, novl = bo;
-		seqlen = A + novl + Bn;	// len - 1; len = seqlen + 1 is in 3 .. 511
+		seqlen = A + novl + Bn;	// len - 1; len = seqlen + 1 is in 3 .. 511 (639)
 		const u64 need = ((u64) seqlen + 15ull) & ~15ull;
 		// (the launch parameters this block needs, read together: the compiler otherwise re-reads each from the kernel
 		// argument segment, one exposed scalar-memory round trip per use, in whichever branch it is used)
@@ -764,7 +1359,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		// per trip, each round by its kind -- wave-uniform: all forward-only, all reverse-only (a shift and an add), or mixed
 		// (the overlap's table index and base, with per-lane selects at the region borders) -- table reads, then the writes.
 		// A lane past the end of the row reads whatever lies there, inside the LDS, and its base is forced to 0.
-		const unsigned lF = lds_addr(wb + FK_F), lR = lds_addr(wb + FK_R), lT = lds_addr(ltab), lN = lds_addr(nts);
+		const unsigned lF = lds_addr(wb + L::F), lR = lds_addr(wb + L::R), lT = lds_addr(ltab), lN = lds_addr(nts);
 		// a pair whose row does not fit stores nothing (it ends as NOSPACE whatever its sums are)
 #ifdef FK_NO_PSTORE	/* experiment: what do the log-p stores cost? (results are wrong) */
 		const int lim = 0;
@@ -774,26 +1369,28 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 #endif
 		// the B-cliff cases (assembler.c:192-207) only when a read ends in a run of quality 2
 		const bool cliff = uf < flen || ur < rlen;
-		const int AF = A + novl;	// forward bases end here
+		const int A0 = PRIM && A < 0 ? 0 : A;	// the overlap region starts here ...
+		const int AF = PRIM ? A0 + novl + (A < 0 ? A : 0) + (Bn < 0 ? Bn : 0) : A + novl;	// ... and ends here (assembler.c:181)
 		const unsigned nN = lN + (unsigned) lane;
 		// (explicitly global: through a generic pointer these would be flat_store, which every later LDS wait waits for as well)
 		gbl_f64 *const gP = (gbl_f64 *) (row_p + lane);
 		MARK("merge");
-		unsigned ef[8], er[8];
-		{
-			const unsigned aF = lF + 2u * (unsigned) lane;					// round r: F[64r + lane] ...
-			const unsigned aR = lR + 2u * (unsigned) (rlen - 1 + A - lane) - 128u * 7u;	// ... and R[rlen - 1 - (64r + lane - A)]
+		constexpr int NR = L::NR;
+		unsigned ef[NR], er[NR];
+		const unsigned aF = lF + 2u * (unsigned) (lane + fo);					// round r: F[fo + 64r + lane] ...
+		const unsigned aR = lR + 2u * (unsigned) (rlen - 1 + A - lane) - 128u * (NR - 1);	// ... and R[rlen - 1 - (64r + lane - A)]
+		{	// all rounds' bases up front: one wait (read trip by trip, a 2x300 pair's merge takes 70 % longer)
 #pragma unroll
-			for (int r = 0; r < 8; r++) {
+			for (int r = 0; r < NR; r++) {
 				ef[r] = lds_read_u16(aF + 128u * r);
-				er[r] = lds_read_u16(aR + 128u * (7 - r));
+				er[r] = lds_read_u16(aR + 128u * (NR - 1 - r));
 			}
 		}
 		// one round: table index and base of output base 64 R + lane
 		auto round = [&](auto rc, unsigned &qi_out, unsigned &nt_out) __attribute__((always_inline)) {
 			constexpr int R = decltype(rc)::value;
 			const unsigned e_f = ef[R], e_r = er[R];
-			if (64 * (R + 1) <= A) {	// all forward-only (assembler.c:162-173)
+			if (64 * (R + 1) <= A0) {	// all forward-only (assembler.c:162-173)
 				qi_out = PAMD_LT_SCORE + (e_f >> 8);
 				nt_out = e_f;
 				return;
@@ -805,7 +1402,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				return;
 			}
 			const int j = 64 * R + lane;
-			const bool inF = j < AF, inR = j >= A;
+			const bool inF = j < AF, inR = j >= A0;
 			const unsigned ab = e_f & e_r;	// low byte: the bases the two reads agree on
 			const unsigned fq = e_f >> 8, rq = e_r >> 8;
 			const bool match = (ab & 0xFFu) != 0;
@@ -823,7 +1420,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			}
 			if (cliff) {
 				asm volatile("; B-cliff");	// (keeps this a branch: as selects it would cost every pair six instructions a round)
-				const bool fmask = j >= uf, rmask = rlen - 1 + A - j >= ur;
+				const bool fmask = j + fo >= uf, rmask = rlen - 1 + A - j >= ur;
 				qi = rmask ? PAMD_LT_SCORE + fq : qi;
 				qi = fmask ? PAMD_LT_SCORE + (rmask ? 47u : rq) : qi;	// slot 47 of the score block holds qual_nn
 			}
@@ -862,8 +1459,13 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			trip(std::integral_constant<int, 2>());
 			if (seqlen > 256) {
 				trip(std::integral_constant<int, 4>());
-				if (seqlen > 384)
+				if (seqlen > 384) {
 					trip(std::integral_constant<int, 6>());
+					if constexpr (LONG) {
+						if (seqlen > 512)
+							trip(std::integral_constant<int, 8>());
+					}
+				}
 			}
 		}
 		wave_sync();
@@ -900,6 +1502,12 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		cur = nxt;
 		settle(cur);
 	}
+	if constexpr (PRIM) {
+		// a deferred pair takes its primer offsets along (what the scan returned, forward | reverse << 16), or the mark that
+		// the primer kernel has to find them
+		if (status == PAMD_ST_DEFER && P.primer_offsets != nullptr && lane == 0)
+			P.primer_offsets[pair] = primers_known ? ((P.fprimer_len > 0 ? (unsigned) fo + 1u : 0u) | ((P.rprimer_len > 0 ? (unsigned) ro + 1u : 0u) << 16)) : 0xFFFFFFFFu;
+	}
 	// park the pair's scalars in lane `slot_idx` of the pending registers (finish64)
 	const bool mine = lane == slot_idx;
 	union {
@@ -916,8 +1524,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	pd.b_hi = put_lane(pd.b_hi, bb.u[1], mine);
 	pd.len_bo = put_lane(pd.len_bo, (unsigned) seqlen | ((unsigned) (bo < 0 ? 0 : bo) << 16), mine);
 	pd.ex_mm = put_lane(pd.ex_mm, (unsigned) examined | ((unsigned) mism << 16), mine);
-	pd.dg_fo = put_lane(pd.dg_fo, (unsigned) degen | (EXACT ? (unsigned) (seqlen - rlen) << 16 : 0u), mine);	// exact sums: + the forward-only bases
-	pd.ro_st = put_lane(pd.ro_st, ((unsigned) status << 16) | ((unsigned) slow << 24) | ((unsigned) (phmin > 63 ? 63 : phmin) << 26), mine);
+	pd.dg_fo = put_lane(pd.dg_fo, (unsigned) degen | (EXACT ? (unsigned) (seqlen - rlen) << 16 : (unsigned) fo << 16), mine);	// exact sums (no offsets there): + the forward-only bases
+	pd.ro_st = put_lane(pd.ro_st, (unsigned) ro | ((unsigned) status << 16) | ((unsigned) slow << 24) | ((unsigned) (phmin > 63 ? 63 : phmin) << 26), mine);
 }
 
 // PHRED: a min_phred module is loaded, the merge tracks the row's smallest log-p (plugin_min_phred.c:8-22)
@@ -929,7 +1537,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 // (one 16-wave workgroup fills a CU's LDS: four waves per SIMD whatever the registers allow, so the compiler is told to
 // spend all 128 vector registers on scheduling instead of saving them for waves that cannot come -- 1 % on a 16 M-pair
 // launch, nothing measurable at 50 M)
-template <int ALGO, bool EXACT, bool PHRED>
+template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM>
 __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const PamdKernelParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	double *ltab = reinterpret_cast<double *>(lds);
@@ -943,9 +1551,20 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 		ltab[i] = P.tables[i];
 	for (unsigned i = tid; i < PAMD_NUM_COUNTERS; i += blockDim.x)
 		lctr[i] = 0;
+	unsigned char *wb = lds + P.lds_primer_off + (size_t) wave * Geo<LONG, t1_bits<ALGO>()>::WAVE_BYTES;	// (the per-wave regions start where the general kernel keeps its primers)
+	unsigned primer_bases = 0;	// PRIM: this lane's base of the forward primer | of the reverse primer << 8 (N past their ends) | << 16: lanes 0..31 the forward, lanes 32..63 the reverse primer's bases 0..31
+	if constexpr (LONG) {
+		// what lies before a read reads as N: the word before the forward N map (seed windows start eight bases early)
+		if (lane < 4) {
+			reinterpret_cast<unsigned *>(wb + Lay<true>::PAD0)[lane] = 0x55555555u;
+			reinterpret_cast<unsigned *>(wb + Lay<true>::PAD1)[lane] = 0xAAAAAAAAu;
+		}
+		if constexpr (PRIM)
+			primer_bases = (lane < P.fprimer_len ? (unsigned) P.primers[lane] : 15u) | ((lane < P.rprimer_len ? (unsigned) P.primers[456 + lane] : 15u) << 8)
+				       | ((lane < 32 ? (lane < P.fprimer_len ? (unsigned) P.primers[lane] : 15u) : (lane - 32 < P.rprimer_len ? (unsigned) P.primers[456 + lane - 32] : 15u)) << 16);
+	}
 	__syncthreads();
 
-	unsigned char *wb = lds + P.lds_primer_off + (size_t) wave * Geo<t1_bits<ALGO>()>::WAVE_BYTES;	// (no primers here: the per-wave regions start where the general kernel keeps them)
 	WaveArena arena;
 	arena.cur = 0;
 	arena.end = 0;
@@ -959,11 +1578,8 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 	unsigned pair = blockIdx.x * (unsigned) nwaves + (unsigned) wave;
 	const unsigned last = n_pairs - 1u;
 	unsigned q = pair < n_pairs ? pair : last;
-	Carry cur;
-	cur.flen_v = P.flen[q];
-	cur.rlen_v = P.rlen[q];
-	cur.f = load_row(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
-	cur.r = load_row(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
+	Carry<LONG> cur;
+	load_pair<LONG>(cur, P, q, lane);
 	settle(cur);
 	int npend = 0;
 	bool deep_dirty = true;	// the first pair clears all four tables
@@ -972,13 +1588,10 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 	while (pair < n_pairs) {
 		const unsigned next = pair + total_waves;
 		q = next < n_pairs ? next : last;
-		Carry nxt;
-		nxt.flen_v = P.flen[q];
-		nxt.rlen_v = P.rlen[q];
-		nxt.f = load_row(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
-		nxt.r = load_row(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
+		Carry<LONG> nxt;
+		load_pair<LONG>(nxt, P, q, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
-		fast_pair<ALGO, EXACT, PHRED>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane, flen, rlen, cur, nxt);
+		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane, flen, rlen, cur, nxt, primer_bases);
 		MARK("loop");
 		npend++;
 		if (npend == 64) {
@@ -1003,27 +1616,44 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 }	// namespace
 
 // ---- host side: does the lean kernel serve this configuration, and its launch ---------------------------------
+// 0: not served (the general kernel takes the launch whole); PAMD_FAST_SHORT: reads of at most 256 bases, no primers or
+// trims; PAMD_FAST_LONG: reads of at most 320 bases; PAMD_FAST_PRIM: the same with `-p` / `-q` primers (at most 24 bases, no
+// penalty) and / or trims.  The two LONG variants serve any-order sums only.
 int pamd_fast_supports(const PamdKernelParams &p) {
-	if (p.smax > 256 || p.post_primers)
-		return 0;
-	if (p.fprimer_len > 0 || p.rprimer_len > 0 || p.ftrim != 0 || p.rtrim != 0 || p.maxoverlap != 0)
+	if (p.post_primers || p.maxoverlap != 0)
 		return 0;
 	if (p.n_pairs > 0x7FFFFFFFull)
 		return 0;	// 32-bit pair indices in the kernel and in the deferred list
-	return 1;
+	const bool clipped = p.fprimer_len > 0 || p.rprimer_len > 0 || p.ftrim != 0 || p.rtrim != 0;
+	if (clipped) {
+		if (p.exact_sums || p.smax > (uint32_t) Lay<true>::MAXLEN || p.primer_penalty != 0.0 || p.fprimer_len > 24 || p.rprimer_len > 24)
+			return 0;
+		if (p.ftrim < 0 || p.rtrim < 0 || p.ftrim > Lay<true>::MAXLEN || p.rtrim > Lay<true>::MAXLEN)
+			return 0;
+		return PAMD_FAST_PRIM;
+	}
+	if (p.smax <= (uint32_t) Lay<false>::MAXLEN)
+		return PAMD_FAST_SHORT;
+	if (p.smax <= (uint32_t) Lay<true>::MAXLEN && !p.exact_sums)
+		return PAMD_FAST_LONG;
+	return 0;
 }
 
 size_t pamd_fast_lds_bytes(const PamdKernelParams &p, int waves_per_wg) {
-	return (size_t) p.lds_primer_off + (size_t) waves_per_wg * (p.algo == PAMD_ALGO_RDP_MLE ? Geo<9>::WAVE_BYTES : Geo<10>::WAVE_BYTES);
+	const bool rdp = p.algo == PAMD_ALGO_RDP_MLE;
+	const size_t wave = pamd_fast_supports(p) == PAMD_FAST_SHORT ? (rdp ? Geo<false, 9>::WAVE_BYTES : Geo<false, 10>::WAVE_BYTES) : (rdp ? Geo<true, 9>::WAVE_BYTES : Geo<true, 10>::WAVE_BYTES);
+	return (size_t) p.lds_primer_off + (size_t) waves_per_wg * wave;
 }
 
 int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg, size_t lds_bytes, void *stream) {
 	const dim3 grid((unsigned) workgroups), block((unsigned) waves_per_wg * 64u);
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	void (*kern)(const PamdKernelParams) = nullptr;
-#define FK_PICK2(A, E) (p.has_min_phred ? pamd_fast_kernel<A, E, true> : pamd_fast_kernel<A, E, false>)
-#define FK_PICK(A) (p.exact_sums ? FK_PICK2(A, true) : FK_PICK2(A, false))
-	switch (p.algo) {
+	const int variant = pamd_fast_supports(p);
+#define FK_PICK2(A, PH) (variant == PAMD_FAST_SHORT ? (p.exact_sums ? pamd_fast_kernel<A, true, PH, false, false> : pamd_fast_kernel<A, false, PH, false, false>) \
+						    : (variant == PAMD_FAST_LONG ? pamd_fast_kernel<A, false, PH, true, false> : pamd_fast_kernel<A, false, PH, true, true>))
+#define FK_PICK(A) (p.has_min_phred ? FK_PICK2(A, true) : FK_PICK2(A, false))
+	switch (variant == 0 ? -1 : p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
 		kern = FK_PICK(PAMD_ALGO_SIMPLE_BAYES);
 		break;
@@ -1046,7 +1676,7 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 		kern = FK_PICK(PAMD_ALGO_STITCH);
 		break;
 	default:
-		pamd_set_error("the lean kernel does not serve algorithm %d", p.algo);
+		pamd_set_error("the lean kernel does not serve algorithm %d in this configuration", p.algo);
 		return PAMD_EINVAL;
 	}
 #undef FK_PICK

@@ -39,6 +39,8 @@ struct PrimerParams {
 	const double *tables;
 	const uint8_t *primers;
 	uint32_t *primer_offsets;
+	const uint32_t *in_list;	// listed launches: the pairs to scan ...
+	const unsigned *in_count;	// ... and how many (device word)
 	uint32_t *redo_list;	// the pairs the fast kernel leaves to the careful one ...
 	unsigned *redo_count;	// ... and how many (device word)
 	unsigned *cursor;	// work counter (device word, zeroed per kernel): the batch goes out sixteen pairs at a time
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(PK_WAVES * 64) void pamd_primer_kernel(const Primer
 	for (int i = tid; i < 912; i += PK_WAVES * 64)
 		lprimers[i] = P.primers[i];
 	__syncthreads();
-	const u64 n_work = listed ? (u64) *P.redo_count : P.n_pairs;
+	const u64 n_work = listed ? (u64) *P.in_count : P.n_pairs;
 	// (work from a counter, not in fixed shares: a read without its primer costs five times one with it)
 	u64 took = 0;
 	unsigned took_left = 0;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(PK_WAVES * 64) void pamd_primer_kernel(const Primer
 	int flen = 0, rlen = 0;
 	u64 pair = 0;
 	if (at < n_work) {
-		pair = listed ? (u64) P.redo_list[at] : at;
+		pair = listed ? (u64) P.in_list[at] : at;
 		flen = P.flen[pair];
 		rlen = P.rlen[pair];
 		if (in_f)
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(PK_WAVES * 64) void pamd_primer_kernel(const Primer
 		const u64 this_pair = pair;
 		at = take();
 		if (at < n_work) {	// the next pair's rows travel while this one is scanned
-			pair = listed ? (u64) P.redo_list[at] : at;
+			pair = listed ? (u64) P.in_list[at] : at;
 			flen = P.flen[pair];
 			rlen = P.rlen[pair];
 			if (in_f)
@@ -387,6 +389,9 @@ __global__ __launch_bounds__(PK_WAVES * 64) void pamd_primer_kernel(const Primer
 		// scan serves both reads (everything that selects the read is wave-uniform).
 		int found[2] = { 0, 0 };
 		bool again = false;
+		// a listed pair whose word is not the "unknown" mark has its offsets already (the lean kernel found them, pamd_fast.hip)
+		if (listed && LOGDOMAIN && P.primer_offsets[this_pair] != 0xFFFFFFFFu)
+			continue;
 #pragma unroll 1
 		for (int which = 0; which < 2; which++) {
 			const int plen = which == 0 ? P.fprimer_len : P.rprimer_len;
@@ -415,7 +420,8 @@ __global__ __launch_bounds__(PK_WAVES * 64) void pamd_primer_kernel(const Primer
 
 }	// namespace
 
-int pamd_launch_primers(const PamdKernelParams &p, int cu_count, void *stream) {
+// list == nullptr: pairs 0 .. n_pairs-1; else the pairs list[0 .. *count - 1] (device memory: the lean kernel's deferred pairs)
+int pamd_launch_primers(const PamdKernelParams &p, int cu_count, void *stream, const uint32_t *list, const unsigned *count) {
 	if (p.n_pairs == 0)
 		return PAMD_OK;
 	if (p.n_pairs > 0xFF000000ull) {	// (the work counter is 32 bits wide)
@@ -436,6 +442,7 @@ int pamd_launch_primers(const PamdKernelParams &p, int cu_count, void *stream) {
 	const size_t want = (p.n_pairs + PK_WAVES - 1) / PK_WAVES;
 	if (blocks > want)
 		blocks = want;
+	const bool listed = list != nullptr;
 	PrimerParams q;
 	q.fwd = p.fwd;
 	q.rev = p.rev;
@@ -444,6 +451,8 @@ int pamd_launch_primers(const PamdKernelParams &p, int cu_count, void *stream) {
 	q.tables = p.tables;
 	q.primers = p.primers;
 	q.primer_offsets = p.primer_offsets;
+	q.in_list = list;
+	q.in_count = count;
 	q.redo_list = p.primer_offsets + p.n_pairs;	// the buffer holds 2 n words + the count (pamd_api.cpp)
 	q.redo_count = reinterpret_cast<unsigned *>(p.primer_offsets + 2 * p.n_pairs);
 	q.cursor = q.redo_count + 1;
@@ -460,17 +469,19 @@ int pamd_launch_primers(const PamdKernelParams &p, int cu_count, void *stream) {
 			pamd_set_error("primer kernel: hipMemsetAsync failed");
 			return PAMD_ENODEVICE;
 		}
-		hipLaunchKernelGGL(pamd_primer_kernel<false>, dim3((unsigned) blocks), dim3(PK_WAVES * 64), 0, st, q, false);
+		hipLaunchKernelGGL(pamd_primer_kernel<false>, dim3((unsigned) blocks), dim3(PK_WAVES * 64), 0, st, q, listed);
 	} else {
 		if (hipMemsetAsync(q.redo_count, 0, 2 * sizeof(unsigned), st) != hipSuccess) {
 			pamd_set_error("primer kernel: hipMemsetAsync failed");
 			return PAMD_ENODEVICE;
 		}
-		hipLaunchKernelGGL(pamd_primer_kernel<true>, dim3((unsigned) blocks), dim3(PK_WAVES * 64), 0, st, q, false);
+		hipLaunchKernelGGL(pamd_primer_kernel<true>, dim3((unsigned) blocks), dim3(PK_WAVES * 64), 0, st, q, listed);
 		if (hipMemsetAsync(q.cursor, 0, sizeof(unsigned), st) != hipSuccess) {
 			pamd_set_error("primer kernel: hipMemsetAsync failed");
 			return PAMD_ENODEVICE;
 		}
+		q.in_list = q.redo_list;
+		q.in_count = q.redo_count;
 		hipLaunchKernelGGL(pamd_primer_kernel<false>, dim3(8), dim3(PK_WAVES * 64), 0, st, q, true);	// next to nothing to do
 	}
 #ifdef PK_DEBUG

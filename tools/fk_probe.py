@@ -48,6 +48,13 @@ for mode in ((args.only,) if args.only else ("two-kernel", "general")):
         torch.cuda.synchronize()
         best = min(best, asm.last_kernel_ms())
     asm.check_overflow()
+    if mode == "two-kernel":
+        import ctypes as C
+        from pandaseq_amd import _lib
+        ph = (C.c_ulonglong * 10)()
+        _lib.lib().pamd_debug_phase_cycles(asm._h, ph, 1)
+        why = [v // args.reps for v in ph]
+        print("deferred because: domain %d, k-mer lost %d, score too close %d, many candidates %d, LOWQ guard %d, primer scan %d, clipped overlap %d; (debug builds) reads settled block by block: %d without, %d with a summed alignment" % (why[0], why[1], why[2], why[3], why[4], why[6], why[7], why[8], why[9]))
     print(f"{mode:11s} {best:9.3f} ms  {n / best / 1e3:8.1f} M pairs/s  deferred {asm.last_deferred()}  launch {asm.last_launch_info()}  arena {int(b.cursor.item())}")
     if not args.no_compare:
         res = b.results_numpy()
