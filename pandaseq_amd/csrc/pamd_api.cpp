@@ -567,15 +567,25 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 		if (pear && -a->pear_random_base > p.many_all)
 			p.many_all = -a->pear_random_base;
 	}
-	// the lean kernel's primer scan (pamd_fast.hip): the primers as 4-bit masks, and what a disagreement costs at least
+	// the lean kernel's primer scan (pamd_fast.hip): the primers as 2-bit codes of the reads' code streams, and what a
+	// disagreement costs at least
 	for (int which = 0; which < 2; which++) {
 		const int plen = which == 0 ? a->fprimer_len : a->rprimer_len;
 		const uint8_t *pr = a->primers + (which == 0 ? 0 : 456);
-		for (int w = 0; w < 3; w++) {
-			uint32_t m = 0;
-			for (int k = 0; k < 8; k++)
-				m |= (uint32_t) (8 * w + k < plen ? (pr[8 * w + k] & 0xFu) : 0xFu) << (4 * k);
-			p.primer_masks[which].pm[w] = m;
+		for (int w = 0; w < 2; w++) {
+			uint32_t code = 0, counts = 0;
+			for (int k = 0; k < 16; k++) {
+				const int x = 16 * w + k;
+				const unsigned nt = x < plen ? (pr[x] & 0xFu) : 15u;
+				const unsigned c = nt == 8 ? 3u : (nt == 4 ? 2u : (nt == 2 ? 1u : 0u));	// misc.h:41
+				const unsigned stored = which == 0 ? c : (((c & 1u) << 1) | (c >> 1));	// the reverse stream swaps the two bits
+				if (nt == 1 || nt == 2 || nt == 4 || nt == 8) {
+					code |= stored << (2 * k);
+					counts |= 2u << (2 * k);
+				}
+			}
+			p.primer_codes[which].code[w] = code;
+			p.primer_codes[which].counts[w] = counts;
 		}
 	}
 	p.primer_qthr = 22;

@@ -62,7 +62,7 @@ struct Lay<true> {
 	// (a pad word before the forward N map: what lies before a read reads as N; see the kernel's prologue)
 	static constexpr unsigned F = 0, R = 640, FC = 1280, RC = 1376, PAD0 = 1472, FN = 1488, RN = 1584, PAD1 = 1680, FLAGS = 1696, T1 = 2080;
 	static constexpr unsigned NT = T1;				// merged-nt staging: up to 640 + 64 bytes
-	static constexpr unsigned NIBF = T1, NIBR = T1 + 192, SCR = T1 + 384;	// primer scan: 4-bit nt streams, 512 bytes of f64 terms
+	static constexpr unsigned CAREF = T1 + 16, CARER = T1 + 128, SCR = T1 + 256;	// primer scan: "counts" maps (96 bytes each), 512 bytes of f64 terms
 	static constexpr int BPL = 5;
 	static constexpr int MAXLEN = 320;
 	static constexpr int NR = 10;
@@ -229,15 +229,15 @@ __device__ __forceinline__ void pack4(unsigned x, unsigned y, int cnt, unsigned 
 	nmap = FORWARD ? nb : nb << 1;
 }
 
-// the 4-bit nt codes of four bases as 16 bits; a base whose quality is below qthr reads as N (the primer scan's filter
-// counts disagreements at qualities of at least qthr only)
-__device__ __forceinline__ unsigned nibbles4(unsigned n4, unsigned q4, unsigned qadd, int cnt) {
-	const unsigned ge = ((q4 & 0x7F7F7F7Fu) + qadd) & 0x80808080u;	// 0x80 where quality >= qthr (qadd = (0x80 - qthr) in every byte)
-	const unsigned lowm = ((ge >> 7) ^ 0x01010101u) * 0x0Fu;
-	const unsigned past = ~(unsigned) ((0xFFFFFFFFull << (8 * cnt)) >> 32);	// bases past the read's end agree with anything as well
-	unsigned x = (n4 | lowm | past) & 0x0F0F0F0Fu;
-	x = (x | (x >> 4)) & 0x00FF00FFu;
-	return (x | (x >> 8)) & 0xFFFFu;
+// which of four bases count in the primer scan's filter (bit 2k+1): a definite base of quality >= qthr that exists; an N,
+// a low quality or the end of the read agrees with anything there
+__device__ __forceinline__ unsigned care4(unsigned n4, unsigned q4, unsigned qadd, int cnt) {
+	const unsigned ge = (((q4 & 0x7F7F7F7Fu) + qadd) >> 7) & 0x01010101u;	// 1 where quality >= qthr (qadd = (0x80 - qthr) in every byte)
+	const unsigned isn = (n4 & (n4 >> 1) & (n4 >> 2) & (n4 >> 3)) & 0x01010101u;	// 1 where nt == 15
+	const unsigned in1 = (unsigned) ((0x01010101ull << (8 * cnt)) >> 32);	// 1 in the bytes of the bases that exist
+	const unsigned f = ge & ~isn & in1;
+	const unsigned y = f | (f >> 6);
+	return ((y | (y >> 12)) & 0x55u) << 1;
 }
 
 __device__ __forceinline__ unsigned is2_mask(unsigned q4) {	// bit k: quality byte k == 2
@@ -263,7 +263,7 @@ __device__ __forceinline__ int stage8(const uint4 v, const int len, int lane, un
 		reinterpret_cast<uint16_t *>(wb + (FORWARD ? L::FC : L::RC))[lane] = (uint16_t) (ca | (cb << 8));
 		reinterpret_cast<uint16_t *>(wb + (FORWARD ? L::FN : L::RN))[lane] = (uint16_t) (na | (nb << 8));
 		if (PRIM)
-			reinterpret_cast<unsigned *>(wb + (FORWARD ? L::NIBF : L::NIBR))[lane] = nibbles4(n4a, q4a, qadd, c0) | (nibbles4(n4b, q4b, qadd, c1) << 16);
+			reinterpret_cast<uint16_t *>(wb + (FORWARD ? L::CAREF : L::CARER))[lane] = (uint16_t) (care4(n4a, q4a, qadd, c0) | (care4(n4b, q4b, qadd, c1) << 8));
 	}
 	// the usual read does not end in quality 2: two lane reads settle it
 	const int li = (len - 1) >> 3, lb = (len - 1) & 7;
@@ -294,22 +294,24 @@ __device__ __forceinline__ int stage8(const uint4 v, const int len, int lane, un
 // (4) the few that are left are summed exactly, in the reference's order, and compared as the reference compares them.
 // Returns -1 when it cannot settle the read that cheaply (no good alignment, a bound too loose to filter, too many left).
 
-// disagreements between the primer's first 8 * NW bases (nibble masks pm; 0xF past its end and for N) and the read at s
+// disagreements that count -- the read's base is definite and of quality >= qthr, the primer's a single base -- between the
+// primer's first 16 * NW bases (2-bit codes pc, "counts" maps pk: bit 2k+1) and the read at s
 template <int NW>
-__device__ __forceinline__ int nib_mismatches(unsigned nib_addr, int s, const unsigned (&pm)[3]) {
-	const unsigned a = nib_addr + 4u * (unsigned) (s >> 3), sh = 4u * ((unsigned) s & 7u);
-	unsigned d[NW + 1];
+__device__ __forceinline__ int code_mismatches(unsigned code_addr, unsigned care_addr, int s, const unsigned (&pc)[2], const unsigned (&pk)[2]) {
+	const unsigned o = 4u * (unsigned) (s >> 4), sh = 2u * ((unsigned) s & 15u);
+	unsigned c[NW + 1], k[NW + 1];
 #pragma unroll
-	for (int i = 0; i <= NW; i++)
-		d[i] = lds_read_u32(a + 4u * i);
-	unsigned agree = 0;
+	for (int i = 0; i <= NW; i++) {
+		c[i] = lds_read_u32(code_addr + o + 4u * i);
+		k[i] = lds_read_u32(care_addr + o + 4u * i);
+	}
+	int mm = 0;
 #pragma unroll
 	for (int i = 0; i < NW; i++) {
-		const unsigned t = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh) & pm[i];
-		const unsigned u = t | (t >> 1);
-		agree += (unsigned) __popc((u | (u >> 2)) & 0x11111111u);
+		const unsigned t = __builtin_amdgcn_alignbit(c[i + 1], c[i], sh) ^ pc[i];
+		mm += __popc((t | (t << 1)) & __builtin_amdgcn_alignbit(k[i + 1], k[i], sh) & pk[i]);
 	}
-	return 8 * NW - (int) agree;
+	return mm;
 }
 
 // the sum of one alignment's terms in primer order (offset.c:79-87): lanes look the terms up, lane 0 adds them
@@ -344,37 +346,40 @@ __device__ __forceinline__ double primer_exact(const double *ltab, unsigned char
 }
 
 // ---- the usual read, five alignments per lane ----
-// disagreements (at qualities >= qthr) among the primer's first sixteen bases for this lane's alignments s = 5 * lane + j, five
-// bits each (31: no such alignment); s0: the first alignment with at most one (-1: none)
-__device__ __forceinline__ unsigned primer_tier1(unsigned nib_addr, int nal, int lane, unsigned pm0, unsigned pm1, int &s0) {
-	const unsigned bit = 20u * (unsigned) lane;
-	const unsigned a = nib_addr + 4u * (bit >> 5), sh = bit & 31u;
-	const unsigned d0 = lds_read_u32(a), d1 = lds_read_u32(a + 4u), d2 = lds_read_u32(a + 8u), d3 = lds_read_u32(a + 12u);
-	const unsigned x0 = __builtin_amdgcn_alignbit(d1, d0, sh), x1 = __builtin_amdgcn_alignbit(d2, d1, sh), x2 = __builtin_amdgcn_alignbit(d3, d2, sh);
+// disagreements that count among the primer's first sixteen bases for this lane's alignments s = 5 * lane + j, five bits each
+// (31: no such alignment); s0: the first alignment with at most one (-1: none)
+__device__ __forceinline__ unsigned primer_tier1(unsigned code_addr, unsigned care_addr, int nal, int lane, unsigned pc0, unsigned pk0, int &s0) {
+	const unsigned bit = 10u * (unsigned) lane;
+	const unsigned o = 4u * (bit >> 5), sh = bit & 31u;
+	const unsigned c0 = lds_read_u32(code_addr + o), c1 = lds_read_u32(code_addr + o + 4u), c2 = lds_read_u32(code_addr + o + 8u);
+	const unsigned k0 = lds_read_u32(care_addr + o), k1 = lds_read_u32(care_addr + o + 4u), k2 = lds_read_u32(care_addr + o + 8u);
+	const unsigned x0 = __builtin_amdgcn_alignbit(c1, c0, sh), x1 = __builtin_amdgcn_alignbit(c2, c1, sh);
+	const unsigned y0 = __builtin_amdgcn_alignbit(k1, k0, sh), y1 = __builtin_amdgcn_alignbit(k2, k1, sh);
 	unsigned packed = 0;
-	int first = 0x7FFFFFFF;
+	int firstj = 7;
 #pragma unroll
-	for (int j = 0; j < 5; j++) {
-		const unsigned w0 = j == 0 ? x0 : __builtin_amdgcn_alignbit(x1, x0, 4u * j), w1 = j == 0 ? x1 : __builtin_amdgcn_alignbit(x2, x1, 4u * j);
-		const unsigned t0 = w0 & pm0, t1 = w1 & pm1;
-		const unsigned u0 = t0 | (t0 << 1), u1 = t1 | (t1 << 1);
-		const unsigned v0 = u0 | (u0 << 2), v1 = u1 | (u1 << 2);	// bit 3 of a nibble: read and primer base agree
-		int mm = 16 - __popc((v0 & 0x88888888u) | ((v1 & 0x88888888u) >> 1));
+	for (int j = 4; j >= 0; j--) {
+		const unsigned w = j == 0 ? x0 : __builtin_amdgcn_alignbit(x1, x0, 2u * j), kk = j == 0 ? y0 : __builtin_amdgcn_alignbit(y1, y0, 2u * j);
+		const unsigned t = w ^ pc0;
+		int mm = __popc((t | (t << 1)) & kk & pk0);
 		mm = 5 * lane + j < nal ? mm : 31;
-		packed |= (unsigned) mm << (5 * j);
-		const u64 c = ballot(mm <= 1);
-		if (c != 0) {
-			const int cand = 5 * __builtin_ctzll(c) + j;
-			first = cand < first ? cand : first;
-		}
+		packed = (packed << 5) | (unsigned) mm;
+		firstj = mm <= 1 ? j : firstj;
 	}
-	s0 = first == 0x7FFFFFFF ? -1 : first;
+	const u64 any = ballot(firstj != 7);
+	s0 = -1;
+	if (any != 0) {
+		const int l = __builtin_ctzll(any);
+		s0 = 5 * l + __builtin_amdgcn_readlane(firstj, l);
+	}
 	return packed;
 }
 
-// the exact sums (offset.c:79-87) of one alignment of each read at once: lanes 0..31 look up the terms of the forward read's
-// alignment s0f (lane x: primer base x), lanes 32..63 those of the reverse read's s0r; lanes 0 and 32 add them in primer order
-__device__ __forceinline__ void primer_exact_joint(const double *ltab, unsigned char *wb, int s0f, int s0r, int fplen, int rplen, unsigned pbj, int lane, double &sumf, double &sumr) {
+// The sums of one alignment of each read at once, in ANY order (|error| < 1e-12: good for a bound and for a verdict with
+// a margin; values that are compared with each other are summed in the reference's order, primer_exact): lanes 0..31 look up
+// the terms of the forward read's alignment s0f (lane x: primer base x), lanes 32..63 those of the reverse read's s0r; no
+// LDS round trip but the two lookups
+__device__ __forceinline__ void primer_sums_any_order(const double *ltab, unsigned char *wb, int s0f, int s0r, int fplen, int rplen, unsigned pbj, int lane, double &sumf, double &sumr) {
 	typedef Lay<true> L;
 	const int half = lane >> 5, x = lane & 31;
 	const int s0 = half ? s0r : s0f, plen = half ? rplen : fplen;
@@ -384,69 +389,74 @@ __device__ __forceinline__ void primer_exact_joint(const double *ltab, unsigned 
 		const double v = ltab[(((e & pbj & 0xFu) != 0) ? PAMD_LT_SCORE : PAMD_LT_ERR) + (e >> 8)];
 		t = pbj != 15u ? v : 0.0;
 	}
-	double *scr = reinterpret_cast<double *>(wb + L::SCR);
-	wave_sync();
-	scr[lane] = t;
-	wave_sync();
-	double acc = 0.0;
-	if (x == 0) {
-		const double *q = scr + 32 * half;
-		const int n = fplen > rplen ? fplen : rplen;
-		for (int c = 0; c < n; c += 8) {
-			const double2 v0 = *reinterpret_cast<const double2 *>(q + c), v1 = *reinterpret_cast<const double2 *>(q + c + 2);
-			const double2 v2 = *reinterpret_cast<const double2 *>(q + c + 4), v3 = *reinterpret_cast<const double2 *>(q + c + 6);
-			acc += v0.x;
-			acc += v0.y;
-			acc += v1.x;
-			acc += v1.y;
-			acc += v2.x;
-			acc += v2.y;
-			acc += v3.x;
-			acc += v3.y;
-		}
-	}
-	sumf = lane_f64(acc, 0);
-	sumr = lane_f64(acc, 32);
+	t += dpp_f64<0xB1>(t);	// quad_perm:[1,0,3,2]
+	t += dpp_f64<0x4E>(t);	// quad_perm:[2,3,0,1]
+	t += dpp_f64<0x141>(t);	// row_half_mirror
+	t += dpp_f64<0x140>(t);	// row_mirror: every lane holds its row's sum
+	sumf = lane_f64(t, 0) + lane_f64(t, 16);
+	sumr = lane_f64(t, 32) + lane_f64(t, 48);
 }
 
-// With the alignment s0 summed: if no other alignment can reach its value, the read is settled (>= 0: what the scan returns);
-// -1: more work (primer_settle)
-__device__ __forceinline__ int primer_shortcut(unsigned packed, int s0, double sum0, int len, int plen, double thr, double inv_err_t, int lane) {
+// With the alignment s0 summed: the alignments that could still reach its value -- none, usually -- are summed as well and
+// compared as offset.c:72-77 compares them (before exp).  >= 0: what the scan returns; -1: more work (primer_settle)
+__device__ __forceinline__ int primer_shortcut(const double *ltab, unsigned char *wb, unsigned row_off, unsigned pbase, unsigned packed, int s0, double sum0, int len, int plen, double thr, double inv_err_t, int lane) {
 	const int n0 = s0 + plen + 1;
 	const double kv = sum0 * (double) (1.0f / (float) n0) * (1.0 + 1e-5);	// a shade below its value: a bound may be anything an alignment reaches
 	const double bound = kv > thr ? kv : thr;
 	// alignment s may hold K(s) = floor((bound * (s + plen + 1) - 1e-6) / err_t) disagreements and still reach the bound
+	// (taken at the lane's last alignment for all five: a budget may be too large, never too small)
 	const double xs = bound * inv_err_t * 1.0001, x0 = (double) (plen + 1) * xs - 1e-6 * inv_err_t + 0.001;	// all >= 0
 	if (!((double) (len - plen - 1) * xs + x0 < 8.0))
 		return -1;
-	const double y = (double) (5 * lane) * xs + x0;
-	const int s0l = s0 / 5, s0j = s0 - 5 * s0l;
-	int nleft = 0;
-	bool s0_left = false;
-#pragma unroll
-	for (int j = 0; j < 5; j++) {
-		const int K = (int) (y + (double) j * xs);
-		const u64 left = ballot((int) ((packed >> (5 * j)) & 31u) <= K);
-		nleft += __popcll(left);
-		if (j == s0j)
-			s0_left = ((left >> s0l) & 1ull) != 0;
-	}
-	if (nleft == 1 && s0_left) {
+	const int K = (int) ((double) (5 * lane + 4) * xs + x0);
+	u64 l0 = ballot((int) (packed & 31u) <= K), l1 = ballot((int) ((packed >> 5) & 31u) <= K), l2 = ballot((int) ((packed >> 10) & 31u) <= K);
+	u64 l3 = ballot((int) ((packed >> 15) & 31u) <= K), l4 = ballot((int) ((packed >> 20) & 31u) <= K);
+	const int nleft = __popcll(l0) + __popcll(l1) + __popcll(l2) + __popcll(l3) + __popcll(l4);
+	if (nleft == 1) {	// the usual read: only the alignment already summed is left (it always is: it reaches the bound it set)
 		if (sum0 > (thr + 1e-9) * (double) n0)
 			return n0;
 		if (sum0 < (thr - 1e-9) * (double) n0)
 			return 0;
+		return -1;
 	}
-	return -1;
+	if (nleft > 4)
+		return -1;
+	double best = thr;
+	int besti = 0;
+	bool close = false;
+	for (int it = 0; it < nleft; it++) {	// in ascending order
+		const int c0 = l0 != 0 ? 5 * __builtin_ctzll(l0) : 0x7FFFFFF0, c1 = l1 != 0 ? 5 * __builtin_ctzll(l1) + 1 : 0x7FFFFFF0, c2 = l2 != 0 ? 5 * __builtin_ctzll(l2) + 2 : 0x7FFFFFF0;
+		const int c3 = l3 != 0 ? 5 * __builtin_ctzll(l3) + 3 : 0x7FFFFFF0, c4 = l4 != 0 ? 5 * __builtin_ctzll(l4) + 4 : 0x7FFFFFF0;
+		const int m01 = c0 < c1 ? c0 : c1, m23 = c2 < c3 ? c2 : c3, m03 = m01 < m23 ? m01 : m23, s = m03 < c4 ? m03 : c4;
+		if (s == c0)
+			l0 &= l0 - 1;
+		else if (s == c1)
+			l1 &= l1 - 1;
+		else if (s == c2)
+			l2 &= l2 - 1;
+		else if (s == c3)
+			l3 &= l3 - 1;
+		else
+			l4 &= l4 - 1;
+		const double sum = primer_exact(ltab, wb, row_off, s, pbase, plen, lane);
+		const double v = sum / (double) (s + plen + 1);
+		if (v > best) {	// strict: the earliest index wins ties (offset.c:74)
+			close |= v - best <= 4.5e-16;	// their exponentials might not differ: the reference would keep the earlier one
+			best = v;
+			besti = s + plen + 1;
+		}
+	}
+	return close ? -1 : besti;
 }
 
 // ---- every other read: blocks of 64 alignments ----
-// pm0..2: nibble masks of the primer's bases 0..7, 8..15, 16..23 (host-built); thr: plen * threshold (offset.c:59, before exp);
-// s0, sum0: an alignment already summed (s0 < 0: none)
-__device__ __forceinline__ int primer_settle(const double *ltab, unsigned char *wb, unsigned row_off, unsigned nib_off, int len, unsigned pbase, unsigned pm0, unsigned pm1, unsigned pm2, int plen, double thr, double inv_err_t, int lane, int s0, double sum0) {
-	const unsigned pm[3] = { pm0, pm1, pm2 };
+// pc0, pc1 / pk0, pk1: the primer's bases 0..15, 16..31 as 2-bit codes / which of them count (host-built); thr: plen * threshold
+// (offset.c:59, before exp);
+// s0, sum0: an alignment already summed, in any order: good for the bound only (s0 < 0: none)
+__device__ __forceinline__ int primer_settle(const double *ltab, unsigned char *wb, unsigned row_off, unsigned code_off, unsigned care_off, int len, unsigned pbase, unsigned pc0, unsigned pc1, unsigned pk0, unsigned pk1, int plen, double thr, double inv_err_t, int lane, int s0, double sum0) {
+	const unsigned pc[2] = { pc0, pc1 }, pk[2] = { pk0, pk1 };
 	const int nal = len - plen;	// alignments 0 .. nal-1 are judged (at index s + plen <= len - 1, offset.c:70-77)
-	const unsigned na = lds_addr(wb + nib_off);
+	const unsigned ca = lds_addr(wb + code_off), ka = lds_addr(wb + care_off);
 	// the bound: the value of that alignment, or the threshold every alignment has to beat
 	double bound = thr;
 	const int n0 = s0 + plen + 1;
@@ -472,7 +482,7 @@ __device__ __forceinline__ int primer_settle(const double *ltab, unsigned char *
 			left[k] = valid;
 		} else {
 			const int K = (int) ((double) s * xs + x0);
-			const int mm = plen > 16 ? nib_mismatches<3>(na, s, pm) : (plen > 8 ? nib_mismatches<2>(na, s, pm) : nib_mismatches<1>(na, s, pm));
+			const int mm = plen > 16 ? code_mismatches<2>(ca, ka, s, pc, pk) : code_mismatches<1>(ca, ka, s, pc, pk);
 			left[k] = ballot(mm <= K) & valid;
 		}
 		nleft += __popcll(left[k]);
@@ -503,7 +513,7 @@ __device__ __forceinline__ int primer_settle(const double *ltab, unsigned char *
 			while (m != 0) {
 				const int l = __builtin_ctzll(m), s = 64 * k + l;
 				m &= m - 1;
-				const double sum = s == s0 ? sum0 : primer_exact(ltab, wb, row_off, s, pbase, plen, lane);
+				const double sum = primer_exact(ltab, wb, row_off, s, pbase, plen, lane);
 				const double q = sum / (double) (s + plen + 1);
 				if (lane == l) {
 					v = q;
@@ -905,16 +915,16 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				unsigned pkf = 0, pkr = 0;
 				int s0f = -1, s0r = -1;
 				if (rf == -2)
-					pkf = primer_tier1(lds_addr(wb + L::NIBF), flen - fpl, lane, P.primer_masks[0].pm[0], P.primer_masks[0].pm[1], s0f);
+					pkf = primer_tier1(lds_addr(wb + L::FC), lds_addr(wb + L::CAREF), flen - fpl, lane, P.primer_codes[0].code[0], P.primer_codes[0].counts[0], s0f);
 				if (rr == -2)
-					pkr = primer_tier1(lds_addr(wb + L::NIBR), rlen - rpl, lane, P.primer_masks[1].pm[0], P.primer_masks[1].pm[1], s0r);
+					pkr = primer_tier1(lds_addr(wb + L::RC), lds_addr(wb + L::CARER), rlen - rpl, lane, P.primer_codes[1].code[0], P.primer_codes[1].counts[0], s0r);
 				double sumf = 0.0, sumr = 0.0;
 				if (s0f >= 0 || s0r >= 0)
-					primer_exact_joint(ltab, wb, s0f, s0r, fpl, rpl, (primer_bases >> 16) & 0xFFu, lane, sumf, sumr);
+					primer_sums_any_order(ltab, wb, s0f, s0r, fpl, rpl, (primer_bases >> 16) & 0xFFu, lane, sumf, sumr);
 				if (rf == -2)
-					rf = s0f >= 0 ? primer_shortcut(pkf, s0f, sumf, flen, fpl, thr_f, inv_err_t, lane) : -1;
+					rf = s0f >= 0 ? primer_shortcut(ltab, wb, L::F, primer_bases & 0xFFu, pkf, s0f, sumf, flen, fpl, thr_f, inv_err_t, lane) : -1;
 				if (rr == -2)
-					rr = s0r >= 0 ? primer_shortcut(pkr, s0r, sumr, rlen, rpl, thr_r, inv_err_t, lane) : -1;
+					rr = s0r >= 0 ? primer_shortcut(ltab, wb, L::R, (primer_bases >> 8) & 0xFFu, pkr, s0r, sumr, rlen, rpl, thr_r, inv_err_t, lane) : -1;
 				// the reads that did not settle (one copy of the code: everything that selects the read is wave-uniform);
 				// the reverse primer is looked for only in pairs that have the forward one
 #pragma unroll 1
@@ -925,8 +935,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 #ifdef PAMD_FK_DEBUG
 					note(P, (which == 0 ? s0f : s0r) < 0 ? 8 : 9, lane);
 #endif
-					const PamdPrimerMasks &pk = P.primer_masks[which];
-					const int r = primer_settle(ltab, wb, which == 0 ? L::F : L::R, which == 0 ? L::NIBF : L::NIBR, which == 0 ? flen : rlen, (which == 0 ? primer_bases : primer_bases >> 8) & 0xFFu, pk.pm[0], pk.pm[1], pk.pm[2], which == 0 ? fpl : rpl, which == 0 ? thr_f : thr_r, inv_err_t, lane, which == 0 ? s0f : s0r, which == 0 ? sumf : sumr);
+					const PamdPrimerCodes &pk = P.primer_codes[which];
+					const int r = primer_settle(ltab, wb, which == 0 ? L::F : L::R, which == 0 ? L::FC : L::RC, which == 0 ? L::CAREF : L::CARER, which == 0 ? flen : rlen, (which == 0 ? primer_bases : primer_bases >> 8) & 0xFFu, pk.code[0], pk.code[1], pk.counts[0], pk.counts[1], which == 0 ? fpl : rpl, which == 0 ? thr_f : thr_r, inv_err_t, lane, which == 0 ? s0f : s0r, which == 0 ? sumf : sumr);
 					if (which == 0)
 						rf = r;
 					else
@@ -1433,6 +1443,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			mism += __popcll(ballot(inF) & ballot(inR) & ~ballot(match));
 		};
 		// two rounds per trip, straight-line; trips nest so that nothing but the accumulators lives across them
+		// (four rounds per trip, their table reads in flight together: no faster on 2x250, slower on 2x300 -- registers)
 		auto trip = [&](auto r0c) __attribute__((always_inline)) {
 			constexpr int R0 = decltype(r0c)::value;
 			unsigned qi[2], ntv[2];
