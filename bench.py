@@ -12,6 +12,7 @@ step.  Rank 0 prints ONE JSON line.
            --master-port 29500 bench.py --gpus 8 --steps 5 --warmup 1
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -41,7 +42,7 @@ def parse():
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (0 = the config's size)")
     ap.add_argument("--chunk-pairs", type=int, default=0, help="pairs per launch (0 = the whole shard when its output fits in HBM beside "
                                                                 "its input, else the largest chunk whose two output arenas do)")
-    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall-clock target of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=18.0, help="wall-clock target of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sums", choices=["fast", "exact"], default="fast",
                     help="fast: quality / pear+rdp scores summed in any order with exactness guards on every decision "
@@ -93,7 +94,7 @@ def main():
 
     import pandaseq_amd as pa
     from pandaseq_amd import _lib, synth
-    from pandaseq_amd.stats import allreduce_counters
+    from pandaseq_amd.stats import allreduce_counters, format_stat_block
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -264,6 +265,9 @@ def main():
             "launch": asm.last_launch_info(),
         },
         "stat": {k: ctr[k] for k in ("count", "ok", "noalgn", "lowq", "badr", "nofp", "norp", "slow")},
+        # the STAT lines a reference worker prints at the end of its input (pool.c:86-104), from the counters of one step summed
+        # over the ranks: the whole block as one checksum, so that an N-rank run can be held against a single run of the same pairs
+        "stat_block_sha1": hashlib.sha1(format_stat_block(ctr, has_forward_primer=cfg_index == 2 and not args.primers_after, has_reverse_primer=cfg_index == 2 and not args.primers_after).encode()).hexdigest(),
         "roofline": {
             "bound": "hbm",
             "kernel": ("pamd_fast_kernel + pamd_assemble_kernel over the pairs it deferred (both inside the HIP events)" if asm.last_deferred() >= 0
@@ -284,37 +288,58 @@ def main():
         out["stat"]["rejected"] = ctr["rejected"][:2]
 
     # ---- CPU baseline: the oracle (a scalar C port of the reference path) on this host's cores ----
+    # pool.c:140-167 gives every thread an assembler of its own over its share of the input; so does this leg (po_bench_mt:
+    # pinned pthreads, each over a private copy of its slice that it allocated and first touched itself), at 1, 8, 32, 64,
+    # 128 and all CPUs of the affinity mask.  `value` is the best of them, `cores` the thread count that reached it.
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import pyoracle as po
-        threads = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
+        quota = None
+        try:
+            q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = None if q == "max" else float(q) / float(period)
+        except (OSError, ValueError):
+            pass
+        effective = min(affinity, quota) if quota else affinity
         ocfg = oracle_config(po, synth, cfg_index, args.algo, args.primers_after)
-        probe = 20000
-        hf = batch.fwd[:probe].cpu().numpy()
-        hr = batch.rev[:probe].cpu().numpy()
-        hfl = batch.flen[:probe].cpu().numpy().view(np.uint16)
-        hrl = batch.rlen[:probe].cpu().numpy().view(np.uint16)
-        c0 = time.perf_counter()
-        po.assemble_batch(ocfg, hf, hr, hfl, hrl, want_seq=False, threads=1)
-        rate1 = probe / (time.perf_counter() - c0)
-        sample = int(min(n, max(probe, rate1 * threads * args.cpu_seconds)))
-        sample = min(sample, 4_000_000)
-        hf = batch.fwd[:sample].cpu().numpy()
-        hr = batch.rev[:sample].cpu().numpy()
-        hfl = batch.flen[:sample].cpu().numpy().view(np.uint16)
-        hrl = batch.rlen[:sample].cpu().numpy().view(np.uint16)
-        c0 = time.perf_counter()
-        o_res, _, _, o_ctr = po.assemble_batch(ocfg, hf, hr, hfl, hrl, want_seq=True if sample <= 200_000 else False, threads=threads)
-        cpu_s = time.perf_counter() - c0
-        # the sample doubles as an at-scale parity check of statuses and overlaps
+        pool_n = int(min(n, 4_000_000))
+        hf = batch.fwd[:pool_n].cpu().numpy()
+        hr = batch.rev[:pool_n].cpu().numpy()
+        hfl = batch.flen[:pool_n].cpu().numpy().view(np.uint16)
+        hrl = batch.rlen[:pool_n].cpu().numpy().view(np.uint16)
+        probe = min(20000, pool_n)
+        secs, _, _ = po.bench_mt(ocfg, hf[:probe], hr[:probe], hfl[:probe], hrl[:probe], 1)
+        rate1 = probe / secs
+        ladder = sorted({t for t in (1, 8, 32, 64, 128, affinity) if t <= affinity})
+        per_run = args.cpu_seconds / len(ladder)
+        scaling, best, o_res, sample = [], None, None, 0
+        for t in ladder:
+            m = int(min(pool_n, max(probe, rate1 * min(t, effective) * per_run)))
+            secs, res_t, ctr_t = po.bench_mt(ocfg, hf[:m], hr[:m], hfl[:m], hrl[:m], t)
+            rate = m / secs
+            scaling.append({"threads": t, "pairs": m, "seconds": secs, "pairs_per_s": rate, "efficiency_vs_1": rate / (rate1 * t)})
+            if best is None or rate > best["pairs_per_s"]:
+                best = scaling[-1]
+            if m > sample:
+                o_res, sample = res_t, m
+        # the largest sample doubles as an at-scale parity check of statuses and overlaps
         dres = batch.results[:sample].cpu().numpy().view(_lib.RESULT_DTYPE).reshape(-1)
         same = bool((dres["status"] == o_res["status"]).all() and (dres["overlap"][o_res["status"] == 0] == o_res["overlap"][o_res["status"] == 0]).all())
+        eff_at_cores = best["pairs_per_s"] / (rate1 * min(best["threads"], effective))
         out["cpu_baseline"] = {
-            "value": sample / cpu_s,
+            "value": best["pairs_per_s"],
             "unit": "pairs/s",
-            "cores": threads,
+            "cores": best["threads"],
             "kind": "port",
-            "sample": f"first {sample} pairs of the same batch, oracle C port, {threads} pthreads over contiguous slices, in-memory (no FASTQ parsing), merged sequence {'kept' if sample <= 200_000 else 'discarded'}",
+            "sample": (f"first {best['pairs']} pairs of the same batch, oracle C port, {best['threads']} pinned pthreads, one assembler each over a private, "
+                       "self-touched copy of its contiguous slice (pool.c:140-167), in memory (no FASTQ parsing), merged sequence discarded; "
+                       "clock from all-threads-ready to all-done"),
             "single_thread_pairs_per_s": rate1,
+            "threads_scaling": scaling,
+            "effective_cores": {"sched_getaffinity": affinity, "cgroup_cpu_max": quota, "os_cpu_count": os.cpu_count(), "used_for_efficiency": effective},
+            "parallel_efficiency_at_cores": eff_at_cores,
+            "note": ("efficiency = rate / (single-thread rate x min(threads, effective cores)); SMT siblings share a core's pipelines, so "
+                     "the upper half of the ladder (threads > physical cores) adds well under 1x per thread"),
             "matches_gpu_on_sample": same,
         }
     # ---- end to end through the drop-in API (never `value`): the reference's loop, PCIe both ways, plain C ----
@@ -325,13 +350,21 @@ def main():
         import bench_next
         try:
             e2e = {}
-            for name, consume in (("record_only", 0), ("every_base_read", 2)):
-                d = bench_next.run(config=cfg_index, pairs=args.e2e_pairs if consume == 0 else args.e2e_pairs // 4, sums=args.sums, consume=consume)
-                e2e[name] = {k: d[k] for k in ("pairs", "seconds", "pairs_per_s", "ok", "batch_pairs", "distinct_pairs")}
+            keys = ("pairs", "seconds", "pairs_per_s", "ok", "batch_pairs", "distinct_pairs", "api", "rows")
+            for name, consume, rows in (("record_only", 0, "eager"), ("every_base_read", 2, "eager"), ("every_base_read_rows_on_callers_thread", 2, "lazy")):
+                d = bench_next.run(config=cfg_index, pairs=args.e2e_pairs if consume == 0 else args.e2e_pairs // 4, sums=args.sums, consume=consume, rows=rows)
+                e2e[name] = {k: d[k] for k in keys}
+            # the per-pair entry point (what panda_diff calls, diff.c:26-99) and its array form
+            d = bench_next.run(config=cfg_index, pairs=min(20000, args.e2e_pairs), sums=args.sums, consume=2, api=1)
+            e2e["panda_assembler_assemble_per_pair"] = {k: d[k] for k in keys}
+            d = bench_next.run(config=cfg_index, pairs=args.e2e_pairs // 4, sums=args.sums, consume=2, api=2)
+            e2e["pamd_compat_assemble_many"] = {k: d[k] for k in keys}
             e2e["unit"] = "pairs/s"
             e2e["path"] = ("tests/c/bench_next.c: while ((r = panda_assembler_next(a)) != NULL) over an in-memory PandaNextSeq source; pinned staging, four "
-                           "batches in flight, log-p downloaded as u16 table indices, panda_result[] rows expanded by helper threads; record_only: the consumer "
-                           "reads each record's scalars; every_base_read: it reads nt and p of every merged base (16 B per base on its one thread)")
+                           "batches in flight, log-p downloaded as u16 table indices, panda_result[] rows expanded by helper threads (rows: eager) or on the "
+                           "caller's thread as each record is handed over (rows: lazy, PAMD_COMPAT_ROWS); record_only: the consumer reads each record's "
+                           "scalars; every_base_read: it reads nt and p of every merged base (16 B per base on its one thread); the last two entries: the "
+                           "caller holds the pairs and calls panda_assembler_assemble() per pair / pamd_compat_assemble_many() per 65536 pairs")
             out["end_to_end"] = e2e
         except Exception as exc:  # the headline number does not depend on this leg
             out["end_to_end"] = {"error": str(exc)[:300]}

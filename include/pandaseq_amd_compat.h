@@ -244,9 +244,25 @@ void pamd_compat_set_thread_device(int device);
 int pamd_compat_device_for_new_assembler(void);
 /* how many pairs panda_assembler_next() pulls from the source per batch (default 65536); two batches are in flight */
 void pamd_compat_set_batch_pairs(size_t pairs);
-/* how assemblers created from now on sum quality and pear / rdp_mle scores (pamd_set_exact_sums): 1 (default) = in the
- * reference's order, every output bit-identical; 0 = any order with every decision guarded, faster */
+/* how assemblers created from now on sum quality and pear / rdp_mle scores (pamd_set_exact_sums): 0 (default) = any order
+ * with every decision guarded: statuses, overlaps, merged bases and per-base log-p bit-identical to the reference, `quality`
+ * and `estimated_overlap_probability` within 1e-9 (diff.c:26-99 compares bases and log-p, never these two); 1 = in the
+ * reference's own order, every output bit bit-identical, about a fifth slower.  PAMD_COMPAT_SUMS=exact in the environment
+ * makes 1 the default of a process. */
 void pamd_compat_set_exact_sums(int exact);
+/* The array form of panda_assembler_assemble() (pandaseq-assembler.h:137-163): n pairs through one upload, one launch and
+ * one download per 65536 of them instead of one of each per pair -- what a caller that already holds its pairs wants
+ * (panda_diff's A/B loop, diff.c:26-99: INTEGRATION.md section 2).  `visit` is called for every pair, in order, with its record
+ * (NULL when the pair did not assemble; valid during the call only, as panda_assembler_assemble's is until the next call);
+ * counters, modules and the fail-alignment handler behave as if the pairs had been passed one by one.  Returns how many
+ * pairs assembled. */
+typedef void (*PamdVisit) (size_t index, const panda_result_seq *result, void *user_data);
+size_t pamd_compat_assemble_many(PandaAssembler assembler, const panda_seq_identifier *ids, const panda_qual *const *forward, const size_t *forward_length, const panda_qual *const *reverse, const size_t *reverse_length, size_t n, PamdVisit visit, void *user_data);
+/* where panda_assembler_next() builds a record's panda_result[] rows: 0 (default) = helper threads, batch by batch, ahead of
+ * the caller (a consumer that reads only a record's scalars never pays for the rows); 1 = the caller's thread, when the record
+ * is handed over, into one buffer that stays in its cache (faster for a consumer that reads every base, as output.c:85-126
+ * does).  PAMD_COMPAT_ROWS=lazy in the environment selects 1. */
+void pamd_compat_set_lazy_rows(int lazy);
 
 #ifdef __cplusplus
 }

@@ -812,3 +812,132 @@ void po_assemble_batch_mt(const po_config *c, const po_tables *t, size_t n, cons
 	free(jobs);
 	free(tid);
 }
+
+/* ---- cpu_baseline of bench.py: the same per-thread loop as pool.c:140-167 runs (one assembler per thread over its own
+ * share of the input), timed without the effects a Python caller adds: every thread copies its slice into memory it
+ * allocates and first touches itself (so the pages are local to its NUMA node), is pinned to one CPU of the process's
+ * affinity mask, and the clock runs from the moment all threads are ready to the moment the last one is done.
+ * Returns the elapsed seconds (< 0: could not start); counters are added up as above. */
+#include <sched.h>
+#include <time.h>
+
+struct bench_job {
+	struct mt_job j;
+	int cpu;	/* -1: not pinned */
+	pthread_barrier_t *ready, *go;
+	double seconds;
+	int failed;
+};
+
+static double now_s(void) {
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
+
+static void *bench_worker(void *arg) {
+	struct bench_job *b = arg;
+	struct mt_job *j = &b->j;
+	const size_t n = j->hi - j->lo;
+	if (b->cpu >= 0) {
+		cpu_set_t set;
+		CPU_ZERO(&set);
+		CPU_SET(b->cpu, &set);
+		(void) pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+	}
+	po_qual *f = malloc((n ? n : 1) * j->fstride * sizeof(po_qual)), *r = malloc((n ? n : 1) * j->rstride * sizeof(po_qual));
+	uint16_t *fl = malloc((n ? n : 1) * sizeof(uint16_t)), *rl = malloc((n ? n : 1) * sizeof(uint16_t));
+	po_result *res = malloc((n ? n : 1) * sizeof(po_result));
+	b->failed = !f || !r || !fl || !rl || !res;
+	if (!b->failed) {
+		memcpy(f, j->fwd + j->lo * j->fstride, n * j->fstride * sizeof(po_qual));
+		memcpy(r, j->rev + j->lo * j->rstride, n * j->rstride * sizeof(po_qual));
+		memcpy(fl, j->flen + j->lo, n * sizeof(uint16_t));
+		memcpy(rl, j->rlen + j->lo, n * sizeof(uint16_t));
+		memset(res, 0, n * sizeof(po_result));
+	}
+	memset(&j->ctr, 0, sizeof j->ctr);
+	pthread_barrier_wait(b->ready);
+	pthread_barrier_wait(b->go);
+	const double t0 = now_s();
+	if (!b->failed)
+		po_assemble_batch(j->c, j->t, n, f, j->fstride, r, j->rstride, fl, rl, res, NULL, NULL, 2 * PO_MAX_LEN, &j->ctr);
+	b->seconds = now_s() - t0;
+	if (!b->failed && j->res)
+		memcpy(j->res + j->lo, res, n * sizeof(po_result));
+	free(f);
+	free(r);
+	free(fl);
+	free(rl);
+	free(res);
+	return NULL;
+}
+
+double po_bench_mt(const po_config *c, const po_tables *t, size_t n, const po_qual *fwd, size_t fstride, const po_qual *rev, size_t rstride, const uint16_t *flen, const uint16_t *rlen, po_result *res, po_counters *ctr, int threads, int pin) {
+	if (threads < 1)
+		threads = 1;
+	cpu_set_t allowed;
+	int cpus[4096], ncpus = 0;
+	if (pin && sched_getaffinity(0, sizeof allowed, &allowed) == 0)
+		for (int k = 0; k < CPU_SETSIZE && ncpus < 4096; k++)
+			if (CPU_ISSET(k, &allowed))
+				cpus[ncpus++] = k;
+	struct bench_job *jobs = calloc((size_t) threads, sizeof *jobs);
+	pthread_t *tid = calloc((size_t) threads, sizeof *tid);
+	pthread_barrier_t ready, go;
+	if (!jobs || !tid || pthread_barrier_init(&ready, NULL, (unsigned) threads + 1) || pthread_barrier_init(&go, NULL, (unsigned) threads + 1)) {
+		free(jobs);
+		free(tid);
+		return -1.0;
+	}
+	int started = 0;
+	for (int k = 0; k < threads; k++) {
+		struct mt_job *j = &jobs[k].j;
+		j->c = c;
+		j->t = t;
+		j->lo = n * (size_t) k / (size_t) threads;
+		j->hi = n * (size_t) (k + 1) / (size_t) threads;
+		j->fwd = fwd;
+		j->rev = rev;
+		j->fstride = fstride;
+		j->rstride = rstride;
+		j->ostride = 2 * PO_MAX_LEN;
+		j->flen = flen;
+		j->rlen = rlen;
+		j->res = res;
+		/* spread over the allowed CPUs: with fewer threads than CPUs every thread gets a CPU (and, on most hosts, a core) of its own */
+		jobs[k].cpu = ncpus > 0 ? cpus[(size_t) k * (size_t) ncpus / (size_t) threads] : -1;
+		jobs[k].ready = &ready;
+		jobs[k].go = &go;
+		if (pthread_create(&tid[k], NULL, bench_worker, &jobs[k]) != 0)
+			break;
+		started++;
+	}
+	if (started != threads) {	/* cannot release a barrier that not everybody reaches: give up on the process' behalf */
+		fprintf(stderr, "po_bench_mt: only %d of %d threads started\n", started, threads);
+		abort();
+	}
+	pthread_barrier_wait(&ready);
+	const double t0 = now_s();
+	pthread_barrier_wait(&go);
+	int failed = 0;
+	for (int k = 0; k < threads; k++) {
+		pthread_join(tid[k], NULL);
+		failed |= jobs[k].failed;
+		const po_counters *w = &jobs[k].j.ctr;
+		ctr->count += w->count;
+		ctr->badr += w->badr;
+		ctr->nofp += w->nofp;
+		ctr->norp += w->norp;
+		ctr->noalgn += w->noalgn;
+		ctr->lowq += w->lowq;
+		ctr->ok += w->ok;
+		ctr->slow += w->slow;
+	}
+	const double elapsed = now_s() - t0;
+	pthread_barrier_destroy(&ready);
+	pthread_barrier_destroy(&go);
+	free(jobs);
+	free(tid);
+	return failed ? -1.0 : elapsed;
+}

@@ -170,4 +170,8 @@ void po_assemble_batch_mt(const po_config *c, const po_tables *t, size_t n, cons
 #ifdef __cplusplus
 }
 #endif
+/* bench.py's cpu_baseline leg: `threads` pinned workers, each over a private, self-touched copy of its slice; returns the
+ * seconds from "all ready" to "all done" (< 0 on failure).  res may be NULL. */
+double po_bench_mt(const po_config *c, const po_tables *t, size_t n, const po_qual *fwd, size_t fstride, const po_qual *rev, size_t rstride, const uint16_t *flen, const uint16_t *rlen, po_result *res, po_counters *ctr, int threads, int pin);
+
 #endif

@@ -215,6 +215,27 @@ def assemble_batch(cfg, fwd, rev, flen, rlen, want_seq=True, threads=1):
     return res, seq_nt, seq_p, ctr[0]
 
 
+def bench_mt(cfg, fwd, rev, flen, rlen, threads, pin=True):
+    """bench.py's cpu_baseline leg (po_bench_mt): `threads` pinned pthreads, each over its own, self-touched copy of its
+    slice; returns (seconds from all-ready to all-done, results, counters)."""
+    fwd = np.ascontiguousarray(fwd, dtype=np.uint8)
+    rev = np.ascontiguousarray(rev, dtype=np.uint8)
+    flen = np.ascontiguousarray(flen, dtype=np.uint16)
+    rlen = np.ascontiguousarray(rlen, dtype=np.uint16)
+    n = fwd.shape[0]
+    res = np.zeros(n, dtype=RESULT_DTYPE)
+    ctr = np.zeros(1, dtype=COUNTER_DTYPE)
+    L = lib()
+    L.po_bench_mt.restype = C.c_double
+    L.po_bench_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    secs = L.po_bench_mt(C.byref(cfg), C.byref(tables()), n, fwd.ctypes.data, fwd.shape[1], rev.ctypes.data, rev.shape[1],
+                         flen.ctypes.data, rlen.ctypes.data, res.ctypes.data, ctr.ctypes.data, int(threads), 1 if pin else 0)
+    if secs < 0:
+        raise RuntimeError("po_bench_mt failed")
+    return secs, res, ctr[0]
+
+
 def ref_tables_np():
     """Tables emitted by the REFERENCE's own mktable (oracle/_ref/libreftable.so), or None when
     that build is absent (it can only be produced where /root/reference exists)."""

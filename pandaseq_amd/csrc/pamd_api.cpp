@@ -92,6 +92,7 @@ struct pamd_assembler {
 	size_t scratch_rows = 0;	// 10 words, only written by -DPAMD_PHASE_TIMING builds
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 	bool timed = false;
+	hipStream_t last_stream = nullptr;	// the stream of the launch ev_stop was recorded on
 	int last_wgs = 0, last_waves = 0, last_lds = 0;
 };
 
@@ -380,6 +381,11 @@ int pamd_clear_modules(pamd_assembler *a) {
 }
 
 static int upload_tables(pamd_assembler *a, hipStream_t st) {
+	// what follows overwrites device memory an earlier launch of this assembler reads (tables, count table, primers) with
+	// blocking copies on the null stream, which do not wait for a caller's non-blocking stream: wait for that launch first
+	const bool will_copy = a->d_tables_algo != a->algo || ((a->algo == PAMD_ALGO_EA_UTIL || a->algo == PAMD_ALGO_STITCH) && a->count_table_algo != a->algo) || a->primers_dirty;
+	if (will_copy && a->timed)
+		HIP_TRY(hipEventSynchronize(a->ev_stop));
 	if (a->d_tables_algo != a->algo) {
 		std::vector<double> img(PAMD_LT_C + PAMD_TAB, 0.0);
 		memcpy(&img[PAMD_LT_SCORE], a->tabs.score, sizeof a->tabs.score);
@@ -425,8 +431,15 @@ static int upload_tables(pamd_assembler *a, hipStream_t st) {
 			unsigned long long bits;
 			memcpy(&bits, &img[i], 8);
 			unsigned h = (unsigned) ((bits * 0x9E3779B97F4A7C15ull) >> 50) & (PAMD_ENCODE_SLOTS - 1u);
-			while (slots[h] != 0xFFFFu && memcmp(&img[slots[h]], &img[i], 8) != 0)
+			unsigned walked = 0;
+			while (slots[h] != 0xFFFFu && memcmp(&img[slots[h]], &img[i], 8) != 0) {
 				h = (h + 1u) & (PAMD_ENCODE_SLOTS - 1u);
+				walked++;
+			}
+			if (walked >= PAMD_ENCODE_PROBES) {	// the device lookup gives up after that many slots (pamd_encode.hip)
+				pamd_set_error("table image: entry %zu lies %u slots from its hash slot (the device walks %d); PAMD_ENCODE_SLOTS is too small for these tables", i, walked, PAMD_ENCODE_PROBES);
+				return PAMD_EINVAL;
+			}
 			if (slots[h] == 0xFFFFu)
 				slots[h] = (uint16_t) i;
 		}
@@ -722,6 +735,10 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	}
 	p.pair_cursor = b->n_pairs <= 0xFF000000ull ? a->d_defer_count + 1 : nullptr;	// (a 32-bit counter that every wave overshoots by up to sixteen; beyond it fixed shares)
 	p.wave_pids = a->d_wave_pids;
+	// One launch in flight per assembler: a launch owns the assembler's deferred list, work counters, per-wave records and
+	// primer words, and zeroes them on its stream.  A launch on another stream than the previous one waits for it.
+	if (a->timed && a->last_stream != st)
+		HIP_TRY(hipStreamWaitEvent(st, a->ev_stop, 0));
 	HIP_TRY(hipEventRecord(a->ev_start, st));
 	HIP_TRY(hipMemsetAsync(a->d_defer_count, 0, 2 * sizeof(unsigned), st));
 	// (the lean kernel finds the primers of the pairs it keeps itself; the primer kernel then serves the pairs it deferred)
@@ -766,6 +783,7 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 		return rc;
 	HIP_TRY(hipEventRecord(a->ev_stop, st));
 	a->timed = true;
+	a->last_stream = st;
 	return PAMD_OK;
 }
 

@@ -36,7 +36,35 @@ std::atomic<int> g_device{0};
 thread_local int t_device = -1;
 std::atomic<unsigned> g_device_rr{0};
 std::atomic<size_t> g_batch_pairs{65536};
-std::atomic<int> g_exact_sums{1};
+// Summation mode of the assemblers this layer creates (pamd_set_exact_sums, include/pandaseq_amd.h).  Default: any order with
+// exactness guards -- every decision, merged base and per-base log-p bit-identical to the reference, `quality` and
+// `estimated_overlap_probability` within 1e-9 (the tolerance this path is specified to is 1e-6, and panda_diff, diff.c:26-99,
+// compares bases and log-p, never those two scalars).  PAMD_COMPAT_SUMS=exact in the environment, or
+// pamd_compat_set_exact_sums(1), selects sums in the reference's own order (every output bit bit-identical, ~20 % slower).
+// Where panda_assembler_next() builds a record's panda_result[] (16 bytes per base): 0 = by helper threads, batch by batch,
+// ahead of the caller (streamed to memory: a consumer that only looks at a record's scalars never touches the rows);
+// 1 = on the caller's thread when the record is handed over, into one buffer that stays in its cache (a consumer that reads
+// every base reads it from there instead of from memory other threads wrote).  PAMD_COMPAT_ROWS=lazy selects 1.
+std::atomic<int> g_lazy_rows{-1};
+int compat_lazy_rows() {
+	int v = g_lazy_rows.load();
+	if (v < 0) {
+		const char *e = getenv("PAMD_COMPAT_ROWS");
+		v = (e != nullptr && strcmp(e, "lazy") == 0) ? 1 : 0;
+		g_lazy_rows.store(v);
+	}
+	return v;
+}
+std::atomic<int> g_exact_sums{-1};
+int compat_exact_sums() {
+	int v = g_exact_sums.load();
+	if (v < 0) {
+		const char *e = getenv("PAMD_COMPAT_SUMS");
+		v = (e != nullptr && strcmp(e, "exact") == 0) ? 1 : 0;
+		g_exact_sums.store(v);
+	}
+	return v;
+}
 std::mutex g_ref_lock;	// one lock for all refcounts, like module.c:38-41
 
 int pick_device() {
@@ -558,36 +586,48 @@ struct panda_assembler {
 
 namespace {
 
+// which kernel scorer an algorithm object is (-1: none: a class registered by the caller), and its parameter
+int device_algo_of(PandaAlgorithm algorithm, double *param_out = nullptr) {
+	int algo = -1;
+	double param = NAN;
+	if (algorithm == nullptr) {
+		algo = -1;
+	} else if (panda_algorithm_is_a(algorithm, &panda_algorithm_simple_bayes_class)) {
+		algo = PAMD_ALGO_SIMPLE_BAYES;
+		param = panda_algorithm_simple_bayes_get_error_estimation(algorithm);
+	} else if (panda_algorithm_is_a(algorithm, &panda_algorithm_pear_class)) {
+		algo = PAMD_ALGO_PEAR;
+		param = panda_algorithm_pear_get_random_base_log_p(algorithm);
+	} else if (panda_algorithm_is_a(algorithm, &panda_algorithm_rdp_mle_class)) {
+		algo = PAMD_ALGO_RDP_MLE;
+	} else if (panda_algorithm_is_a(algorithm, &panda_algorithm_uparse_class)) {
+		algo = PAMD_ALGO_UPARSE;
+		param = panda_algorithm_uparse_get_error_estimation(algorithm);
+	} else if (panda_algorithm_is_a(algorithm, &panda_algorithm_flash_class)) {
+		algo = PAMD_ALGO_FLASH;
+	} else if (panda_algorithm_is_a(algorithm, &panda_algorithm_ea_util_class)) {
+		algo = PAMD_ALGO_EA_UTIL;
+	} else if (panda_algorithm_is_a(algorithm, &panda_algorithm_stitch_class)) {
+		algo = PAMD_ALGO_STITCH;
+	}
+	if (param_out != nullptr)
+		*param_out = param;
+	return algo;
+}
+
 int push_config(PandaAssembler a) {
 	if (!a->dev_dirty)
 		return PAMD_OK;
-	int algo;
 	double param = NAN;
-	if (panda_algorithm_is_a(a->algo, &panda_algorithm_simple_bayes_class)) {
-		algo = PAMD_ALGO_SIMPLE_BAYES;
-		param = panda_algorithm_simple_bayes_get_error_estimation(a->algo);
-	} else if (panda_algorithm_is_a(a->algo, &panda_algorithm_pear_class)) {
-		algo = PAMD_ALGO_PEAR;
-		param = panda_algorithm_pear_get_random_base_log_p(a->algo);
-	} else if (panda_algorithm_is_a(a->algo, &panda_algorithm_rdp_mle_class)) {
-		algo = PAMD_ALGO_RDP_MLE;
-	} else if (panda_algorithm_is_a(a->algo, &panda_algorithm_uparse_class)) {
-		algo = PAMD_ALGO_UPARSE;
-		param = panda_algorithm_uparse_get_error_estimation(a->algo);
-	} else if (panda_algorithm_is_a(a->algo, &panda_algorithm_flash_class)) {
-		algo = PAMD_ALGO_FLASH;
-	} else if (panda_algorithm_is_a(a->algo, &panda_algorithm_ea_util_class)) {
-		algo = PAMD_ALGO_EA_UTIL;
-	} else if (panda_algorithm_is_a(a->algo, &panda_algorithm_stitch_class)) {
-		algo = PAMD_ALGO_STITCH;
-	} else {
-		pamd_set_error("algorithm %s has no device implementation (user-registered classes are not supported)", a->algo ? panda_algorithm_class(a->algo)->name : "(null)");
+	const int algo = device_algo_of(a->algo, &param);
+	if (algo < 0) {	// (panda_assembler_set_algorithm admits such a class only with its own functions, and then the host path runs)
+		pamd_set_error("algorithm %s has no device implementation", a->algo ? panda_algorithm_class(a->algo)->name : "(null)");
 		return PAMD_EUNSUPPORTED;
 	}
 	for (pamd_assembler *d : a->devs) {
 	if (d == nullptr)
 		continue;
-	pamd_set_exact_sums(d, g_exact_sums.load());
+	pamd_set_exact_sums(d, compat_exact_sums());
 	pamd_set_algorithm(d, algo, param);
 	pamd_set_primers_after(d, a->post_primers ? 1 : 0);
 	pamd_set_log_threshold(d, a->threshold);	// the stored logarithm itself (assembler_support.c:395): no exp / log round trip
@@ -687,6 +727,317 @@ bool host_module_check(PandaModule mod, const panda_result_seq *res) {
 		return true;
 	}
 	return mod->fused_bits * 0.69314718055994530942 <= res->estimated_overlap_probability;	// plugin_min_overlapbits.c:17-23
+}
+
+// ---- the host path: algorithm classes whose scoring the kernel does not implement ---------------------------------------
+// A class registered by the caller (algo.c:106-120) scores an overlap and a merged base through its own function pointers
+// (pandaseq-common.h:594-605), which cannot run on the device.  An assembler given such an algorithm assembles on the caller's
+// thread, pair by pair, as assemble_seq() / align() do (assembler.c:48-348), calling those pointers where the reference calls
+// them; the seven classes of this library never take this path (their pointers are NULL here: the kernels are their
+// implementation), except under pamd_compat_force_host_callbacks(), which tests/ uses with a class of its own.
+const PamdTables &host_tables() {
+	static PamdTables t;
+	static std::once_flag once;
+	std::call_once(once, [] { pamd_build_tables(&t); });
+	return t;
+}
+
+inline int host_clampq(int q) {	// PHREDCLAMP, prob.h:23
+	return q > 46 ? 46 : (q < 0 ? 0 : q);
+}
+
+inline unsigned kmer_code(panda_nt nt) {	// misc.h:41
+	return nt == 8 ? 3u : (nt == 4 ? 2u : (nt == 2 ? 1u : 0u));
+}
+
+// calls emit(kmer, position) for every 8-mer the reference's iterator yields (misc.h:41-45): ascending positions for the
+// forward read, descending for the reverse one; an N voids the nine windows that hold it
+template <typename Emit>
+void host_kmers(const panda_qual *seq, size_t len, bool descending, Emit emit) {
+	size_t kmer = 0;
+	ptrdiff_t bad = 8;
+	for (size_t step = 0; step < len; step++) {
+		const size_t p = descending ? len - 1 - step : step;
+		kmer = ((kmer << 2) | kmer_code(seq[p].nt)) & 0xFFFFu;
+		if (seq[p].nt == (panda_nt) 15)
+			bad = 8;
+		else if (bad > 0)
+			bad--;
+		else
+			emit(kmer, p);
+	}
+}
+
+// offset.c:47-90: where the primer ends in `n` bases read through base(i) -> (nt, p, notp); 0 = not found
+template <typename Base>
+size_t host_primer_offset(double threshold, double penalty, size_t n, Base base, const panda_nt *primer, size_t plen) {
+	if (plen > n)
+		return 0;
+	std::vector<double> pr(plen, -INFINITY);
+	double bestpr = exp((double) plen * threshold);
+	size_t best = 0;
+	for (size_t index = 0; index < n; index++) {
+		const double last = exp(pr[index % plen] / (double) (index + 1)) - (double) index * penalty;
+		if (last > bestpr) {
+			bestpr = last;
+			best = index + 1;
+		}
+		pr[index % plen] = 0;
+		panda_nt nt;
+		double p, notp;
+		base(index, nt, p, notp);
+		for (ptrdiff_t x = (ptrdiff_t) (plen > index ? index : plen - 1); x >= 0; x--)
+			if (primer[x] != (panda_nt) 15)
+				pr[(index - (size_t) x) % plen] += ((nt & primer[x]) != 0) ? p : notp;
+	}
+	return best;
+}
+
+struct host_scratch {
+	std::vector<uint16_t> seen = std::vector<uint16_t>(2u << 16, 0);	// first two forward positions per k-mer (0 = none)
+	std::vector<uint8_t> bits;
+};
+
+// align(), assembler.c:48-250
+bool host_align(PandaAssembler a, panda_result_seq &res, host_scratch &sc) {
+	const PamdTables &T = host_tables();
+	const struct panda_algorithm_class *cls = panda_algorithm_class(a->algo);
+	void *data = panda_algorithm_data(a->algo);
+	const double qual_nn = cls->prob_unpaired;
+	const size_t flen = res.forward_length, rlen = res.reverse_length, fo = res.forward_offset, ro = res.reverse_offset, minov = (size_t) a->minoverlap;
+	if (minov + fo >= flen || minov + ro >= rlen)
+		return false;
+	size_t maxov = flen + rlen - minov - fo - ro - 1;
+	if (a->maxoverlap == 0)
+		maxov = flen < rlen ? flen : rlen;
+	else if (maxov > (size_t) a->maxoverlap)
+		maxov = (size_t) a->maxoverlap;
+	const size_t size = minov <= maxov ? maxov - minov + 1 : 1;
+	sc.bits.assign(size, 0);
+	host_kmers(res.forward, flen, false, [&](size_t k, size_t p) {
+		uint16_t *slot = &sc.seen[2 * k];
+		if (slot[0] == 0)
+			slot[0] = (uint16_t) p;
+		else if (slot[1] == 0)
+			slot[1] = (uint16_t) p;
+	});
+	bool any = false;
+	host_kmers(res.reverse, rlen, true, [&](size_t k, size_t p) {
+		for (int j = 0; j < 2 && sc.seen[2 * k + j] != 0; j++) {
+			const ptrdiff_t index = (ptrdiff_t) (flen + rlen) - (ptrdiff_t) p - (ptrdiff_t) sc.seen[2 * k + j] - (ptrdiff_t) minov - 1;
+			if (index >= 0 && (size_t) index < size) {
+				sc.bits[(size_t) index] = 1;
+				any = true;
+			}
+		}
+	});
+	host_kmers(res.forward, flen, false, [&](size_t k, size_t) { sc.seen[2 * k] = sc.seen[2 * k + 1] = 0; });
+	double best = qual_nn * (double) (flen + rlen);
+	ptrdiff_t bo = -1;
+	res.overlaps_examined = 0;
+	for (size_t c = 0; c < size; c++) {
+		if (any && !sc.bits[c])
+			continue;
+		const size_t overlap = c + minov;
+		const double pr = cls->overlap_probability(data, res.forward, flen, res.reverse, rlen, overlap);
+		if (pr > best) {
+			best = pr;
+			bo = (ptrdiff_t) overlap;
+		}
+		res.overlaps_examined++;
+	}
+	if (res.overlaps_examined == maxov - minov + 1)
+		a->slowcount++;
+	if (bo < 0)
+		return false;
+	const ptrdiff_t len = (ptrdiff_t) flen - (ptrdiff_t) fo - bo + (ptrdiff_t) rlen - (ptrdiff_t) ro + 1;
+	if (len <= 0 || (size_t) len > 2 * PAMD_MAX_LEN)
+		return false;
+	res.sequence = a->result_seq;
+	res.sequence_length = (size_t) len - 1;
+	res.degenerates = 0;
+	res.overlap_mismatches = 0;
+	const ptrdiff_t df = (ptrdiff_t) flen - (ptrdiff_t) fo - bo, dr = (ptrdiff_t) rlen - (ptrdiff_t) ro - bo;
+	const ptrdiff_t vdf = df < 0 ? 0 : df, wdf = df > 0 ? 0 : df, vdr = dr < 0 ? 0 : dr, wdr = dr > 0 ? 0 : dr;
+	// PANDA_NT_IS_DEGN (pandaseq-nt.h:55): anything but exactly one of the four bits -- nt 0 counts as degenerate
+	auto degenerate = [](panda_nt nt) { return ((((unsigned int) nt) * 0x200040008001ULL & 0x111111111111111ULL) % 0xf) != 1; };
+	double fq = 0, oq = 0, rq = 0;
+	for (ptrdiff_t i = 0; i < vdf; i++) {
+		const panda_qual &b = res.forward[(size_t) i + fo];
+		const double q = T.score[host_clampq(b.qual)];
+		res.sequence[i].nt = b.nt;
+		res.sequence[i].p = q;
+		res.degenerates += degenerate(b.nt);
+		fq += q;
+	}
+	size_t uf = flen, ur = rlen;	// the B-cliff: trailing runs of quality 2 (assembler.c:176-177)
+	while (uf > 0 && res.forward[uf - 1].qual == (char) 2)
+		uf--;
+	while (ur > 0 && res.reverse[ur - 1].qual == (char) 2)
+		ur--;
+	for (ptrdiff_t i = 0; i < bo + wdf + wdr; i++) {
+		const ptrdiff_t index = vdf + i, fi = (ptrdiff_t) fo + vdf + i, ri = (ptrdiff_t) rlen - i - 1 + wdf;
+		if (index < 0 || fi < 0 || ri < 0 || (size_t) fi >= flen || (size_t) ri >= rlen)
+			continue;
+		const panda_qual &f = res.forward[fi], &r = res.reverse[ri];
+		const bool match = (r.nt & f.nt) != 0;
+		if (!match)
+			res.overlap_mismatches++;
+		double q;
+		if ((size_t) fi >= uf && (size_t) ri >= ur)
+			q = qual_nn;
+		else if ((size_t) fi >= uf)
+			q = T.score[host_clampq(r.qual)];
+		else if ((size_t) ri >= ur)
+			q = T.score[host_clampq(f.qual)];
+		else
+			q = cls->match_probability(data, match, f.qual, r.qual);
+		const panda_nt nt = match ? (panda_nt) (r.nt & f.nt) : (f.qual < r.qual ? r.nt : f.nt);
+		res.sequence[index].nt = nt;
+		res.sequence[index].p = q;
+		res.degenerates += degenerate(nt);
+		oq += q;
+	}
+	for (ptrdiff_t i = 0; i < vdr; i++) {
+		const ptrdiff_t index = df + bo + i;
+		const panda_qual &b = res.reverse[(size_t) ((ptrdiff_t) rlen - bo - i - 1)];
+		const double q = T.score[host_clampq(b.qual)];
+		rq += q;
+		res.sequence[index].nt = b.nt;
+		res.sequence[index].p = q;
+		res.degenerates += degenerate(b.nt);
+	}
+	res.quality = (fq + rq + oq) / (double) len;
+	res.overlap = (size_t) bo;
+	res.estimated_overlap_probability = best;
+	return true;
+}
+
+// assemble_seq(), assembler.c:252-348
+const panda_result_seq *host_assemble(PandaAssembler a, const panda_seq_identifier *id, const panda_qual *f, size_t fl, const panda_qual *r, size_t rl) {
+	static thread_local host_scratch sc;
+	const PamdTables &T = host_tables();
+	panda_result_seq &res = a->result;
+	if (id != &res.name)
+		res.name = *id;
+	res.forward = f;
+	res.forward_length = fl;
+	res.reverse = r;
+	res.reverse_length = rl;
+	a->count++;
+	if (fl < 2 || rl < 2) {
+		a->badreadcount++;
+		return nullptr;
+	}
+	for (size_t m = 0; m < a->modules.size(); m++) {	// module_precheckseq, module.c:138-154
+		PandaModule mod = a->modules[m];
+		if (mod->precheck != nullptr && !mod->precheck(a->logger, &res.name, f, fl, r, rl, mod->user_data)) {
+			a->rejected[m]++;
+			return nullptr;
+		}
+	}
+	auto read_base = [&T](const panda_qual *seq) {
+		return [seq, &T](size_t i, panda_nt &nt, double &p, double &notp) {	// qual_base_score, offset.c:92-101
+			const int q = host_clampq(seq[i].qual);
+			nt = seq[i].nt;
+			p = T.score[q];
+			notp = T.score_err[q];
+		};
+	};
+	res.forward_offset = res.reverse_offset = 0;
+	if (!a->post_primers) {
+		if (a->forward_primer_length > 0) {
+			res.forward_offset = host_primer_offset(a->threshold, a->primer_penalty, fl, read_base(f), a->forward_primer, a->forward_primer_length);
+			if (res.forward_offset == 0) {
+				a->nofpcount++;
+				return nullptr;
+			}
+			res.forward_offset--;
+		} else {
+			res.forward_offset = a->forward_trim;
+		}
+		if (a->reverse_primer_length > 0) {
+			res.reverse_offset = host_primer_offset(a->threshold, a->primer_penalty, rl, read_base(r), a->reverse_primer, a->reverse_primer_length);
+			if (res.reverse_offset == 0) {
+				a->norpcount++;
+				return nullptr;
+			}
+			res.reverse_offset--;
+		} else {
+			res.reverse_offset = a->reverse_trim;
+		}
+	}
+	if ((fl < rl ? fl : rl) < (size_t) a->minoverlap) {
+		a->badreadcount++;
+		return nullptr;
+	}
+	if (!host_align(a, res, sc)) {
+		if (a->noalgn != nullptr)
+			a->noalgn(a, &res.name, f, fl, r, rl, a->noalgn_data);
+		a->noalgncount++;
+		return nullptr;
+	}
+	if (a->post_primers) {	// assembler.c:300-333: the primers are looked for in the merged sequence, the reverse one from its end
+		const panda_result *seq = res.sequence;
+		const size_t n = res.sequence_length;
+		auto merged_base = [seq, n](bool reverse) {
+			return [seq, n, reverse](size_t i, panda_nt &nt, double &p, double &notp) {	// result_base_score, offset.c:114-122
+				const panda_result &b = seq[reverse ? n - i - 1 : i];
+				nt = b.nt;
+				p = b.p;
+				notp = (b.p > M_LN2) ? log1p(-exp(-b.p)) : log(-expm1(-b.p));	// panda_log1mexp, offset.c:35-38
+			};
+		};
+		if (a->forward_primer_length > 0) {
+			res.forward_offset = host_primer_offset(a->threshold, a->primer_penalty, n, merged_base(false), a->forward_primer, a->forward_primer_length);
+			if (res.forward_offset == 0) {
+				a->nofpcount++;
+				return nullptr;
+			}
+			res.forward_offset--;
+		} else {
+			res.forward_offset = a->forward_trim;
+		}
+		if (a->reverse_primer_length > 0) {
+			res.reverse_offset = host_primer_offset(a->threshold, a->primer_penalty, n, merged_base(true), a->reverse_primer, a->reverse_primer_length);
+			if (res.reverse_offset == 0) {
+				a->norpcount++;
+				return nullptr;
+			}
+			res.reverse_offset--;
+		} else {
+			res.reverse_offset = a->reverse_trim;
+		}
+		if (res.sequence_length <= res.forward_offset + res.reverse_offset) {
+			a->nofpcount++;
+			return nullptr;
+		}
+		res.sequence_length -= res.forward_offset + res.reverse_offset;
+		for (size_t it = 0; it < res.sequence_length; it++)
+			res.sequence[it] = res.sequence[it + res.forward_offset];
+	}
+	if (res.quality < a->threshold) {
+		a->lowqcount++;
+		return nullptr;
+	}
+	for (size_t m = 0; m < a->modules.size(); m++) {	// module_checkseq, module.c:124-136
+		PandaModule mod = a->modules[m];
+		if (mod->fused_kind != 0 ? !host_module_check(mod, &res) : (mod->check != nullptr && !mod->check(a->logger, &res, mod->user_data))) {
+			a->rejected[m]++;
+			return nullptr;
+		}
+	}
+	a->okcount++;
+	a->overlapcount[res.overlap]++;
+	if (a->longest_overlap < res.overlap)
+		a->longest_overlap = res.overlap;
+	return &res;
+}
+
+// does this assembler's algorithm score through its own function pointers?
+bool uses_host_callbacks(PandaAssembler a) {
+	const struct panda_algorithm_class *cls = a->algo != nullptr ? panda_algorithm_class(a->algo) : nullptr;
+	return cls != nullptr && cls->overlap_probability != nullptr && cls->match_probability != nullptr;
 }
 
 // Replay staged pair `i` the way assemble_seq() would have (assembler.c:252-348).  Returns the
@@ -804,6 +1155,7 @@ void stage_pair(PandaAssembler a, size_t i, const panda_seq_identifier *id, cons
 }	// namespace
 
 struct pamd_slot {
+	bool lazy = false;	// this batch's rows are built on the caller's thread, record by record (compat_lazy_rows)
 	// pinned host memory
 	pamd_qual *h_fwd = nullptr, *h_rev = nullptr;
 	uint16_t *h_flen = nullptr, *h_rlen = nullptr;
@@ -971,6 +1323,11 @@ int slot_run(PandaAssembler a, pamd_slot *s) {
 			total += s->h_res[k].seq_len;
 	}
 	s->row_off[n] = total;
+	s->lazy = compat_lazy_rows() != 0;
+	if (s->lazy) {	// the rows are built record by record on the caller's thread (slot_replay)
+		s->seconds = now_s() - t_begin;
+		return PAMD_OK;
+	}
 	if (s->rows_cap < total) {
 		free(s->rows);
 		s->rows_cap = total + total / 8 + 4096;
@@ -1034,6 +1391,8 @@ int slot_run(PandaAssembler a, pamd_slot *s) {
 	s->seconds = now_s() - t_begin;
 	return PAMD_OK;
 }
+
+void slot_wait(pamd_slot *s);
 
 // Pull the next batch from the source into slot `s` (the caller's thread) and start it.
 void slot_fill_and_submit(PandaAssembler a, pamd_slot *s) {
@@ -1127,6 +1486,14 @@ void slot_fill_and_submit(PandaAssembler a, pamd_slot *s) {
 		s->n++;
 	}
 	s->seq_stride = s->stride == 256 ? 512 : OUT_ROW;
+	if (a->dev_dirty) {
+		// a setter was called after batches were prefetched: those (up to NSLOT x the batch size pairs) were assembled under
+		// the old configuration, as documented; their background work reads the table image and the device assemblers that
+		// push_config() rewrites, so it has to be over first
+		for (pamd_slot *other : a->slots)
+			if (other != nullptr && other != s)
+				slot_wait(other);
+	}
 	if (push_config(a) != PAMD_OK) {
 		fprintf(stderr, "pandaseq_amd: %s\n", pamd_last_error());
 		abort();	// no CPU fallback: a device failure is fatal, never silently wrong
@@ -1205,7 +1572,7 @@ const panda_result_seq *slot_replay(PandaAssembler a, pamd_slot *s, size_t i) {
 	}
 	res.quality = d.quality;
 	res.degenerates = d.degenerates;
-	res.sequence = s->rows + s->row_off[k];
+	res.sequence = s->lazy ? a->result_seq : s->rows + s->row_off[k];
 	res.sequence_length = d.seq_len;
 	res.overlap_mismatches = d.mismatches;
 	res.overlap = d.overlap;
@@ -1217,6 +1584,20 @@ const panda_result_seq *slot_replay(PandaAssembler a, pamd_slot *s, size_t i) {
 	if (d.status == PAMD_ST_REJECT) {
 		a->rejected[d.reject_module]++;
 		return nullptr;
+	}
+	if (s->lazy) {	// nt from the device, p = the table entry the index names -- the very double the kernel wrote
+		const uint8_t *nt = s->h_nt + k * s->seq_stride;
+		const uint16_t *ix = s->h_idx + k * s->seq_stride;
+		const double *image = a->image.data();
+		const size_t n_image = a->image.size();
+		for (size_t j = 0; j < d.seq_len; j++) {
+			if (ix[j] >= n_image) {
+				fprintf(stderr, "pandaseq_amd: a merged log-probability is not an entry of the table image\n");
+				abort();
+			}
+			a->result_seq[j].nt = (panda_nt) nt[j];
+			a->result_seq[j].p = image[ix[j]];
+		}
 	}
 	for (size_t m = a->fused_prefix; m < a->modules.size(); m++) {	// host-callback check modules, in order (module.c:124-136)
 		PandaModule mod = a->modules[m];
@@ -1251,13 +1632,6 @@ extern "C" {
 // Plugins compiled against the reference headers call these on the panda_result rows they are
 // handed (plugin_min_phred.c:16).  The bisection keeps the reference's quirks: 1 at or below
 // qual_score[0] (= -2), "mid == lower" returns lower.
-static const PamdTables &host_tables() {
-	static PamdTables t;
-	static std::once_flag once;
-	std::call_once(once, [] { pamd_build_tables(&t); });
-	return t;
-}
-
 double panda_quality_log_probability(const panda_qual *q) {
 	int v = q->qual < 0 ? 0 : (q->qual > PAMD_NQ - 1 ? PAMD_NQ - 1 : q->qual);
 	return host_tables().score[v];
@@ -1301,6 +1675,10 @@ int pamd_compat_device_for_new_assembler(void) {
 
 void pamd_compat_set_batch_pairs(size_t pairs) {
 	g_batch_pairs.store(pairs ? pairs : 1);
+}
+
+void pamd_compat_set_lazy_rows(int lazy) {
+	g_lazy_rows.store(lazy ? 1 : 0);
 }
 
 void pamd_compat_set_exact_sums(int exact) {
@@ -1409,9 +1787,10 @@ const panda_result_seq *panda_assembler_assemble(PandaAssembler a, panda_seq_ide
 		fprintf(stderr, "pandaseq_amd: panda_assembler_assemble() called while panda_assembler_next() has prefetched pairs pending\n");
 		return nullptr;
 	}
+	if (device_algo_of(a->algo) < 0)	// a class of the caller's: scored through its own functions, on this thread
+		return host_assemble(a, id, forward, forward_length, reverse, reverse_length);
 	ensure_staging(a, 1);
 	stage_pair(a, 0, id, forward, forward_length, reverse, reverse_length);
-	a->h_pre[0] = a->h_pre[0];
 	a->batch_n = 1;
 	a->batch_pos = 1;
 	if (run_batch(a) != PAMD_OK) {
@@ -1421,9 +1800,62 @@ const panda_result_seq *panda_assembler_assemble(PandaAssembler a, panda_seq_ide
 	return replay(a, 0, forward, reverse);
 }
 
+size_t pamd_compat_assemble_many(PandaAssembler a, const panda_seq_identifier *ids, const panda_qual *const *forward, const size_t *forward_length, const panda_qual *const *reverse, const size_t *reverse_length, size_t n, PamdVisit visit, void *user_data) {
+	// a pending prefetched batch of panda_assembler_next() shares the staging area: refuse to mix (as panda_assembler_assemble)
+	for (pamd_slot *sl : a->slots)
+		if (sl != nullptr && (sl->pos < sl->n || sl->done.valid())) {
+			fprintf(stderr, "pandaseq_amd: pamd_compat_assemble_many() called while panda_assembler_next() has prefetched pairs pending\n");
+			return 0;
+		}
+	size_t assembled = 0;
+	const bool host = device_algo_of(a->algo) < 0;	// a class of the caller's: pair by pair through its own functions
+	constexpr size_t CHUNK = 65536;	// one upload, one launch and one download per chunk
+	for (size_t base = 0; base < n; base += CHUNK) {
+		const size_t m = n - base < CHUNK ? n - base : CHUNK;
+		for (size_t i = 0; i < m; i++)
+			if (forward_length[base + i] > PAMD_MAX_LEN || reverse_length[base + i] > PAMD_MAX_LEN) {	// the reference asserts (assembler.c:375-376)
+				fprintf(stderr, "pandaseq_amd: read longer than PANDA_MAX_LEN\n");
+				abort();
+			}
+		if (!host) {
+			ensure_staging(a, m);
+			for (size_t i = 0; i < m; i++)
+				stage_pair(a, i, &ids[base + i], forward[base + i], forward_length[base + i], reverse[base + i], reverse_length[base + i]);
+			a->batch_n = m;
+			a->batch_pos = m;
+			if (run_batch(a) != PAMD_OK) {
+				fprintf(stderr, "pandaseq_amd: %s\n", pamd_last_error());
+				abort();	// a device failure is fatal, never silently wrong
+			}
+		}
+		for (size_t i = 0; i < m; i++) {
+			const panda_result_seq *r = host ? host_assemble(a, &ids[base + i], forward[base + i], forward_length[base + i], reverse[base + i], reverse_length[base + i]) : replay(a, i, forward[base + i], reverse[base + i]);
+			assembled += r != nullptr;
+			if (visit != nullptr)
+				visit(base + i, r, user_data);
+		}
+	}
+	return assembled;
+}
+
 const panda_result_seq *panda_assembler_next(PandaAssembler a) {
 	if (a->next == nullptr)
 		return nullptr;
+	if (device_algo_of(a->algo) < 0 && !a->primed) {	// a class of the caller's: pair by pair on this thread (assembler.c:350-371)
+		for (;;) {
+			const panda_qual *f = nullptr, *r = nullptr;
+			size_t fl = 0, rl = 0;
+			if (!a->next(&a->result.name, &f, &fl, &r, &rl, a->next_data))
+				return nullptr;
+			if (fl > PAMD_MAX_LEN || rl > PAMD_MAX_LEN) {	// the reference asserts (assembler.c:359-360)
+				fprintf(stderr, "pandaseq_amd: read longer than PANDA_MAX_LEN\n");
+				abort();
+			}
+			const panda_result_seq *res = host_assemble(a, &a->result.name, f, fl, r, rl);
+			if (res != nullptr)
+				return res;
+		}
+	}
 	if (a->slots[0] == nullptr) {
 		for (int k = 0; k < panda_assembler::NSLOT; k++) {
 			a->slots[k] = new pamd_slot;
@@ -1500,6 +1932,14 @@ PandaAlgorithm panda_assembler_get_algorithm(PandaAssembler a) {
 void panda_assembler_set_algorithm(PandaAssembler a, PandaAlgorithm algorithm) {
 	if (algorithm == nullptr)
 		return;
+	// one of this library's seven classes (scored by the kernels), or a class that brings its own two functions (scored on
+	// the host through them, as the reference calls them: assembler.c:54-57,125,209); anything else has no implementation
+	// here: say so now and keep the algorithm the assembler had, rather than fail at the first batch
+	const struct panda_algorithm_class *cls = panda_algorithm_class(algorithm);
+	if (device_algo_of(algorithm) < 0 && (cls == nullptr || cls->overlap_probability == nullptr || cls->match_probability == nullptr)) {
+		fprintf(stderr, "pandaseq_amd: algorithm %s has neither a device implementation nor overlap_probability / match_probability functions; keeping %s\n", cls != nullptr && cls->name != nullptr ? cls->name : "(unnamed)", a->algo != nullptr ? panda_algorithm_class(a->algo)->name : "(none)");
+		return;
+	}
 	panda_algorithm_unref(a->algo);
 	a->algo = panda_algorithm_ref(algorithm);
 	a->dev_dirty = true;

@@ -207,7 +207,7 @@ __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// this wave's row stores have reached L2
 	u64 pair = first_pair + (u64) lane * pair_step;
 	if (LIST && lane < npend)
-		pair = list != nullptr ? __hip_atomic_load(list + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)	// the wave's own record of what it
+		pair = list != nullptr ? __hip_atomic_load(list + pair, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)	// the wave's own record of what it
 												// took from the queue, rewritten every 64 pairs: read past the L1
 				       : P.pair_list[pair];
 	bool deferred = false;

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void pamd_encode_kernel(const double *p, uint1
 			const unsigned long long bits = (unsigned long long) __double_as_longlong(x);
 			unsigned h = slot_of(bits);
 			uint16_t found = 0xFFFFu;	// what lies between rows (never written) is no table entry
-			for (int tries = 0; tries < 64; tries++) {
+			for (int tries = 0; tries < PAMD_ENCODE_PROBES; tries++) {
 				const uint16_t s = sl[h];
 				if (s == 0xFFFFu)
 					break;

@@ -1663,7 +1663,7 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		q = next < n_work ? next : last;
 		const u64 npid = plist != nullptr ? (u64) plist[q] : q;
 		if (!EXACT && queued && lane == 0)	// (exact sums park the pair's index with its record)
-			P.wave_pids[(u64) wave_gid * 64u + (u64) npend] = (uint32_t) pid;
+			__hip_atomic_store(&P.wave_pids[(u64) wave_gid * 64u + (u64) npend], (uint32_t) pid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);	// read back by other lanes in finish64 (acquire)
 		Carry nxt;
 		nxt.flen_v = P.flen[npid];
 		nxt.rlen_v = P.rlen[npid];

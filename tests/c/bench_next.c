@@ -7,7 +7,8 @@
  * included: the source callback, the copies into pinned memory, PCIe both ways, the kernels, the expansion into
  * panda_result[] and a consumer that reads every merged base.  Plain C, written as an embedder writes it.
  *
- * usage: bench_next <pairs.bin> <total pairs> <algo> <exact sums 0|1> [batch pairs] [consume]
+ * usage: bench_next <pairs.bin> <total pairs> <algo> <exact sums 0|1> [batch pairs] [consume] [api]
+ *   api: 0 = the panda_assembler_next loop; 1 = panda_assembler_assemble per pair (diff.c:26-99); 2 = pamd_compat_assemble_many
  *   consume: 0 = the record's scalars only (length, overlap, quality); 1 = + every merged nt; 2 = + every log-p
  *            (default 2: what a FASTQ writer reads, output.c:100-126.  At 16 bytes per base, pandaseq-common.h:221-230,
  *            that is 6 KB of memory traffic per 2x250 pair on the consumer's one thread.)
@@ -57,6 +58,32 @@ static double now(void) {
 	return (double) t.tv_sec + 1e-9 * (double) t.tv_nsec;
 }
 
+struct tally {
+	uint64_t returned, bases, check, pbits;
+	double psum;
+	int consume;
+};
+
+static void tally_visit(size_t index, const panda_result_seq *res, void *user_data) {
+	struct tally *t = user_data;
+	(void) index;
+	if (res == NULL)
+		return;
+	t->returned++;
+	t->bases += res->sequence_length;
+	t->psum += res->quality;
+	t->check += res->overlap;
+	if (t->consume >= 1)
+		for (size_t j = 0; j < res->sequence_length; j++)
+			t->check += (uint64_t) res->sequence[j].nt;
+	if (t->consume >= 2)
+		for (size_t j = 0; j < res->sequence_length; j++) {
+			uint64_t b;
+			memcpy(&b, &res->sequence[j].p, 8);
+			t->pbits ^= b;
+		}
+}
+
 int main(int argc, char **argv) {
 	if (argc < 5) {
 		fprintf(stderr, "usage: bench_next <pairs.bin> <total pairs> <algo> <exact 0|1> [batch pairs]\n");
@@ -89,24 +116,56 @@ int main(int argc, char **argv) {
 		panda_assembler_set_algorithm(a, algo);
 		panda_algorithm_unref(algo);
 	}
+	const int api = argc > 7 ? atoi(argv[7]) : 0;	/* 0: panda_assembler_next; 1: panda_assembler_assemble, pair by pair; 2: pamd_compat_assemble_many */
 	const double t0 = now();
 	const panda_result_seq *res;
 	uint64_t returned = 0, bases = 0, check = 0, pbits = 0;
 	double psum = 0.0;
-	while ((res = panda_assembler_next(a)) != NULL) {
-		returned++;
-		bases += res->sequence_length;
-		psum += res->quality;
-		check += res->overlap;
-		if (consume >= 1)
-			for (size_t j = 0; j < res->sequence_length; j++)
-				check += (uint64_t) res->sequence[j].nt;
-		if (consume >= 2)
-			for (size_t j = 0; j < res->sequence_length; j++) {
-				uint64_t b;
-				memcpy(&b, &res->sequence[j].p, 8);
-				pbits ^= b;
-			}
+#define CONSUME(res)                                                               \
+	do {                                                                       \
+		returned++;                                                        \
+		bases += (res)->sequence_length;                                   \
+		psum += (res)->quality;                                            \
+		check += (res)->overlap;                                           \
+		if (consume >= 1)                                                  \
+			for (size_t j = 0; j < (res)->sequence_length; j++)        \
+				check += (uint64_t) (res)->sequence[j].nt;         \
+		if (consume >= 2)                                                  \
+			for (size_t j = 0; j < (res)->sequence_length; j++) {      \
+				uint64_t b;                                        \
+				memcpy(&b, &(res)->sequence[j].p, 8);              \
+				pbits ^= b;                                        \
+			}                                                          \
+	} while (0)
+	if (api == 0) {
+		while ((res = panda_assembler_next(a)) != NULL)
+			CONSUME(res);
+	} else if (api == 1) {	/* what panda_diff does (diff.c:26-99): the caller holds the pair and asks for its assembly */
+		panda_seq_identifier id;
+		const panda_qual *f, *r;
+		size_t fl, rl;
+		while (next_pair(&id, &f, &fl, &r, &rl, &src))
+			if ((res = panda_assembler_assemble(a, &id, f, fl, r, rl)) != NULL)
+				CONSUME(res);
+	} else {	/* the same pairs handed over as arrays, 65536 at a time */
+		enum { CHUNK = 65536 };
+		panda_seq_identifier *ids = malloc(CHUNK * sizeof *ids);
+		const panda_qual **fs = malloc(CHUNK * sizeof *fs), **rs = malloc(CHUNK * sizeof *rs);
+		size_t *fls = malloc(CHUNK * sizeof *fls), *rls = malloc(CHUNK * sizeof *rls);
+		struct tally t = { 0, 0, 0, 0, 0.0, consume };
+		for (;;) {
+			size_t m = 0;
+			while (m < CHUNK && next_pair(&ids[m], &fs[m], &fls[m], &rs[m], &rls[m], &src))
+				m++;
+			if (m == 0)
+				break;
+			pamd_compat_assemble_many(a, ids, fs, fls, rs, rls, m, tally_visit, &t);
+		}
+		returned = t.returned;
+		bases = t.bases;
+		check = t.check;
+		pbits = t.pbits;
+		psum = t.psum;
 	}
 	check ^= pbits;
 	const double t1 = now();

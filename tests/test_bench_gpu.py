@@ -59,6 +59,8 @@ def test_bench_two_ranks_sharded(built):
     assert single.returncode == 0, single.stderr[-2000:]
     s = json.loads(single.stdout.strip().splitlines()[-1])
     assert d["stat"] == s["stat"]
+    # ... and so does the STAT block a reference worker would print from them (pool.c:86-104), overlap histogram included
+    assert d["stat_block_sha1"] == s["stat_block_sha1"]
 
 
 def test_bench_chunked_launches(built):

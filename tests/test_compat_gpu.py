@@ -279,3 +279,57 @@ def test_fused_modules_after_a_host_module(built, tmp_path):
     assert [g["index"] for g in got] == expected
     host_rejected = int(((plain["status"] == 0) & (plain["mismatches"] > 3)).sum())
     assert counters[8] == host_rejected and 0 < len(expected) < int((plain["status"] == 0).sum()) - host_rejected
+
+
+def _build_c(tmp, name):
+    exe = os.path.join(tmp, name)
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", name + ".c"), "-o", exe, "-lm",
+                           "-rdynamic", "-L", os.path.join(ROOT, "pandaseq_amd"), "-lpandaseq_amd", "-ldl",
+                           "-Wl,-rpath," + os.path.join(ROOT, "pandaseq_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+@pytest.mark.parametrize("primers", [False, True])
+def test_algorithm_class_registered_by_the_caller(built, tmp_path, primers):
+    """algo.c:106-120, assembler.c:54-57,125,209: a class the caller registers is scored through its own two functions, on
+    the host path of the library.  The class here is a twin of simple_bayesian written from the published formulas, so every
+    record, merged base, log-p and counter must equal what the kernels produce for the library's own simple_bayesian; a
+    class with neither functions nor a device form is refused by the setter (the assembler keeps its algorithm)."""
+    from pandaseq_amd import synth
+    from util import adversarial_pairs
+    spec = synth.config_spec(2 if primers else 1)
+    if primers:
+        fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 600)
+    else:
+        fwd, rev, flen, rlen = adversarial_pairs(spec, 600, seed=31)
+    pairs = tmp_path / "pairs.bin"
+    _write_pairs(pairs, fwd, rev, flen, rlen)
+    exe = _build_c(str(tmp_path), "test_custom_algo")
+    out = subprocess.run([exe, str(pairs)] + (["primers"] if primers else []), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("same 600 pairs"), out.stdout
+
+
+def test_reference_api_default_sums(built, tmp_path):
+    """Without PAMD_COMPAT_SUMS / pamd_compat_set_exact_sums the reference API sums in any order: every decision, merged
+    base and per-base log-p as the oracle's, `quality` within 1e-9 (north_star: 1e-6)."""
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 500, 700)
+    pin, pout = tmp_path / "pairs.bin", tmp_path / "out.bin"
+    _write_pairs(pin, fwd, rev, flen, rlen)
+    env = dict(os.environ)
+    env.pop("PAMD_COMPAT_SUMS", None)
+    subprocess.check_call([_build_client(str(tmp_path)), str(pin), str(pout), "simple_bayesian", "0"], timeout=300, env=env)
+    got, counters, _ = _parse_output(pout.read_bytes())
+    o_res, o_nt, o_p, o_ctr = po.assemble_batch(po.make_config("simple_bayesian"), fwd, rev, flen, rlen)
+    assert len(got) == int(o_ctr["ok"]) > 600
+    worst = 0.0
+    for g in got:
+        i = g["index"]
+        assert o_res["status"][i] == 0 and g["overlap"] == o_res["overlap"][i] and g["seq_len"] == o_res["seq_len"][i]
+        assert np.array_equal(g["nt"], o_nt[i, :g["seq_len"]]) and np.array_equal(g["p"], o_p[i, :g["seq_len"]])
+        worst = max(worst, abs(g["quality"] - o_res["quality"][i]))
+    assert worst <= 1e-9

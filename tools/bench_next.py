@@ -36,7 +36,7 @@ def write_pairs(path, fwd, rev, flen, rlen):
         fh.write(rec.tobytes())
 
 
-def run(config=1, pairs=4_000_000, sums="exact", batch=65536, distinct=8192, algo=None, consume=2):
+def run(config=1, pairs=4_000_000, sums="exact", batch=65536, distinct=8192, algo=None, consume=2, api=0, rows="eager"):
     from pandaseq_amd import synth
     import bench
     spec = synth.config_spec(config)
@@ -45,9 +45,11 @@ def run(config=1, pairs=4_000_000, sums="exact", batch=65536, distinct=8192, alg
         fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, min(distinct, pairs))
         pin = os.path.join(tmp, "pairs.bin")
         write_pairs(pin, fwd, rev, flen, rlen)
-        out = subprocess.check_output([exe, pin, str(pairs), algo or bench.CONFIGS[config]["algo"].replace("simple_bayesian", "sb"), "1" if sums == "exact" else "0", str(batch), str(consume)], timeout=1200)
+        env = dict(os.environ)
+        env["PAMD_COMPAT_ROWS"] = rows
+        out = subprocess.check_output([exe, pin, str(pairs), algo or bench.CONFIGS[config]["algo"].replace("simple_bayesian", "sb"), "1" if sums == "exact" else "0", str(batch), str(consume), str(api)], timeout=1200, env=env)
     d = json.loads(out.decode().strip().splitlines()[-1])
-    d.update(config=config, sums=sums, batch_pairs=batch, distinct_pairs=min(distinct, pairs),
+    d.update(config=config, sums=sums, batch_pairs=batch, distinct_pairs=min(distinct, pairs), api=("panda_assembler_next", "panda_assembler_assemble", "pamd_compat_assemble_many")[api], rows=rows,
              path="in-memory PandaNextSeq source -> panda_assembler_next (pinned staging, two batches in flight, index-coded download) -> consumer reading every merged base")
     return d
 
