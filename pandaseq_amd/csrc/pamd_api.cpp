@@ -72,8 +72,6 @@ struct pamd_assembler {
 	uint32_t *d_defer = nullptr;	// the pairs it leaves to the general kernel ...
 	size_t defer_cap = 0;
 	unsigned *d_defer_count = nullptr;	// ... and how many; the word behind it: how many of them the general kernel's waves have taken
-	uint32_t *d_wave_pids = nullptr;	// general kernel over the list: the pairs behind each wave's parked records ...
-	size_t wave_pids_cap = 0;	// ... for this many waves
 	bool last_two_kernels = false;
 	double *d_notp = nullptr;
 	std::vector<double> h_image;	// host copy of the table image on the device (pamd_table_image)
@@ -211,8 +209,6 @@ void pamd_assembler_destroy(pamd_assembler *a) {
 		(void) hipFree(a->d_count_table);
 	if (a->d_defer_count)
 		(void) hipFree(a->d_defer_count);
-	if (a->d_wave_pids)
-		(void) hipFree(a->d_wave_pids);
 	for (void *q : a->hb_ptr)
 		if (q)
 			(void) hipFree(q);
@@ -724,17 +720,8 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 		a->primer_cap = b->n_pairs;
 	}
 	p.primer_offsets = primers_first ? a->d_primer_off : nullptr;
-	// the general kernel's work queue (a counter) and its waves' records of what they took
-	if ((size_t) wgs * (size_t) waves > a->wave_pids_cap) {
-		if (a->d_wave_pids)
-			HIP_TRY(hipFree(a->d_wave_pids));
-		a->d_wave_pids = nullptr;
-		a->wave_pids_cap = 0;
-		HIP_TRY(hipMalloc(&a->d_wave_pids, (size_t) wgs * (size_t) waves * 64u * sizeof(uint32_t)));
-		a->wave_pids_cap = (size_t) wgs * (size_t) waves;
-	}
+	// the general kernel's work queue (a counter)
 	p.pair_cursor = b->n_pairs <= 0xFF000000ull ? a->d_defer_count + 1 : nullptr;	// (a 32-bit counter that every wave overshoots by up to sixteen; beyond it fixed shares)
-	p.wave_pids = a->d_wave_pids;
 	// One launch in flight per assembler: a launch owns the assembler's deferred list, work counters, per-wave records and
 	// primer words, and zeroes them on its stream.  A launch on another stream than the previous one waits for it.
 	if (a->timed && a->last_stream != st)

@@ -156,6 +156,7 @@ struct Pend64 {
 	unsigned ex_mm;			// examined | mismatches << 16
 	unsigned dg_fo;			// degenerates | forward offset << 16
 	unsigned ro_st;			// reverse offset | status << 16 | slow << 24 | "q is final" << 25 | smallest phred (63 = none) << 26
+	unsigned pid;			// the pair's index, where a wave takes its pairs from a work queue (general kernel)
 };
 
 __device__ __forceinline__ unsigned put_lane(unsigned reg, unsigned value, bool mine) {
@@ -199,17 +200,18 @@ __device__ __forceinline__ double ordered_row_sum(const double *row, int lo, int
 // EXACTQ (the lean kernel with exact sums): the quality sums are made here, in the reference's order, every lane walking
 // the three chains of its own pair's row (which this wave wrote; dg_fo carries the number of forward-only bases in its
 // upper half instead of a forward offset, which the lean kernel does not have).
-template <bool LIST, bool DEFER, bool EXACTQ = false>
-__device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64 &pd, int npend, u64 first_pair, u64 pair_step, int lane, const uint32_t *list = nullptr) {
+// QUEUED: the pairs' indices are in pd.pid (the wave took them from a work queue).
+template <bool LIST, bool DEFER, bool EXACTQ = false, bool QUEUED = false>
+__device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64 &pd, int npend, u64 first_pair, u64 pair_step, int lane) {
 	int status = -1, reject = -1;
 	bool slow = false;
 	if (EXACTQ)
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// this wave's row stores have reached L2
 	u64 pair = first_pair + (u64) lane * pair_step;
-	if (LIST && lane < npend)
-		pair = list != nullptr ? __hip_atomic_load(list + pair, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)	// the wave's own record of what it
-												// took from the queue, rewritten every 64 pairs: read past the L1
-				       : P.pair_list[pair];
+	if (QUEUED)
+		pair = (u64) pd.pid;
+	else if (LIST && lane < npend)
+		pair = P.pair_list[pair];
 	bool deferred = false;
 	if (DEFER) {
 		deferred = lane < npend && ((pd.ro_st >> 16) & 0xFFu) == (unsigned) PAMD_ST_DEFER;

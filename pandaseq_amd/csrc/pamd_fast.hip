@@ -38,11 +38,12 @@ constexpr unsigned EMPTY = 0xFFFFFFFFu;
 // reads as panda_qual rows; 2-bit code streams and N maps (16 bases per word; the scan reads up to one word either side
 // of a stream: the neighbouring arrays, masked); candidate flags, one byte per overlap; merged-nt staging (+64: lanes past
 // a row's end write into slack); the four k-mer tables
-constexpr unsigned FK_F = 0, FK_R = 512, FK_FC = 1024, FK_RC = 1088, FK_FN = 1152, FK_RN = 1216, FK_FLAGS = 1296, FK_NT = 1552;
+// (16 bytes before the forward N map hold N flags: seeding by windows of the streams starts eight bases before the read)
+constexpr unsigned FK_F = 0, FK_R = 512, FK_FC = 1024, FK_RC = 1088, FK_PAD0 = 1152, FK_FN = 1168, FK_RN = 1232, FK_FLAGS = 1312, FK_NT = 1568;
 // the first k-mer table has 2^T1B slots: 1024 where the scorer's tables leave room (36 KB of them per workgroup), 512 for
 // rdp_mle (54 KB: a third matrix); the other three are fixed
 constexpr unsigned FK_T2_SLOTS = 256, FK_T3_SLOTS = 64, FK_T4_SLOTS = 32;
-constexpr unsigned FK_T1 = 2128;
+constexpr unsigned FK_T1 = 2144;
 // Two geometries.  LONG = false: reads of at most 256 bases, four bases per lane (the offsets above).  LONG = true: reads of
 // at most 320 bases (2x300), primers and trims: rows arrive eight bases per lane, seeding runs five bases per lane on
 // windows of the code streams, and what is only needed before seeding (the primer scan's nibble streams and scratch) or
@@ -51,8 +52,8 @@ template <bool LONG>
 struct Lay;
 template <>
 struct Lay<false> {
-	static constexpr unsigned F = FK_F, R = FK_R, FC = FK_FC, RC = FK_RC, FN = FK_FN, RN = FK_RN, FLAGS = FK_FLAGS, NT = FK_NT, T1 = FK_T1;
-	static constexpr int BPL = 4;		// bases per lane while seeding
+	static constexpr unsigned F = FK_F, R = FK_R, FC = FK_FC, RC = FK_RC, PAD0 = FK_PAD0, FN = FK_FN, RN = FK_RN, FLAGS = FK_FLAGS, NT = FK_NT, T1 = FK_T1;
+	static constexpr int BPL = 4;		// bases per lane while seeding (3 for reads of at most 192 bases: NARROW)
 	static constexpr int MAXLEN = 256;
 	static constexpr int NR = 8;		// rounds of 64 bases a merged row can span
 	static constexpr int SR = 4;		// rounds of 64 positions an overlap can span
@@ -841,10 +842,13 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 #endif
 
 // LONG: the geometry (Lay<LONG>).  PRIM (LONG only): primers (`-p` / `-q`, found by primer_quick) or trims are configured.
-template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM>
+// NARROW (short geometry only): reads of at most 192 bases seed three bases per lane, on windows of the code streams
+template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW>
 __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases) {
 	typedef Lay<LONG> L;
-	constexpr int BPL = L::BPL;
+	constexpr int BPL = NARROW ? 3 : L::BPL;
+	constexpr bool WINDOWS = BPL != 4;	// k-mers from unaligned words of the code streams (else from the neighbouring lanes' registers)
+	static_assert(!NARROW || !LONG, "three bases per lane belong to the short geometry");
 	static_assert(!PRIM || LONG, "primers and trims are served by the LONG geometry");
 	static_assert(!EXACT || !LONG, "exact sums are served by the short geometry");
 	const auto fv = cur.f, rv = cur.r;
@@ -1002,10 +1006,10 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		bool deep = false;
 		{
 			unsigned w, nw;	// base BPL*l - 8 + b at bits 2b..2b+1 of w, its N flag at bit 2b of nw
-			if constexpr (LONG) {
-				// five positions per lane, p = 5*lane + j: the sixteen bases from 5*lane - 8 are one unaligned word of the code
-				// stream and of the N map (before the read: the pad word, all N)
-				const int fb = 10 * lane - 16;
+			if constexpr (WINDOWS) {
+				// BPL positions per lane, p = BPL*lane + j: the sixteen bases from BPL*lane - 8 are one unaligned word of the
+				// code stream and of the N map (before the read: the pad word, all N)
+				const int fb = 2 * BPL * lane - 16;
 				const unsigned *cw = reinterpret_cast<const unsigned *>(wb + L::FC) + (fb >> 5), *nwp = reinterpret_cast<const unsigned *>(wb + L::FN) + (fb >> 5);
 				const unsigned c0 = cw[0], c1 = cw[1], n0 = nwp[0], n1 = nwp[1];
 				w = __builtin_amdgcn_alignbit(c1, c0, (unsigned) fb & 31u);
@@ -1062,13 +1066,15 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		wave_sync();
 		STOP(1);
 		MARK("seed-rev");
+		int ncand = 0, ov0 = 0, ov1 = 0, ov2 = 0, ov3 = 0;
+		bool all = false, quick = false;
 		// ---- seed: reverse k-mers flag candidate overlaps (assembler.c:104-110) ----
 		// The k-mer at p covers bases p .. p+7 and is emitted iff p <= rlen-9 and none of p .. p+8 is N: the codes of
 		// lanes l, l+1, l+2.  Its two smallest forward positions are the reference's first two (kmerseen[2k], [2k+1]).
 		{
 			unsigned w, nw;	// base BPL*l + b at bits 2b..2b+1 of w, its N flag at bit 2b+1 of nw
-			if constexpr (LONG) {
-				const int rb = 10 * lane;
+			if constexpr (WINDOWS) {
+				const int rb = 2 * BPL * lane;
 				const unsigned *cw = reinterpret_cast<const unsigned *>(wb + L::RC) + (rb >> 5), *nwp = reinterpret_cast<const unsigned *>(wb + L::RN) + (rb >> 5);
 				const unsigned c0 = cw[0], c1 = cw[1], n0 = nwp[0], n1 = nwp[1];
 				w = __builtin_amdgcn_alignbit(c1, c0, (unsigned) rb & 31u);
@@ -1108,30 +1114,69 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				}
 			}
 			bool second = false;
+			unsigned idx1[BPL];	// the overlap (less minov) this k-mer's first forward position votes for; out of range: none
 #pragma unroll
 			for (int j = 0; j < BPL; j++) {
 				const unsigned idx = top - (unsigned) j - m1[j];	// no match: m1 >= 0x10000 wraps far beyond size
-				if (ok[j] && idx < (unsigned) size)
-					flags[idx] = 1;
+				idx1[j] = ok[j] && idx < (unsigned) size ? idx : EMPTY;
 				second |= ok[j] && m2[j] < 0xFFFFu;	// (an empty slot reads as 0xFFFF for the k-mer 0xFFFF)
 			}
-			if (ballot(second) != 0) {	// a k-mer that occurs twice in the forward read
+			const bool twice = ballot(second) != 0;	// a k-mer that occurs twice in the forward read
+			// Nearly every pair's k-mers vote for one overlap, or for that and a stray one: settled here in registers, the
+			// candidates need neither the flag bytes nor the walk over them.
+			if (!twice) {
+				unsigned mine = EMPTY;
 #pragma unroll
-				for (int j = 0; j < BPL; j++) {
-					const unsigned idx = top - (unsigned) j - m2[j];
-					if (ok[j] && idx < (unsigned) size)
-						flags[idx] = 1;
+				for (int j = BPL - 1; j >= 0; j--)
+					mine = idx1[j] != EMPTY ? idx1[j] : mine;
+				const u64 have = ballot(mine != EMPTY);
+				if (have != 0) {
+					const unsigned c0 = (unsigned) __builtin_amdgcn_readlane((int) mine, __builtin_ctzll(have));
+					unsigned other = EMPTY;
+#pragma unroll
+					for (int j = 0; j < BPL; j++)
+						other = (idx1[j] != EMPTY && idx1[j] != c0) ? idx1[j] : other;
+					const u64 oth = ballot(other != EMPTY);
+					if (oth == 0) {
+						ncand = 1;
+						ov0 = (int) c0 + minov;
+						quick = true;
+					} else {
+						const unsigned c1 = (unsigned) __builtin_amdgcn_readlane((int) other, __builtin_ctzll(oth));
+						bool third = false;
+#pragma unroll
+						for (int j = 0; j < BPL; j++)
+							third |= idx1[j] != EMPTY && idx1[j] != c0 && idx1[j] != c1;
+						if (ballot(third) == 0) {
+							ncand = 2;
+							ov0 = (int) (c0 < c1 ? c0 : c1) + minov;	// ascending, as the scan walks them (assembler.c:120)
+							ov1 = (int) (c0 < c1 ? c1 : c0) + minov;
+							quick = true;
+						}
+					}
+				}
+			}
+			if (!quick) {
+#pragma unroll
+				for (int j = 0; j < BPL; j++)
+					if (idx1[j] != EMPTY)
+						flags[idx1[j]] = 1;
+				if (twice) {
+#pragma unroll
+					for (int j = 0; j < BPL; j++) {
+						const unsigned idx = top - (unsigned) j - m2[j];
+						if (ok[j] && idx < (unsigned) size)
+							flags[idx] = 1;
+					}
 				}
 			}
 		}
-		wave_sync();
 		STOP(2);
 		MARK("candidates");
 
 		// ---- the candidates (assembler.c:118-143) ----
-		int ncand = 0, ov0 = 0, ov1 = 0, ov2 = 0, ov3 = 0;
-		bool all = false;
-		{
+		if (!quick) {
+			wave_sync();
 			const unsigned mine = reinterpret_cast<const unsigned *>(flags)[lane];	// overlaps minov + 4*lane + 0..3
 			// (kept as scalar selects: indexed by ncand the four overlaps would live in scratch memory)
 #define FK_TAKE(NZ, MINE, BASE)                                                                  \
@@ -1442,19 +1487,27 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			nt_out = ok ? nt : 0u;
 			mism += __popcll(ballot(inF) & ballot(inR) & ~ballot(match));
 		};
-		// two rounds per trip, straight-line; trips nest so that nothing but the accumulators lives across them
-		// (four rounds per trip, their table reads in flight together: no faster on 2x250, slower on 2x300 -- registers)
-		auto trip = [&](auto r0c) __attribute__((always_inline)) {
-			constexpr int R0 = decltype(r0c)::value;
-			unsigned qi[2], ntv[2];
+		// N rounds per trip, straight-line: their table reads are in flight together; trips nest so that nothing but the
+		// accumulators lives across them.  Four rounds per trip in the short geometry (a round past the row's end costs three
+		// instructions, an LDS round trip a couple of hundred cycles: 13 % on rdp_mle with its modules, nothing either way on
+		// simple_bayesian), two in the LONG one, which has no registers to spare.
+		auto trip = [&](auto r0c, auto nc) __attribute__((always_inline)) {
+			constexpr int R0 = decltype(r0c)::value, N = decltype(nc)::value;
+			unsigned qi[4], ntv[4];
 			round(std::integral_constant<int, R0>(), qi[0], ntv[0]);
 			round(std::integral_constant<int, R0 + 1>(), qi[1], ntv[1]);
-			double pv[2];
+			if constexpr (N > 2) {
+				round(std::integral_constant<int, R0 + 2>(), qi[2], ntv[2]);
+				round(std::integral_constant<int, R0 + 3>(), qi[3], ntv[3]);
+			}
+			double pv[4];
 #pragma unroll
-			for (int k = 0; k < 2; k++)
+			for (int k = 0; k < N; k++)
 				pv[k] = lds_read_f64(lT + 8u * qi[k]);
 #pragma unroll
-			for (int k = 0; k < 2; k++) {
+			for (int k = 0; k < N; k++) {
+				if (k > 1 && 64 * (R0 + k) >= seqlen)
+					break;
 				lds_write_u8(nN + 64u * (R0 + k), ntv[k]);
 				if (lane < lim - 64 * (R0 + k)) {
 					gP[64 * (R0 + k)] = pv[k];
@@ -1465,19 +1518,25 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				degen += __popcll(ballot((ntv[k] & 0xFFu) == 15u));	// PANDA_NT_IS_DEGN: only N here
 			}
 		};
-		trip(std::integral_constant<int, 0>());
-		if (seqlen > 128) {
-			trip(std::integral_constant<int, 2>());
-			if (seqlen > 256) {
-				trip(std::integral_constant<int, 4>());
-				if (seqlen > 384) {
-					trip(std::integral_constant<int, 6>());
-					if constexpr (LONG) {
+		typedef std::integral_constant<int, 2> two;
+		typedef std::integral_constant<int, 4> four;
+		if constexpr (LONG) {
+			trip(std::integral_constant<int, 0>(), two());
+			if (seqlen > 128) {
+				trip(std::integral_constant<int, 2>(), two());
+				if (seqlen > 256) {
+					trip(std::integral_constant<int, 4>(), two());
+					if (seqlen > 384) {
+						trip(std::integral_constant<int, 6>(), two());
 						if (seqlen > 512)
-							trip(std::integral_constant<int, 8>());
+							trip(std::integral_constant<int, 8>(), two());
 					}
 				}
 			}
+		} else {
+			trip(std::integral_constant<int, 0>(), four());
+			if (seqlen > 256)
+				trip(std::integral_constant<int, 4>(), four());
 		}
 		wave_sync();
 		STOP(4);
@@ -1548,7 +1607,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 // (one 16-wave workgroup fills a CU's LDS: four waves per SIMD whatever the registers allow, so the compiler is told to
 // spend all 128 vector registers on scheduling instead of saving them for waves that cannot come -- 1 % on a 16 M-pair
 // launch, nothing measurable at 50 M)
-template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM>
+template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW>
 __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const PamdKernelParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	double *ltab = reinterpret_cast<double *>(lds);
@@ -1564,12 +1623,12 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 		lctr[i] = 0;
 	unsigned char *wb = lds + P.lds_primer_off + (size_t) wave * Geo<LONG, t1_bits<ALGO>()>::WAVE_BYTES;	// (the per-wave regions start where the general kernel keeps its primers)
 	unsigned primer_bases = 0;	// PRIM: this lane's base of the forward primer | of the reverse primer << 8 (N past their ends) | << 16: lanes 0..31 the forward, lanes 32..63 the reverse primer's bases 0..31
+	// what lies before a read reads as N: the word before the forward N map (seed windows start eight bases early)
+	if (lane < 4)
+		reinterpret_cast<unsigned *>(wb + Lay<LONG>::PAD0)[lane] = 0x55555555u;
 	if constexpr (LONG) {
-		// what lies before a read reads as N: the word before the forward N map (seed windows start eight bases early)
-		if (lane < 4) {
-			reinterpret_cast<unsigned *>(wb + Lay<true>::PAD0)[lane] = 0x55555555u;
+		if (lane < 4)
 			reinterpret_cast<unsigned *>(wb + Lay<true>::PAD1)[lane] = 0xAAAAAAAAu;
-		}
 		if constexpr (PRIM)
 			primer_bases = (lane < P.fprimer_len ? (unsigned) P.primers[lane] : 15u) | ((lane < P.rprimer_len ? (unsigned) P.primers[456 + lane] : 15u) << 8)
 				       | ((lane < 32 ? (lane < P.fprimer_len ? (unsigned) P.primers[lane] : 15u) : (lane - 32 < P.rprimer_len ? (unsigned) P.primers[456 + lane - 32] : 15u)) << 16);
@@ -1602,7 +1661,7 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 		Carry<LONG> nxt;
 		load_pair<LONG>(nxt, P, q, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
-		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane, flen, rlen, cur, nxt, primer_bases);
+		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane, flen, rlen, cur, nxt, primer_bases);
 		MARK("loop");
 		npend++;
 		if (npend == 64) {
@@ -1661,8 +1720,10 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	void (*kern)(const PamdKernelParams) = nullptr;
 	const int variant = pamd_fast_supports(p);
-#define FK_PICK2(A, PH) (variant == PAMD_FAST_SHORT ? (p.exact_sums ? pamd_fast_kernel<A, true, PH, false, false> : pamd_fast_kernel<A, false, PH, false, false>) \
-						    : (variant == PAMD_FAST_LONG ? pamd_fast_kernel<A, false, PH, true, false> : pamd_fast_kernel<A, false, PH, true, true>))
+	const bool narrow = p.smax <= 192;	// three bases per lane cover the reads
+#define FK_PICK3(A, PH, E) (narrow ? pamd_fast_kernel<A, E, PH, false, false, true> : pamd_fast_kernel<A, E, PH, false, false, false>)
+#define FK_PICK2(A, PH) (variant == PAMD_FAST_SHORT ? (p.exact_sums ? FK_PICK3(A, PH, true) : FK_PICK3(A, PH, false)) \
+						    : (variant == PAMD_FAST_LONG ? pamd_fast_kernel<A, false, PH, true, false, false> : pamd_fast_kernel<A, false, PH, true, true, false>))
 #define FK_PICK(A) (p.has_min_phred ? FK_PICK2(A, true) : FK_PICK2(A, false))
 	switch (variant == 0 ? -1 : p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
@@ -1692,6 +1753,7 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 	}
 #undef FK_PICK
 #undef FK_PICK2
+#undef FK_PICK3
 	hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 	if (e0 != hipSuccess) {
 		pamd_set_error("hipFuncSetAttribute(%zu bytes LDS, lean kernel): %s", lds_bytes, hipGetErrorString(e0));

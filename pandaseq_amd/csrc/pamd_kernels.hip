@@ -1662,8 +1662,8 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		const u64 next = queued ? take() : pair + total_waves;
 		q = next < n_work ? next : last;
 		const u64 npid = plist != nullptr ? (u64) plist[q] : q;
-		if (!EXACT && queued && lane == 0)	// (exact sums park the pair's index with its record)
-			__hip_atomic_store(&P.wave_pids[(u64) wave_gid * 64u + (u64) npend], (uint32_t) pid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);	// read back by other lanes in finish64 (acquire)
+		if (!EXACT && queued)	// which pair this is, parked with its scalars (exact sums park the pair's index with its record)
+			pd.pid = put_lane(pd.pid, (unsigned) pid, lane == npend);
 		Carry nxt;
 		nxt.flen_v = P.flen[npid];
 		nxt.rlen_v = P.rlen[npid];
@@ -1680,7 +1680,7 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		npend++;
 		if (!EXACT && npend == 64) {
 			if (queued)	// (the wave's own record says which pair is behind which parked record)
-				finish64<true, false>(P, lctr, pd, npend, (u64) wave_gid * 64u, 1, lane, P.wave_pids);
+				finish64<true, false, false, true>(P, lctr, pd, npend, 0, 0, lane);
 			else if (plist != nullptr)
 				finish64<true, false>(P, lctr, pd, npend, group_first, total_waves, lane);
 			else
@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		finish_group<ALGO>(P, ltab, lctr, pend, npend, wave_gid, lane);
 	if (!EXACT && npend > 0) {
 		if (queued)
-			finish64<true, false>(P, lctr, pd, npend, (u64) wave_gid * 64u, 1, lane, P.wave_pids);
+			finish64<true, false, false, true>(P, lctr, pd, npend, 0, 0, lane);
 		else if (plist != nullptr)
 			finish64<true, false>(P, lctr, pd, npend, group_first, total_waves, lane);
 		else
