@@ -1431,29 +1431,32 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		gbl_f64 *const gP = (gbl_f64 *) (row_p + lane);
 		MARK("merge");
 		constexpr int NR = L::NR;
-		unsigned ef[NR], er[NR];
+		constexpr int NF = L::MAXLEN / 64;	// rounds that can hold a forward base (a read is at most MAXLEN bases long)
+		unsigned ef[NF], er[NR];
 		const unsigned aF = lF + 2u * (unsigned) (lane + fo);					// round r: F[fo + 64r + lane] ...
 		const unsigned aR = lR + 2u * (unsigned) (rlen - 1 + A - lane) - 128u * (NR - 1);	// ... and R[rlen - 1 - (64r + lane - A)]
 		{	// all rounds' bases up front: one wait (read trip by trip, a 2x300 pair's merge takes 70 % longer)
 #pragma unroll
 			for (int r = 0; r < NR; r++) {
-				ef[r] = lds_read_u16(aF + 128u * r);
+				if (r < NF)
+					ef[r] = lds_read_u16(aF + 128u * r);
 				er[r] = lds_read_u16(aR + 128u * (NR - 1 - r));
 			}
 		}
 		// one round: table index and base of output base 64 R + lane
 		auto round = [&](auto rc, unsigned &qi_out, unsigned &nt_out) __attribute__((always_inline)) {
 			constexpr int R = decltype(rc)::value;
-			const unsigned e_f = ef[R], e_r = er[R];
+			const unsigned e_r = er[R];
+			const bool ok = lane < lim - 64 * R;
+			if (R >= NF || 64 * R >= AF) {	// all reverse-only (assembler.c:231-243); past MAXLEN bases nothing else can be
+				qi_out = PAMD_LT_SCORE + (e_r >> 8);
+				nt_out = ok ? e_r : 0u;
+				return;
+			}
+			const unsigned e_f = ef[R < NF ? R : 0];
 			if (64 * (R + 1) <= A0) {	// all forward-only (assembler.c:162-173)
 				qi_out = PAMD_LT_SCORE + (e_f >> 8);
 				nt_out = e_f;
-				return;
-			}
-			const bool ok = lane < lim - 64 * R;
-			if (64 * R >= AF) {	// all reverse-only (assembler.c:231-243)
-				qi_out = PAMD_LT_SCORE + (e_r >> 8);
-				nt_out = ok ? e_r : 0u;
 				return;
 			}
 			const int j = 64 * R + lane;
