@@ -911,7 +911,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			ro = P.rtrim;
 			bool unsettled = false;
 			{
-				const int fpl = P.fprimer_len, rpl = P.rprimer_len;
+				int fpl = P.fprimer_len, rpl = P.rprimer_len;
+				asm volatile("" : "+s"(fpl), "+s"(rpl));	// (what follows is two multiplications per pair; hoisted out of the loop it is two spilled doubles)
 				const double thr_f = (double) fpl * P.threshold, thr_r = (double) rpl * P.threshold, inv_err_t = P.primer_inv_err_t;
 				// per read: -3 no primer configured, -2 not looked at yet, -1 not settled yet, >= 0 what the scan returns
 				// (a primer as long as the read, or longer, is not found: offset.c:55-57, :70)
@@ -1664,7 +1665,15 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 		Carry<LONG> nxt;
 		load_pair<LONG>(nxt, P, q, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
-		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane, flen, rlen, cur, nxt, primer_bases);
+		int lane_now = lane;
+		if constexpr (LONG) {
+			// The compiler hoists everything that depends on the lane number alone out of this loop -- multiples, shifts,
+			// LDS addresses -- and, out of registers, spills it: a reload from scratch memory then waits, vmcnt being one
+			// in-order queue, for whatever went before it, the rows just requested for the next pair among them.  Made opaque
+			// here, the lane number's derivatives are recomputed where they are used (an instruction or two each).
+			asm volatile("" : "+v"(lane_now));
+		}
+		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases);
 		MARK("loop");
 		npend++;
 		if (npend == 64) {
