@@ -1525,17 +1525,11 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		typedef std::integral_constant<int, 2> two;
 		typedef std::integral_constant<int, 4> four;
 		if constexpr (LONG) {
-			trip(std::integral_constant<int, 0>(), two());
-			if (seqlen > 128) {
-				trip(std::integral_constant<int, 2>(), two());
-				if (seqlen > 256) {
-					trip(std::integral_constant<int, 4>(), two());
-					if (seqlen > 384) {
-						trip(std::integral_constant<int, 6>(), two());
-						if (seqlen > 512)
-							trip(std::integral_constant<int, 8>(), two());
-					}
-				}
+			trip(std::integral_constant<int, 0>(), four());
+			if (seqlen > 256) {
+				trip(std::integral_constant<int, 4>(), four());
+				if (seqlen > 512)
+					trip(std::integral_constant<int, 8>(), two());
 			}
 		} else {
 			trip(std::integral_constant<int, 0>(), four());
