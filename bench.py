@@ -222,18 +222,20 @@ def main():
     algo_bytes = 2 * lens + 9 * merged_bases + 64 * n
     achieved = algo_bytes / avg_kernel_s / 1e9
 
-    # HBM bytes per launch from the PMC passes (tools/traffic_probe.py -> profiles/r02_traffic_config*.json):
+    # HBM bytes per launch from the PMC passes (tools/traffic_probe.py -> profiles/r03_traffic_config*.json):
     # FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, units calibrated on a 1 GiB copy in the same
     # process (gfx950: FETCH_SIZE counts 2 KiB per unit for wide reads).  Measured per pair on the same
     # workload; scaled to this launch's pair count.
     traffic = args.traffic_bytes
     traffic_src = "--traffic-bytes" if traffic is not None else None
-    tpath = os.path.join(ROOT, "profiles", f"r02_traffic_config{cfg_index}_{args.sums}.json")
+    tname = f"r03_traffic_config{cfg_index}_{args.sums}.json"
+    tpath = os.path.join(ROOT, "profiles", tname)
     if traffic is None and os.path.exists(tpath):
         with open(tpath) as fh:
             tj = json.load(fh)
         traffic = tj["hbm_bytes_per_pair"] * n
-        traffic_src = f"profiles/r02_traffic_config{cfg_index}_{args.sums}.json ({tj['pairs']} pairs per launch)"
+        traffic_src = (f"profiles/{tname}: FETCH_SIZE + WRITE_SIZE of one {tj['pairs']}-pair launch of the build of {tj.get('build', 'round 3')}, per pair, "
+                       f"scaled to this launch's {n} pairs (tools/refresh_profiles.sh re-measures it)")
 
     value = n * world * args.steps / elapsed
     out = {
@@ -270,7 +272,7 @@ def main():
         "stat_block_sha1": hashlib.sha1(format_stat_block(ctr, has_forward_primer=cfg_index == 2 and not args.primers_after, has_reverse_primer=cfg_index == 2 and not args.primers_after).encode()).hexdigest(),
         "roofline": {
             "bound": "hbm",
-            "kernel": ("pamd_fast_kernel + pamd_assemble_kernel over the pairs it deferred (both inside the HIP events)" if asm.last_deferred() >= 0
+            "kernel": ("pamd_fast_kernel + pamd_assemble_kernel over the pairs it deferred" + (" (+ pamd_primer_kernel over those deferred before their primers were found)" if cfg_index == 2 and not args.primers_after else "") + ", all inside the HIP events" if asm.last_deferred() >= 0
                        else "pamd_primer_kernel + pamd_assemble_kernel (both inside the HIP events)" if cfg_index == 2 and not args.primers_after
                        else "pamd_assemble_kernel"),
             "achieved": achieved,

@@ -36,6 +36,9 @@ out = {
     "hbm_read_bytes": a_rd * rd_unit,
     "hbm_write_bytes": a_wr * wr_unit,
 }
+import os
+if os.environ.get("PAMD_BUILD"):
+    out["build"] = os.environ["PAMD_BUILD"]   # the commit the measured library was built from (tools/refresh_profiles.sh)
 out["hbm_bytes_per_launch"] = out["hbm_read_bytes"] + out["hbm_write_bytes"]
 out["hbm_bytes_per_pair"] = out["hbm_bytes_per_launch"] / pairs
 print(json.dumps(out, indent=1))

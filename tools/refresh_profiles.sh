@@ -11,6 +11,9 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
+# which build this is: the GPU box has no .git, so the commit is written next to the sources before the trip
+# (git rev-parse --short HEAD > .build_id)
+export PAMD_BUILD=$(cat .build_id 2>/dev/null || git rev-parse --short HEAD 2>/dev/null || echo unknown)
 python3 bench.py --steps 5 --warmup 1 2> "$OUT/bench_config1_fast.err" | tail -1 > "$OUT/bench_config1_fast.json"
 python3 bench.py --steps 5 --warmup 1 --sums exact --no-cpu --no-e2e 2> /dev/null | tail -1 > "$OUT/bench_config1_exact.json"
 for c in 2 3 4; do python3 bench.py --steps 3 --warmup 1 --config $c --no-cpu --no-e2e 2> /dev/null | tail -1 > "$OUT/bench_config$c.json"; done
@@ -29,9 +32,11 @@ traffic 1 exact 50000000
 traffic 2 fast 20000000
 traffic 3 fast 20000000
 traffic 4 fast 40000000
-bash tools/pmc_fk.sh 8000000 1 > "$OUT/pmc_config1_fast.txt" 2>&1
-bash tools/pmc_primer.sh 4000000 > "$OUT/pmc_config2.txt" 2>&1
-bash tools/fk_phases.sh build > "$OUT/phases_build.log" 2>&1 && bash tools/fk_phases.sh 8000000 > "$OUT/phases_config1_fast.txt" 2>&1
-rm -rf "$ROOT"/pandaseq_amd/libpandaseq_amd_fkstop*
+for c in 1 2 3 4; do bash tools/pmc_fk.sh 8000000 $c > "$OUT/pmc_config${c}_fast.txt" 2>&1; done
+# the per-phase ablation wants six more builds of the library: make them BEFORE going to the GPU box (bash tools/fk_phases.sh build);
+# built there only if they did not travel
+ls "$ROOT"/pandaseq_amd/libpandaseq_amd_fkstop5.so > /dev/null 2>&1 || bash tools/fk_phases.sh build > "$OUT/phases_build.log" 2>&1
+bash tools/fk_phases.sh 8000000 1 > "$OUT/phases_config1_fast.txt" 2>&1
+bash tools/fk_phases.sh 8000000 2 > "$OUT/phases_config2_fast.txt" 2>&1
 for f in "$OUT"/bench_*.json; do python3 -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1].split('/')[-1], round(d['value']/1e6,1), 'M pairs/s', round(d['roofline']['frac'],4))" $f; done
 for f in "$OUT"/traffic_config*.json; do python3 -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1].split('/')[-1], round(d['hbm_bytes_per_pair'],1), 'B/pair')" $f; done
