@@ -356,6 +356,10 @@ def main():
             for name, consume, rows in (("record_only", 0, "eager"), ("every_base_read", 2, "eager"), ("every_base_read_rows_on_callers_thread", 2, "lazy")):
                 d = bench_next.run(config=cfg_index, pairs=args.e2e_pairs if consume == 0 else args.e2e_pairs // 4, sums=args.sums, consume=consume, rows=rows)
                 e2e[name] = {k: d[k] for k in keys}
+            # the reference's own deployment: one assembler per thread (pool.c:140-167), every thread reading every base
+            pool_threads = max(2, min(8, len(os.sched_getaffinity(0)) // 2))
+            d = bench_next.run_pool(config=cfg_index, pairs=(args.e2e_pairs // 2) * pool_threads, sums=args.sums, threads=pool_threads)
+            e2e["every_base_read_one_assembler_per_thread"] = {k: d[k] for k in keys + ("threads",)}
             # the per-pair entry point (what panda_diff calls, diff.c:26-99) and its array form
             d = bench_next.run(config=cfg_index, pairs=min(20000, args.e2e_pairs), sums=args.sums, consume=2, api=1)
             e2e["panda_assembler_assemble_per_pair"] = {k: d[k] for k in keys}
@@ -365,7 +369,8 @@ def main():
             e2e["path"] = ("tests/c/bench_next.c: while ((r = panda_assembler_next(a)) != NULL) over an in-memory PandaNextSeq source; pinned staging, four "
                            "batches in flight, log-p downloaded as u16 table indices, panda_result[] rows expanded by helper threads (rows: eager) or on the "
                            "caller's thread as each record is handed over (rows: lazy, PAMD_COMPAT_ROWS); record_only: the consumer reads each record's "
-                           "scalars; every_base_read: it reads nt and p of every merged base (16 B per base on its one thread); the last two entries: the "
+                           "scalars; every_base_read: it reads nt and p of every merged base (16 B per base on its one thread); ..._one_assembler_per_thread: "
+                           "tests/c/bench_pool.c, the same loop in `threads` threads with an assembler each, as pool.c:140-167 runs it; the last two entries: the "
                            "caller holds the pairs and calls panda_assembler_assemble() per pair / pamd_compat_assemble_many() per 65536 pairs")
             out["end_to_end"] = e2e
         except Exception as exc:  # the headline number does not depend on this leg

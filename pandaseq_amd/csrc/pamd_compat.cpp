@@ -5,6 +5,7 @@
 // merges or sums anything.
 #include <hip/hip_runtime_api.h>
 #include <dlfcn.h>
+#include <sched.h>
 #include <atomic>
 #include <cctype>
 #include <emmintrin.h>
@@ -45,6 +46,30 @@ std::atomic<size_t> g_batch_pairs{65536};
 // ahead of the caller (streamed to memory: a consumer that only looks at a record's scalars never touches the rows);
 // 1 = on the caller's thread when the record is handed over, into one buffer that stays in its cache (a consumer that reads
 // every base reads it from there instead of from memory other threads wrote).  PAMD_COMPAT_ROWS=lazy selects 1.
+std::atomic<int> g_streaming{0};	// assemblers that have batches in flight (panda_assembler_next was called on them)
+
+// CPUs this process may actually use: the affinity mask, capped by the cgroup's quota (cpu.max: "<quota> <period>" or "max")
+unsigned effective_cpus() {
+	static const unsigned n = [] {
+		unsigned cpus = std::thread::hardware_concurrency();
+		cpu_set_t set;
+		if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0)
+			cpus = (unsigned) CPU_COUNT(&set);
+		if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+			char quota[32] = "";
+			double period = 0;
+			if (fscanf(f, "%31s %lf", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+				const double q = atof(quota) / period;
+				if (q >= 1 && q < cpus)
+					cpus = (unsigned) (q + 0.5);
+			}
+			fclose(f);
+		}
+		return cpus < 1 ? 1u : cpus;
+	}();
+	return n;
+}
+
 std::atomic<int> g_lazy_rows{-1};
 int compat_lazy_rows() {
 	int v = g_lazy_rows.load();
@@ -1170,6 +1195,7 @@ struct pamd_slot {
 	double *d_p = nullptr;
 	int64_t *d_ctr = nullptr;
 	hipStream_t stream = nullptr;
+	hipEvent_t done_ev = nullptr;	// recorded behind a batch's last copy; waited for without spinning
 	size_t cap = 0;		// pairs all of the above are sized for (rows of ROW bases in, OUT_ROW bases out)
 	// the batch
 	// what is remembered of every pair pulled from the source, compactly (the caller's thread streams through all of
@@ -1218,6 +1244,8 @@ void slot_free(pamd_slot *s) {
 			(void) hipFree(q);
 	if (s->stream)
 		(void) hipStreamDestroy(s->stream);
+	if (s->done_ev)
+		(void) hipEventDestroy(s->done_ev);
 	free(s->rows);
 	delete s;
 }
@@ -1263,6 +1291,8 @@ bool slot_reserve(PandaAssembler a, pamd_slot *s, size_t pairs) {
 	dev(s->d_ctr, PAMD_NUM_COUNTERS * 8);
 	if (s->stream == nullptr)
 		ok = ok && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+	if (s->done_ev == nullptr)
+		ok = ok && hipEventCreateWithFlags(&s->done_ev, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
 	s->cap = ok ? pairs : 0;
 	return ok;
 }
@@ -1311,7 +1341,10 @@ int slot_run(PandaAssembler a, pamd_slot *s) {
 	SLOT_TRY(hipMemcpyAsync(s->h_res, s->d_res, n * sizeof(pamd_pair_result), hipMemcpyDeviceToHost, s->stream));
 	SLOT_TRY(hipMemcpyAsync(s->h_nt, s->d_nt, n * ss, hipMemcpyDeviceToHost, s->stream));
 	SLOT_TRY(hipMemcpyAsync(s->h_idx, s->d_idx, n * ss * 2, hipMemcpyDeviceToHost, s->stream));
-	SLOT_TRY(hipStreamSynchronize(s->stream));
+	// (a blocking event: hipStreamSynchronize spins, and with one assembler per thread -- pool.c:140-167 -- there are four such
+	// waits per assembler competing with the callers' threads for the CPUs)
+	SLOT_TRY(hipEventRecord(s->done_ev, s->stream));
+	SLOT_TRY(hipEventSynchronize(s->done_ev));
 #undef SLOT_TRY
 	// expand the accepted rows into the reference's 16-byte panda_result (pandaseq-common.h:221-230): nt from the
 	// device, p = the table entry the index names -- the very double the kernel wrote
@@ -1340,7 +1373,11 @@ int slot_run(PandaAssembler a, pamd_slot *s) {
 	}
 	const double *image = a->image.data();
 	const size_t n_image = a->image.size();
-	unsigned helpers = std::thread::hardware_concurrency() / 4;	// the expansion writes 16 bytes per base: memory-bound, it scales with threads
+	// the expansion writes 16 bytes per base: memory-bound, it scales with threads -- those this process may run on (its
+	// affinity mask and its cgroup's CPU quota, not the machine's count), shared between the assemblers that are streaming
+	// (pool.c:140-167 runs one per thread)
+	const int streaming = g_streaming.load();
+	unsigned helpers = effective_cpus() / (2u * (unsigned) (streaming < 1 ? 1 : streaming));
 	helpers = helpers < 1 ? 1 : (helpers > 32 ? 32 : helpers);
 	if (n < 4096)
 		helpers = 1;
@@ -1750,6 +1787,8 @@ void panda_assembler_unref(PandaAssembler a) {	// assembler_support.c:151-175
 	if (getenv("PAMD_COMPAT_STATS") != nullptr && a->n_batches > 0)
 		fprintf(stderr, "pandaseq_amd: %ld batches; caller: %.3f s pulling and staging, %.3f s blocked on a batch; background: %.3f s in all (%.2f ms per batch)\n", a->n_batches, a->t_fill, a->t_wait, a->t_bg, 1e3 * a->t_bg / (double) a->n_batches);
 	panda_algorithm_unref(a->algo);
+	if (a->slots[0] != nullptr)
+		g_streaming.fetch_sub(1);
 	for (pamd_slot *sl : a->slots)
 		slot_free(sl);
 	for (pamd_assembler *d : a->devs)
@@ -1861,6 +1900,7 @@ const panda_result_seq *panda_assembler_next(PandaAssembler a) {
 			a->slots[k] = new pamd_slot;
 			a->slots[k]->dev = a->devs[k];
 		}
+		g_streaming.fetch_add(1);
 	}
 	while (true) {
 		pamd_slot *s = a->slots[a->cur];

@@ -54,6 +54,25 @@ def run(config=1, pairs=4_000_000, sums="exact", batch=65536, distinct=8192, alg
     return d
 
 
+def run_pool(config=1, pairs=8_000_000, sums="fast", threads=8, distinct=8192, algo=None):
+    """tests/c/bench_pool.c: `threads` threads, each with an assembler of its own on the same GPU (pool.c:140-167), each
+    consuming every merged base."""
+    from pandaseq_amd import synth
+    import bench
+    spec = synth.config_spec(config)
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "bench_pool")
+        subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "bench_pool.c"), "-o", exe, "-lpthread",
+                               "-L", os.path.join(ROOT, "pandaseq_amd"), "-lpandaseq_amd", "-Wl,-rpath," + os.path.join(ROOT, "pandaseq_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+        fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, min(distinct, pairs))
+        pin = os.path.join(tmp, "pairs.bin")
+        write_pairs(pin, fwd, rev, flen, rlen)
+        out = subprocess.check_output([exe, pin, str(pairs), algo or bench.CONFIGS[config]["algo"].replace("simple_bayesian", "sb"), "1" if sums == "exact" else "0", str(threads)], timeout=1200)
+    d = json.loads(out.decode().strip().splitlines()[-1])
+    d.update(config=config, sums=sums, distinct_pairs=min(distinct, pairs), api="panda_assembler_next, one assembler per thread", rows="eager", batch_pairs=65536)
+    return d
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=1)
@@ -61,5 +80,11 @@ if __name__ == "__main__":
     ap.add_argument("--sums", default="exact")
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--consume", type=int, default=2)
+    ap.add_argument("--api", type=int, default=0, help="0 panda_assembler_next, 1 panda_assembler_assemble per pair, 2 pamd_compat_assemble_many")
+    ap.add_argument("--rows", default="eager", help="eager | lazy (PAMD_COMPAT_ROWS)")
+    ap.add_argument("--threads", type=int, default=0, help="> 0: bench_pool.c, that many threads with an assembler each")
     args = ap.parse_args()
-    print(json.dumps(run(args.config, args.pairs, args.sums, args.batch, consume=args.consume)))
+    if args.threads > 0:
+        print(json.dumps(run_pool(args.config, args.pairs, args.sums, args.threads)))
+        sys.exit(0)
+    print(json.dumps(run(args.config, args.pairs, args.sums, args.batch, consume=args.consume, api=args.api, rows=args.rows)))
