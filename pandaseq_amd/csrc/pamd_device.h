@@ -156,7 +156,8 @@ struct Pend64 {
 	unsigned ex_mm;			// examined | mismatches << 16
 	unsigned dg_fo;			// degenerates | forward offset << 16
 	unsigned ro_st;			// reverse offset | status << 16 | slow << 24 | "q is final" << 25 | smallest phred (63 = none) << 26
-	unsigned pid;			// the pair's index, where a wave takes its pairs from a work queue (general kernel)
+	unsigned pid;			// the pair's index, where a wave takes its pairs from a work queue (general kernel); the lean kernel with
+					// exact sums: where the row's overlap region begins | ends << 16
 };
 
 __device__ __forceinline__ unsigned put_lane(unsigned reg, unsigned value, bool mine) {
@@ -198,8 +199,7 @@ __device__ __forceinline__ double ordered_row_sum(const double *row, int lo, int
 }
 
 // EXACTQ (the lean kernel with exact sums): the quality sums are made here, in the reference's order, every lane walking
-// the three chains of its own pair's row (which this wave wrote; dg_fo carries the number of forward-only bases in its
-// upper half instead of a forward offset, which the lean kernel does not have).
+// the three chains of its own pair's row (which this wave wrote; pd.pid says where the overlap region begins and ends).
 // QUEUED: the pairs' indices are in pd.pid (the wave took them from a work queue).
 template <bool LIST, bool DEFER, bool EXACTQ = false, bool QUEUED = false>
 __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64 &pd, int npend, u64 first_pair, u64 pair_step, int lane) {
@@ -241,15 +241,14 @@ __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64
 		const int seqlen = (int) (pd.len_bo & 0xFFFFu), bo = (int) (pd.len_bo >> 16);
 		unsigned dg_fo = pd.dg_fo;
 		if (EXACTQ) {
-			dg_fo &= 0xFFFFu;
 			if (status == PAMD_ST_OK && row != ~0ull) {
 				// plain cached loads: this wave's own stores have been waited for (below), and a CU's vector L1 is
-				// coherent for its own stores
-				const int A = (int) (pd.dg_fo >> 16);
+				// coherent for its own stores.  pd.pid: where the overlap region of the row begins | ends << 16
+				const int A0 = (int) (pd.pid & 0xFFFFu), AF = (int) (pd.pid >> 16);
 				const double *rowp = P.seq_p + row;
-				const double fq = ordered_row_sum(rowp, 0, A);
-				const double rq = ordered_row_sum(rowp, A + bo, seqlen);
-				const double oq = ordered_row_sum(rowp, A, A + bo);
+				const double fq = ordered_row_sum(rowp, 0, A0);
+				const double rq = ordered_row_sum(rowp, AF, seqlen);
+				const double oq = ordered_row_sum(rowp, A0, AF);
 				q.d = (fq + rq + oq) / (double) (seqlen + 1);	// assembler.c:244
 			}
 		}

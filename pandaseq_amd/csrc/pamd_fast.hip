@@ -850,10 +850,10 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	constexpr bool WINDOWS = BPL != 4;	// k-mers from unaligned words of the code streams (else from the neighbouring lanes' registers)
 	static_assert(!NARROW || !LONG, "three bases per lane belong to the short geometry");
 	static_assert(!PRIM || LONG, "primers and trims are served by the LONG geometry");
-	static_assert(!EXACT || !LONG, "exact sums are served by the short geometry");
 	const auto fv = cur.f, rv = cur.r;
 	bool rotated = false;
 	int fo = 0, ro = 0;	// bases clipped from the reads' 5' ends (primers, trims): assembler.c:262-288
+	int region_a0 = 0, region_af = 0;	// the merged row's overlap region, for the exact finish
 	bool primers_known = false;
 	int status = PAMD_ST_OK;
 	u64 off = ~0ull;
@@ -1427,6 +1427,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		const bool cliff = uf < flen || ur < rlen;
 		const int A0 = PRIM && A < 0 ? 0 : A;	// the overlap region starts here ...
 		const int AF = PRIM ? A0 + novl + (A < 0 ? A : 0) + (Bn < 0 ? Bn : 0) : A + novl;	// ... and ends here (assembler.c:181)
+		region_a0 = A0;
+		region_af = AF;
 		const unsigned nN = lN + (unsigned) lane;
 		// (explicitly global: through a generic pointer these would be flat_store, which every later LDS wait waits for as well)
 		gbl_f64 *const gP = (gbl_f64 *) (row_p + lane);
@@ -1592,7 +1594,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	pd.b_hi = put_lane(pd.b_hi, bb.u[1], mine);
 	pd.len_bo = put_lane(pd.len_bo, (unsigned) seqlen | ((unsigned) (bo < 0 ? 0 : bo) << 16), mine);
 	pd.ex_mm = put_lane(pd.ex_mm, (unsigned) examined | ((unsigned) mism << 16), mine);
-	pd.dg_fo = put_lane(pd.dg_fo, (unsigned) degen | (EXACT ? (unsigned) (seqlen - rlen) << 16 : (unsigned) fo << 16), mine);	// exact sums (no offsets there): + the forward-only bases
+	pd.dg_fo = put_lane(pd.dg_fo, (unsigned) degen | ((unsigned) fo << 16), mine);
+	if (EXACT)	// exact sums: where the row's three chains begin and end (assembler.c:171,226,236): the overlap is [A0, AF)
+		pd.pid = put_lane(pd.pid, (unsigned) region_a0 | ((unsigned) region_af << 16), mine);
 	pd.ro_st = put_lane(pd.ro_st, (unsigned) ro | ((unsigned) status << 16) | ((unsigned) slow << 24) | ((unsigned) (phmin > 63 ? 63 : phmin) << 26), mine);
 }
 
@@ -1694,7 +1698,7 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 // ---- host side: does the lean kernel serve this configuration, and its launch ---------------------------------
 // 0: not served (the general kernel takes the launch whole); PAMD_FAST_SHORT: reads of at most 256 bases, no primers or
 // trims; PAMD_FAST_LONG: reads of at most 320 bases; PAMD_FAST_PRIM: the same with `-p` / `-q` primers (at most 24 bases, no
-// penalty) and / or trims.  The two LONG variants serve any-order sums only.
+// penalty) and / or trims.
 int pamd_fast_supports(const PamdKernelParams &p) {
 	if (p.post_primers || p.maxoverlap != 0)
 		return 0;
@@ -1702,7 +1706,7 @@ int pamd_fast_supports(const PamdKernelParams &p) {
 		return 0;	// 32-bit pair indices in the kernel and in the deferred list
 	const bool clipped = p.fprimer_len > 0 || p.rprimer_len > 0 || p.ftrim != 0 || p.rtrim != 0;
 	if (clipped) {
-		if (p.exact_sums || p.smax > (uint32_t) Lay<true>::MAXLEN || p.primer_penalty != 0.0 || p.fprimer_len > 24 || p.rprimer_len > 24)
+		if (p.smax > (uint32_t) Lay<true>::MAXLEN || p.primer_penalty != 0.0 || p.fprimer_len > 24 || p.rprimer_len > 24)
 			return 0;
 		if (p.ftrim < 0 || p.rtrim < 0 || p.ftrim > Lay<true>::MAXLEN || p.rtrim > Lay<true>::MAXLEN)
 			return 0;
@@ -1710,7 +1714,7 @@ int pamd_fast_supports(const PamdKernelParams &p) {
 	}
 	if (p.smax <= (uint32_t) Lay<false>::MAXLEN)
 		return PAMD_FAST_SHORT;
-	if (p.smax <= (uint32_t) Lay<true>::MAXLEN && !p.exact_sums)
+	if (p.smax <= (uint32_t) Lay<true>::MAXLEN)
 		return PAMD_FAST_LONG;
 	return 0;
 }
@@ -1728,8 +1732,9 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 	const int variant = pamd_fast_supports(p);
 	const bool narrow = p.smax <= 192;	// three bases per lane cover the reads
 #define FK_PICK3(A, PH, E) (narrow ? pamd_fast_kernel<A, E, PH, false, false, true> : pamd_fast_kernel<A, E, PH, false, false, false>)
+#define FK_PICK4(A, PH, E) (variant == PAMD_FAST_LONG ? pamd_fast_kernel<A, E, PH, true, false, false> : pamd_fast_kernel<A, E, PH, true, true, false>)
 #define FK_PICK2(A, PH) (variant == PAMD_FAST_SHORT ? (p.exact_sums ? FK_PICK3(A, PH, true) : FK_PICK3(A, PH, false)) \
-						    : (variant == PAMD_FAST_LONG ? pamd_fast_kernel<A, false, PH, true, false, false> : pamd_fast_kernel<A, false, PH, true, true, false>))
+						    : (p.exact_sums ? FK_PICK4(A, PH, true) : FK_PICK4(A, PH, false)))
 #define FK_PICK(A) (p.has_min_phred ? FK_PICK2(A, true) : FK_PICK2(A, false))
 	switch (variant == 0 ? -1 : p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
@@ -1760,6 +1765,7 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 #undef FK_PICK
 #undef FK_PICK2
 #undef FK_PICK3
+#undef FK_PICK4
 	hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 	if (e0 != hipSuccess) {
 		pamd_set_error("hipFuncSetAttribute(%zu bytes LDS, lean kernel): %s", lds_bytes, hipGetErrorString(e0));

@@ -63,15 +63,17 @@ def test_bench_two_ranks_sharded(built):
     assert d["stat_block_sha1"] == s["stat_block_sha1"]
 
 
-def test_bench_chunked_launches(built):
+@pytest.mark.parametrize("cfg", [1, 2])
+def test_bench_chunked_launches(built, cfg):
     """A shard cut into three launches (what bench.py does by itself when the output does not fit beside the input)
-    reports the same counters as the single launch, and says how it ran."""
+    reports the same counters as the single launch, and says how it ran.  (Config 2: the lean kernel finds the primers and
+    hands deferred pairs' offsets on, per launch.)"""
     runs = []
     for extra in ([], ["--chunk-pairs", "110000"]):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "300000", "--steps", "1", "--warmup", "0", "--no-cpu"] + extra,
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(cfg), "--pairs", "300000", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e"] + extra,
                              capture_output=True, text=True, timeout=600, cwd=ROOT)
         assert out.returncode == 0, out.stderr[-2000:]
         runs.append(_check(out.stdout.strip().splitlines()[-1], 1, 1, 0))
     assert runs[0]["config"]["launches_per_step"] == 1 and runs[1]["config"]["launches_per_step"] == 3
-    assert runs[0]["stat"] == runs[1]["stat"]
+    assert runs[0]["stat"] == runs[1]["stat"] and runs[0]["stat_block_sha1"] == runs[1]["stat_block_sha1"]
     assert runs[0]["roofline"]["algorithmic_bytes_per_launch"] == runs[1]["roofline"]["algorithmic_bytes_per_launch"]

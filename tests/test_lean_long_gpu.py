@@ -1,8 +1,7 @@
 """The lean kernel's second geometry (pamd_fast.hip, LONG / PRIM: reads of up to 320 bases, primers and trims found and
 applied inside it) against the oracle: what only that geometry can get wrong -- seeding five bases per lane on windows of
 the code streams, the primer scan's filter / bound / lockstep fallback, clipped merges, offsets carried to the general
-kernel by deferred pairs.  Any-order sums (the LONG geometry serves no other mode); every test also checks that the lean
-kernel is what ran."""
+kernel by deferred pairs.  Every test also checks that the lean kernel is what ran."""
 import numpy as np
 import pytest
 
@@ -29,15 +28,21 @@ def _oracle(algo, fwd, rev, flen, rlen, **kw):
     return po.assemble_batch(po.make_config(algo, **kw), fwd, rev, flen, rlen)
 
 
-def _check(asm, b, o, n, max_deferred):
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=False)
+@pytest.fixture(params=["fast", "exact"])
+def sums(request):
+    """Both summation modes (pamd_set_exact_sums): any order with guards, and the reference's order."""
+    return request.param
+
+
+def _check(asm, b, o, n, max_deferred, exact=False):
+    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=exact)
     compare_counters(b.counters_dict(), o[3])
     d = asm.last_deferred()
     assert 0 <= d <= max_deferred, f"the lean kernel must have served this launch (deferred {d} of {n})"
 
 
 @pytest.mark.parametrize("algo", ALL)
-def test_long_geometry_all_scorers(built, algo):
+def test_long_geometry_all_scorers(built, algo, sums):
     """2x300 reads without primers: ordinary pairs, then ragged lengths up to 304, Ns, quality-2 tails, ambiguity codes and
     out-of-range qualities (deferred), tandem repeats and unrelated reads (many candidates: deferred in this geometry)."""
     import pandaseq_amd as pa
@@ -52,9 +57,9 @@ def test_long_geometry_all_scorers(built, algo):
             fwd, rev, flen, rlen = synth.generate_numpy(spec, 200, n)
         asm = pa.Assembler(0)
         asm.set_algorithm(algo)
-        asm.set_exact_sums(False)
+        asm.set_exact_sums(sums == "exact")
         b = _run(asm, fwd, rev, flen, rlen)
-        _check(asm, b, _oracle(algo, fwd, rev, flen, rlen), n, limit)
+        _check(asm, b, _oracle(algo, fwd, rev, flen, rlen), n, limit, exact=sums == "exact")
 
 
 def _plant(rng, rows, lens, primer, where, subst, lowq):
@@ -73,7 +78,7 @@ def _plant(rng, rows, lens, primer, where, subst, lowq):
 
 @pytest.mark.parametrize("algo", ["simple_bayesian", "pear"])
 @pytest.mark.parametrize("plen", [1, 3, 8, 9, 16, 17, 23, 24])
-def test_primer_scan_inside_the_lean_kernel(built, plen, algo):
+def test_primer_scan_inside_the_lean_kernel(built, plen, algo, sums):
     """offset.c:47-112 as the lean kernel runs it: primers of every length it serves, with ambiguity codes and N among
     their bases, planted at the start of the read, anywhere in it or nowhere, damaged and on poor qualities (loose bounds,
     many alignments left: the lockstep fallback), a read shorter than its primer and one exactly as long."""
@@ -98,12 +103,12 @@ def test_primer_scan_inside_the_lean_kernel(built, plen, algo):
     flen[7] = plen + 1
     asm = pa.Assembler(0)
     asm.set_algorithm(algo)
-    asm.set_exact_sums(False)
+    asm.set_exact_sums(sums == "exact")
     asm.set_forward_primer(fp)
     asm.set_reverse_primer(rp)
     b = _run(asm, fwd, rev, flen, rlen)
     o = _oracle(algo, fwd, rev, flen, rlen, fprimer=fp, rprimer=rp)
-    _check(asm, b, o, n, n // 3)
+    _check(asm, b, o, n, n // 3, exact=sums == "exact")
     st = o[0]["status"]
     assert (st == 0).sum() > n // 4 and ((st == 2) | (st == 3)).sum() > 0 or plen < 8
 
@@ -132,7 +137,7 @@ def test_primers_the_lean_kernel_does_not_serve(built):
 
 
 @pytest.mark.parametrize("ftrim,rtrim", [(5, 0), (0, 9), (20, 31), (140, 150), (249, 3)])
-def test_trims_inside_the_lean_kernel(built, ftrim, rtrim):
+def test_trims_inside_the_lean_kernel(built, ftrim, rtrim, sums):
     """Trims without primers (assembler.c:270,282): offsets enter the merge; a trim as long as the rest of the read leaves
     NOALGN (assembler.c:73-82), an overlap that runs into a trimmed stretch is clipped (VEEZ / WEDGEZ)."""
     import pandaseq_amd as pa
@@ -143,12 +148,12 @@ def test_trims_inside_the_lean_kernel(built, ftrim, rtrim):
     flen[::7] = rng.integers(2, 251, len(flen[::7]))
     rlen[::5] = rng.integers(2, 251, len(rlen[::5]))
     asm = pa.Assembler(0)
-    asm.set_exact_sums(False)
+    asm.set_exact_sums(sums == "exact")
     asm.set_forward_trim(ftrim)
     asm.set_reverse_trim(rtrim)
     b = _run(asm, fwd, rev, flen, rlen)
     o = _oracle("simple_bayesian", fwd, rev, flen, rlen, ftrim=ftrim, rtrim=rtrim)
-    _check(asm, b, o, len(flen), len(flen) // 3)
+    _check(asm, b, o, len(flen), len(flen) // 3, exact=sums == "exact")
 
 
 def test_one_primer_only_and_offsets_of_deferred_pairs(built):
