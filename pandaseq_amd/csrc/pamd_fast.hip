@@ -139,6 +139,11 @@ typedef __attribute__((address_space(1))) u32x4 gbl_u128;
 __device__ __forceinline__ unsigned lds_read_u16(unsigned addr) {
 	return *reinterpret_cast<lds_cu16 *>(addr);
 }
+// (volatile: stays where it is written relative to the other volatile statements around it -- used to get a batch of reads
+// under way BEFORE a stretch of scalar work the compiler would otherwise leave them behind)
+__device__ __forceinline__ unsigned lds_read_u16_early(unsigned addr) {
+	return *reinterpret_cast<volatile lds_cu16 *>(addr);
+}
 __device__ __forceinline__ double lds_read_f64(unsigned addr) {
 	return *reinterpret_cast<lds_cf64 *>(addr);
 }
@@ -1365,6 +1370,28 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			break;
 		}
 		STOP(3);
+		// (the launch parameters the allocation below needs, read together and FIRST: scalar loads and LDS reads share a counter,
+		// so a wait for these after the reads below would wait for those as well; and the compiler otherwise re-reads each
+		// from the kernel argument segment, one exposed scalar-memory round trip per use, in whichever branch it is used)
+		u64 k_stride = P.seq_stride, k_capacity = P.seq_capacity;
+		uint8_t *k_nt = P.seq_nt;
+		double *k_p = P.seq_p;
+		asm volatile("" : "+s"(k_stride), "+s"(k_capacity), "+s"(k_nt), "+s"(k_p));
+		// The staged bases of all rounds of the merge (below), requested before the register rotation and the row's allocation:
+		// sixty scalar instructions that need nothing from the LDS run while the reads are under way.
+		constexpr int NR = L::NR;
+		constexpr int NF = L::MAXLEN / 64;	// rounds that can hold a forward base (a read is at most MAXLEN bases long)
+		unsigned ef[NF], er[NR];
+		{
+			const unsigned aF = lds_addr(wb + L::F) + 2u * (unsigned) (lane + fo);					// round r: F[fo + 64r + lane] ...
+			const unsigned aR = lds_addr(wb + L::R) + 2u * (unsigned) (rlen - 1 + A - lane) - 128u * (NR - 1);	// ... and R[rlen - 1 - (64r + lane - A)]
+#pragma unroll
+			for (int r = 0; r < NR; r++) {
+				if (r < NF)
+					ef[r] = lds_read_u16_early(aF + 128u * r);
+				er[r] = lds_read_u16_early(aR + 128u * (NR - 1 - r));
+			}
+		}
 		MARK("rotate+alloc");
 		// Rotate the prefetched registers in BEFORE this pair's stores are issued (vmcnt is one in-order queue for
 		// loads and stores: waiting for the loads at the top of the next pair would also wait for the stores).
@@ -1374,12 +1401,6 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 
 		seqlen = A + novl + Bn;	// len - 1; len = seqlen + 1 is in 3 .. 511 (639)
 		const u64 need = ((u64) seqlen + 15ull) & ~15ull;
-		// (the launch parameters this block needs, read together: the compiler otherwise re-reads each from the kernel
-		// argument segment, one exposed scalar-memory round trip per use, in whichever branch it is used)
-		u64 k_stride = P.seq_stride, k_capacity = P.seq_capacity;
-		uint8_t *k_nt = P.seq_nt;
-		double *k_p = P.seq_p;
-		asm volatile("" : "+s"(k_stride), "+s"(k_capacity), "+s"(k_nt), "+s"(k_p));
 		if (k_stride != 0) {
 			off = pair * k_stride;
 		} else {
@@ -1415,7 +1436,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		// per trip, each round by its kind -- wave-uniform: all forward-only, all reverse-only (a shift and an add), or mixed
 		// (the overlap's table index and base, with per-lane selects at the region borders) -- table reads, then the writes.
 		// A lane past the end of the row reads whatever lies there, inside the LDS, and its base is forced to 0.
-		const unsigned lF = lds_addr(wb + L::F), lR = lds_addr(wb + L::R), lT = lds_addr(ltab), lN = lds_addr(nts);
+		const unsigned lT = lds_addr(ltab), lN = lds_addr(nts);
 		// a pair whose row does not fit stores nothing (it ends as NOSPACE whatever its sums are)
 #ifdef FK_NO_PSTORE	/* experiment: what do the log-p stores cost? (results are wrong) */
 		const int lim = 0;
@@ -1433,19 +1454,6 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		// (explicitly global: through a generic pointer these would be flat_store, which every later LDS wait waits for as well)
 		gbl_f64 *const gP = (gbl_f64 *) (row_p + lane);
 		MARK("merge");
-		constexpr int NR = L::NR;
-		constexpr int NF = L::MAXLEN / 64;	// rounds that can hold a forward base (a read is at most MAXLEN bases long)
-		unsigned ef[NF], er[NR];
-		const unsigned aF = lF + 2u * (unsigned) (lane + fo);					// round r: F[fo + 64r + lane] ...
-		const unsigned aR = lR + 2u * (unsigned) (rlen - 1 + A - lane) - 128u * (NR - 1);	// ... and R[rlen - 1 - (64r + lane - A)]
-		{	// all rounds' bases up front: one wait (read trip by trip, a 2x300 pair's merge takes 70 % longer)
-#pragma unroll
-			for (int r = 0; r < NR; r++) {
-				if (r < NF)
-					ef[r] = lds_read_u16(aF + 128u * r);
-				er[r] = lds_read_u16(aR + 128u * (NR - 1 - r));
-			}
-		}
 		// one round: table index and base of output base 64 R + lane
 		auto round = [&](auto rc, unsigned &qi_out, unsigned &nt_out) __attribute__((always_inline)) {
 			constexpr int R = decltype(rc)::value;
