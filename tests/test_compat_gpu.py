@@ -1,5 +1,6 @@
 """The reference's own per-assembler API (panda_assembler_next / _assemble), re-linked against
 libpandaseq_amd.so by a plain-C client, compared with the oracle."""
+import json
 import os
 import struct
 import subprocess
@@ -333,3 +334,42 @@ def test_reference_api_default_sums(built, tmp_path):
         assert np.array_equal(g["nt"], o_nt[i, :g["seq_len"]]) and np.array_equal(g["p"], o_p[i, :g["seq_len"]])
         worst = max(worst, abs(g["quality"] - o_res["quality"][i]))
     assert worst <= 1e-9
+
+
+def test_rows_built_on_the_callers_thread(built, tmp_path):
+    """PAMD_COMPAT_ROWS=lazy (pamd_compat_set_lazy_rows): panda_assembler_next() builds each record's panda_result[] on the
+    caller's thread instead of ahead of it -- the same records, bit for bit."""
+    from pandaseq_amd import synth
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 900, 1500)
+    pin = tmp_path / "pairs.bin"
+    _write_pairs(pin, fwd, rev, flen, rlen)
+    exe = _build_client(str(tmp_path))
+    outs = []
+    for rows in ("eager", "lazy"):
+        pout = tmp_path / f"out_{rows}.bin"
+        subprocess.check_call([exe, str(pin), str(pout), "rdp_mle", "0"], timeout=300, env=dict(os.environ, PAMD_COMPAT_ROWS=rows))
+        outs.append(pout.read_bytes())
+    assert len(outs[0]) > 100_000 and outs[0] == outs[1]
+
+
+def test_one_assembler_per_thread_consumers(built, tmp_path):
+    """pool.c:140-167's shape: several threads, an assembler each on the same GPU, every thread reading every base
+    (tests/c/bench_pool.c).  Each thread's share of the pairs is assembled exactly once: the OK counts add up to what the
+    oracle says for the shares."""
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    spec = synth.config_spec(1)
+    distinct, total, threads = 3000, 50_000, 4
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, distinct)
+    pin = tmp_path / "pairs.bin"
+    _write_pairs(pin, fwd, rev, flen, rlen)
+    exe = _build_c(str(tmp_path), "bench_pool")
+    out = subprocess.check_output([exe, str(pin), str(total), "sb", "1", str(threads)], timeout=600).decode()
+    d = json.loads(out.strip().splitlines()[-1])
+    ok = po.assemble_batch(po.make_config("simple_bayesian"), fwd, rev, flen, rlen, want_seq=False)[0]["status"] == 0
+    expect = 0
+    for k in range(threads):
+        share = total * (k + 1) // threads - total * k // threads      # the first `share` pairs of the cycled source
+        expect += (share // distinct) * int(ok.sum()) + int(ok[: share % distinct].sum())
+    assert d["threads"] == threads and d["pairs"] == total and d["ok"] == expect == d["returned"]

@@ -378,3 +378,22 @@ def test_candidate_sets_from_reference_kmers_match_the_oracle(po):
         assert int(res["examined"][i]) == ex, i
         checked += 1
     assert checked > 1000
+
+
+def test_cpu_baseline_harness_assembles_what_the_plain_entry_point_does(built):
+    """bench.py's cpu_baseline leg (po_bench_mt: pinned pthreads over private, self-touched copies of their slices) returns the
+    records and counters of po_assemble_batch, whatever the thread count."""
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 3000)
+    cfg = po.make_config("rdp_mle")
+    want, _, _, wctr = po.assemble_batch(cfg, fwd, rev, flen, rlen, want_seq=False)
+    for threads in (1, 3, 8):
+        secs, got, ctr = po.bench_mt(cfg, fwd, rev, flen, rlen, threads)
+        assert secs > 0
+        for name in ("status", "overlap", "seq_len", "examined", "mismatches"):
+            assert np.array_equal(got[name], want[name]), (threads, name)
+        assert np.array_equal(got["quality"].view(np.uint64), want["quality"].view(np.uint64))
+        for k in ("count", "ok", "noalgn", "lowq", "badr", "slow"):
+            assert int(ctr[k]) == int(wctr[k]), (threads, k)
