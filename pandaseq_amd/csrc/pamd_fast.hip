@@ -1672,7 +1672,7 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 		load_pair<LONG>(nxt, P, q, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
 		int lane_now = lane;
-		if constexpr (LONG) {
+		if constexpr (LONG || ALGO == PAMD_ALGO_EA_UTIL || ALGO == PAMD_ALGO_STITCH) {	// (the two table-scored counting scorers spill in the short geometry too)
 			// The compiler hoists everything that depends on the lane number alone out of this loop -- multiples, shifts,
 			// LDS addresses -- and, out of registers, spills it: a reload from scratch memory then waits, vmcnt being one
 			// in-order queue, for whatever went before it, the rows just requested for the next pair among them.  Made opaque
