@@ -1671,10 +1671,16 @@ __global__ __launch_bounds__(1024) void pamd_assemble_kernel(const PamdKernelPar
 		nxt.f = load_read<BPL>(P.fwd + npid * P.fwd_row_bytes, P.fwd_row_bytes, lane);
 		nxt.r = load_read<BPL>(P.rev + npid * P.rev_row_bytes, P.rev_row_bytes, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
+		// The primers-after variants run out of registers; what the compiler would otherwise keep across pairs in scratch
+		// (every constant derived from the lane number) is cheaper recomputed, because a scratch reload waits in the same
+		// in-order queue as the next pair's rows.
+		int lane_now = lane;
+		if constexpr (POST)
+			asm volatile("" : "+v"(lane_now));
 #ifdef PAMD_PHASE_TIMING
-		assemble_pair<ALGO, PHRED, BPL, EXACT, POST>(P, ltab, lprimers, lctr, L, arena, &pend[EXACT ? npend : 0], pd, npend, wave_gid, pid, lane, flen, rlen, cur, nxt, ph_acc);
+		assemble_pair<ALGO, PHRED, BPL, EXACT, POST>(P, ltab, lprimers, lctr, L, arena, &pend[EXACT ? npend : 0], pd, npend, wave_gid, pid, lane_now, flen, rlen, cur, nxt, ph_acc);
 #else
-		assemble_pair<ALGO, PHRED, BPL, EXACT, POST>(P, ltab, lprimers, lctr, L, arena, &pend[EXACT ? npend : 0], pd, npend, wave_gid, pid, lane, flen, rlen, cur, nxt);
+		assemble_pair<ALGO, PHRED, BPL, EXACT, POST>(P, ltab, lprimers, lctr, L, arena, &pend[EXACT ? npend : 0], pd, npend, wave_gid, pid, lane_now, flen, rlen, cur, nxt);
 #endif
 		pid = npid;
 		npend++;
