@@ -300,26 +300,6 @@ __device__ __forceinline__ int stage8(const uint4 v, const int len, int lane, un
 // (4) the few that are left are summed exactly, in the reference's order, and compared as the reference compares them.
 // Returns -1 when it cannot settle the read that cheaply (no good alignment, a bound too loose to filter, too many left).
 
-// disagreements that count -- the read's base is definite and of quality >= qthr, the primer's a single base -- between the
-// primer's first 16 * NW bases (2-bit codes pc, "counts" maps pk: bit 2k+1) and the read at s
-template <int NW>
-__device__ __forceinline__ int code_mismatches(unsigned code_addr, unsigned care_addr, int s, const unsigned (&pc)[2], const unsigned (&pk)[2]) {
-	const unsigned o = 4u * (unsigned) (s >> 4), sh = 2u * ((unsigned) s & 15u);
-	unsigned c[NW + 1], k[NW + 1];
-#pragma unroll
-	for (int i = 0; i <= NW; i++) {
-		c[i] = lds_read_u32(code_addr + o + 4u * i);
-		k[i] = lds_read_u32(care_addr + o + 4u * i);
-	}
-	int mm = 0;
-#pragma unroll
-	for (int i = 0; i < NW; i++) {
-		const unsigned t = __builtin_amdgcn_alignbit(c[i + 1], c[i], sh) ^ pc[i];
-		mm += __popc((t | (t << 1)) & __builtin_amdgcn_alignbit(k[i + 1], k[i], sh) & pk[i]);
-	}
-	return mm;
-}
-
 // the sum of one alignment's terms in primer order (offset.c:79-87): lanes look the terms up, lane 0 adds them
 __device__ __forceinline__ double primer_exact(const double *ltab, unsigned char *wb, unsigned row_off, int s, unsigned pbase, int plen, int lane) {
 	typedef Lay<true> L;
@@ -367,11 +347,15 @@ __device__ __forceinline__ unsigned primer_tier1(unsigned code_addr, unsigned ca
 	for (int j = 4; j >= 0; j--) {
 		const unsigned w = j == 0 ? x0 : __builtin_amdgcn_alignbit(x1, x0, 2u * j), kk = j == 0 ? y0 : __builtin_amdgcn_alignbit(y1, y0, 2u * j);
 		const unsigned t = w ^ pc0;
-		int mm = __popc((t | (t << 1)) & kk & pk0);
-		mm = 5 * lane + j < nal ? mm : 31;
+		const int mm = __popc((t | (t << 1)) & kk & pk0);
 		packed = (packed << 5) | (unsigned) mm;
 		firstj = mm <= 1 ? j : firstj;
 	}
+	// the alignments this lane has: j < lim (all five but in the lane the read ends in, none above it)
+	int lim = nal - 5 * lane;
+	lim = lim < 0 ? 0 : (lim > 5 ? 5 : lim);
+	packed |= (0x1FFFFFFu << (5 * lim)) & 0x1FFFFFFu;
+	firstj = firstj < lim ? firstj : 7;
 	const u64 any = ballot(firstj != 7);
 	s0 = -1;
 	if (any != 0) {
@@ -407,7 +391,7 @@ __device__ __forceinline__ void primer_sums_any_order(const double *ltab, unsign
 // compared as offset.c:72-77 compares them (before exp).  >= 0: what the scan returns; -1: more work (primer_settle)
 __device__ __forceinline__ int primer_shortcut(const double *ltab, unsigned char *wb, unsigned row_off, unsigned pbase, unsigned packed, int s0, double sum0, int len, int plen, double thr, double inv_err_t, int lane) {
 	const int n0 = s0 + plen + 1;
-	const double kv = sum0 * (double) (1.0f / (float) n0) * (1.0 + 1e-5);	// a shade below its value: a bound may be anything an alignment reaches
+	const double kv = sum0 * (double) __builtin_amdgcn_rcpf((float) n0) * (1.0 + 1e-5);	// a shade below its value (the reciprocal is good to 1e-7): a bound may be anything an alignment reaches
 	const double bound = kv > thr ? kv : thr;
 	// alignment s may hold K(s) = floor((bound * (s + plen + 1) - 1e-6) / err_t) disagreements and still reach the bound
 	// (taken at the lane's last alignment for all five: a budget may be too large, never too small)
@@ -455,138 +439,127 @@ __device__ __forceinline__ int primer_shortcut(const double *ltab, unsigned char
 	return close ? -1 : besti;
 }
 
-// ---- every other read: blocks of 64 alignments ----
-// pc0, pc1 / pk0, pk1: the primer's bases 0..15, 16..31 as 2-bit codes / which of them count (host-built); thr: plen * threshold
-// (offset.c:59, before exp);
-// s0, sum0: an alignment already summed, in any order: good for the bound only (s0 < 0: none)
-__device__ __forceinline__ int primer_settle(const double *ltab, unsigned char *wb, unsigned row_off, unsigned code_off, unsigned care_off, int len, unsigned pbase, unsigned pc0, unsigned pc1, unsigned pk0, unsigned pk1, int plen, double thr, double inv_err_t, int lane, int s0, double sum0) {
-	const unsigned pc[2] = { pc0, pc1 }, pk[2] = { pk0, pk1 };
+// ---- every other read: exact sums with lanes as alignments ----
+// One pass: lane sums alignment s (if it has one) in primer order (offset.c:79-87), four primer bases at a time; the pass is
+// given up once no lane can reach `bound` any more (every term is <= 0).  false: given up
+__device__ __forceinline__ bool primer_lockstep(const double *ltab, const unsigned char *wb, unsigned row_off, int s, bool have, unsigned pbase, int plen, double bound, double &v) {
+	const uint16_t *S = reinterpret_cast<const uint16_t *>(wb + row_off) + (have ? s : 0);
+	const double floor_acc = bound * (double) (s + plen + 1) - 1e-6;
+	double acc = 0.0;
+	int x = 0;
+	for (; x + 4 <= plen; x += 4) {
+		unsigned e[4], pn[4];
+		double t[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			e[u] = S[x + u];
+			pn[u] = (unsigned) __builtin_amdgcn_readlane((int) pbase, x + u);
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+			t[u] = ltab[(((e[u] & pn[u] & 0xFu) != 0) ? PAMD_LT_SCORE : PAMD_LT_ERR) + (e[u] >> 8)];
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+			if (pn[u] != 15u)
+				acc += t[u];
+		if (ballot(have && !(acc < floor_acc)) == 0)
+			return false;
+	}
+	for (; x < plen; x++) {
+		const unsigned pn = (unsigned) __builtin_amdgcn_readlane((int) pbase, x);
+		if (pn != 15u) {
+			const unsigned e = S[x];
+			acc += ltab[(((e & pn & 0xFu) != 0) ? PAMD_LT_SCORE : PAMD_LT_ERR) + (e >> 8)];
+		}
+	}
+	v = acc / (double) (s + plen + 1);
+	return true;
+}
+
+// packed: primer_tier1's counts for this lane's alignments 5 lane + j; thr: plen * threshold (offset.c:59, before exp);
+// s0, sum0: an alignment already summed, in any order: good for the bound only (s0 < 0: none).
+// An alignment's value divides by its index, so with a disagreement or two in the primer proper the winner is usually some
+// LATE alignment: when many alignments could still reach the bound, the last 64 are summed first and the best of them is
+// the bound for the rest -- few of which are then left; those are gathered into a list and summed 64 at a time.
+__device__ __forceinline__ int primer_settle(const double *ltab, unsigned char *wb, unsigned row_off, int len, unsigned pbase, unsigned packed, int plen, double thr, double inv_err_t, int lane, int s0, double sum0) {
+	typedef Lay<true> L;
 	const int nal = len - plen;	// alignments 0 .. nal-1 are judged (at index s + plen <= len - 1, offset.c:70-77)
-	const unsigned ca = lds_addr(wb + code_off), ka = lds_addr(wb + care_off);
-	// the bound: the value of that alignment, or the threshold every alignment has to beat
+	// the bound: a value some alignment reaches, or the threshold every alignment has to beat
 	double bound = thr;
-	const int n0 = s0 + plen + 1;
 	if (s0 >= 0) {
-		const double kv = sum0 * (double) (1.0f / (float) n0) * (1.0 + 1e-5);
+		const double kv = sum0 * (double) __builtin_amdgcn_rcpf((float) (s0 + plen + 1)) * (1.0 + 1e-5);
 		bound = kv > thr ? kv : thr;
 	}
-	// (3) alignment s may hold K(s) = floor((bound * (s + plen + 1) - 1e-6) / err_t) such disagreements; where that is too
-	// many to tell anything (a bound that stayed loose: no primer in the read, or one with low qualities), all are left
-	const double xs = bound * inv_err_t * 1.0001, x0 = (double) (plen + 1) * xs - 1e-6 * inv_err_t + 0.001;	// all >= 0
-	u64 left[5] = { 0, 0, 0, 0, 0 };
-	int nleft = 0;
-	bool s0_left = false;
-#pragma unroll
-	for (int k = 0; k < 5; k++) {
-		if (64 * k >= nal)
-			break;
-		const int s = 64 * k + lane;
-		const u64 valid = nal - 64 * k >= 64 ? ~0ull : ((1ull << (nal - 64 * k)) - 1ull);
-		const int last = nal - 64 * k >= 64 ? 64 * k + 63 : nal - 1;	// the block's loosest alignment
-		const double klast = (double) last * xs + x0;
-		if (klast >= 8.0) {
-			left[k] = valid;
-		} else {
-			const int K = (int) ((double) s * xs + x0);
-			const int mm = plen > 16 ? code_mismatches<2>(ca, ka, s, pc, pk) : code_mismatches<1>(ca, ka, s, pc, pk);
-			left[k] = ballot(mm <= K) & valid;
-		}
-		nleft += __popcll(left[k]);
-		if (k == (s0 >> 6))
-			s0_left = s0 >= 0 && ((left[k] >> (s0 & 63)) & 1ull) != 0;
-	}
-	// (4) what is left is summed exactly and compared as offset.c:72-77 compares (before exp)
-	if (nleft == 1 && s0_left) {	// the usual read: only the alignment already summed
-		if (sum0 > (thr + 1e-9) * (double) n0)
-			return n0;
-		if (sum0 < (thr - 1e-9) * (double) n0)
-			return 0;
-		return -1;
-	}
-	// lane l keeps the best of the alignments 64 k + l it has seen, in ascending order; the lanes are compared at the end
+	// lane l keeps the best of the alignments it has summed, the first of equals; the lanes are compared at the end.
+	// Two values may differ and their exponentials not: the reference then keeps the earlier index (the careful path's case)
 	double best = thr;
 	int besti = 0;
 	bool close = false;
-#pragma unroll 1
-	for (int k = 0; k < 5; k++) {
-		const u64 lk = k == 0 ? left[0] : (k == 1 ? left[1] : (k == 2 ? left[2] : (k == 3 ? left[3] : left[4])));
-		if (lk == 0)
-			continue;
-		double v = 0.0;
-		bool mine = false;
-		if (__popcll(lk) <= 3) {	// a few: the wave sums them one after the other
-			u64 m = lk;
-			while (m != 0) {
-				const int l = __builtin_ctzll(m), s = 64 * k + l;
-				m &= m - 1;
-				const double sum = primer_exact(ltab, wb, row_off, s, pbase, plen, lane);
-				const double q = sum / (double) (s + plen + 1);
-				if (lane == l) {
-					v = q;
-					mine = true;
-				}
-			}
-		} else {
-			// many: lanes are alignments, each adds its own terms in primer order, four primer bases at a time; the block
-			// is given up once no lane can reach the bound any more (every term is <= 0)
-			const int s = 64 * k + lane;
-			const bool have = ((lk >> lane) & 1ull) != 0;
-			const uint16_t *S = reinterpret_cast<const uint16_t *>(wb + row_off) + (have ? s : 0);
-			const double floor_acc = bound * (double) (s + plen + 1) - 1e-6;
-			double acc = 0.0;
-			bool live = true;
-			int x = 0;
-			for (; x + 4 <= plen && live; x += 4) {
-				unsigned e[4], pn[4];
-				double t[4];
-#pragma unroll
-				for (int u = 0; u < 4; u++) {
-					e[u] = S[x + u];
-					pn[u] = (unsigned) __builtin_amdgcn_readlane((int) pbase, x + u);
-				}
-#pragma unroll
-				for (int u = 0; u < 4; u++)
-					t[u] = ltab[(((e[u] & pn[u] & 0xFu) != 0) ? PAMD_LT_SCORE : PAMD_LT_ERR) + (e[u] >> 8)];
-#pragma unroll
-				for (int u = 0; u < 4; u++)
-					if (pn[u] != 15u)
-						acc += t[u];
-				live = ballot(have && !(acc < floor_acc)) != 0;
-			}
-			if (!live)
-				continue;
-			for (; x < plen; x++) {
-				const unsigned pn = (unsigned) __builtin_amdgcn_readlane((int) pbase, x);
-				if (pn != 15u) {
-					const unsigned e = S[x];
-					acc += ltab[(((e & pn & 0xFu) != 0) ? PAMD_LT_SCORE : PAMD_LT_ERR) + (e >> 8)];
-				}
-			}
-			v = acc / (double) (s + plen + 1);
-			mine = have;
-		}
-		const bool better = mine && v > best;	// strict: the earliest index wins ties (offset.c:74)
-		// two values may differ and their exponentials not: the reference then keeps the earlier index (the careful path's case)
-		close |= better && v - best <= 4.5e-16;
+	auto consider = [&](double v, int s, bool mine) {
+		const int idx = s + plen + 1;
+		const bool first = besti == 0;
+		const bool better = mine && (v > best || (!first && v == best && idx < besti));	// strict against the threshold (offset.c:74)
+		close |= mine && v != best && fabs(v - best) <= 4.5e-16 && (!first || v > best);
 		if (better) {
 			best = v;
-			besti = 64 * k + lane + plen + 1;
+			besti = idx;
 		}
-		const u64 improved = ballot(better);
-		if (improved != 0 && k < 4) {	// a better bound for the blocks to come
-			double m = best;
-			if ((improved & (improved - 1)) == 0) {
-				m = lane_f64(best, __builtin_ctzll(improved));
-			} else {
-				m = besti != 0 ? best : bound;
-				for (int off = 32; off > 0; off >>= 1) {
-					const double o = __shfl_xor(m, off);
-					m = o > m ? o : m;
-				}
-				m = uni_f64(m);
-			}
-			bound = m > bound ? m : bound;
+	};
+	auto raise = [&]() {	// a better bound for what is still to be summed
+		double m = besti != 0 ? best : bound;
+		for (int off = 32; off > 0; off >>= 1) {
+			const double o = __shfl_xor(m, off);
+			m = o > m ? o : m;
 		}
+		m = uni_f64(m);
+		bound = m > bound ? m : bound;
+	};
+	// Alignment s may hold K(s) = floor((bound * (s + plen + 1) - 1e-6) / err_t) disagreements that count and still reach the
+	// bound (taken at the lane's last alignment for all five: a budget may be too large, never too small; the counts are
+	// those of the primer's first sixteen bases: never too many).  Bit j: alignment 5 lane + j, below `top`, is left
+	auto filter = [&](int top) -> unsigned {
+		const double xs = bound * inv_err_t * 1.0001, x0 = (double) (plen + 1) * xs - 1e-6 * inv_err_t + 0.001;	// all >= 0
+		int K = (int) ((double) (5 * lane + 4) * xs + x0);
+		K = K > 30 ? 30 : K;	// (31: no such alignment)
+		unsigned m = 0;
+#pragma unroll
+		for (int j = 0; j < 5; j++)
+			m |= ((int) ((packed >> (5 * j)) & 31u) <= K && 5 * lane + j < top) ? 1u << j : 0u;
+		return m;
+	};
+	unsigned surv = filter(nal);
+	int n = 0;
+#pragma unroll
+	for (int j = 0; j < 5; j++)
+		n += __popcll(ballot(((surv >> j) & 1u) != 0));
+	if (n > 64) {
+		const int top = nal - 64;
+		const int s = top + lane;
+		double v = 0.0;
+		if (primer_lockstep(ltab, wb, row_off, s, s >= 0, pbase, plen, bound, v))
+			consider(v, s, s >= 0);
+		raise();
+		surv = filter(top);
+	}
+	uint16_t *const list = reinterpret_cast<uint16_t *>(wb + L::SCR);
+	int count = 0;
+#pragma unroll
+	for (int j = 0; j < 5; j++) {
+		const bool left = ((surv >> j) & 1u) != 0;
+		const u64 m = ballot(left);
+		if (left)
+			list[count + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u))] = (uint16_t) (5 * lane + j);
+		count += __popcll(m);
+	}
+	wave_sync();
+	for (int p0 = 0; p0 < count; p0 += 64) {
+		const bool have = p0 + lane < count;
+		const int s = have ? (int) list[p0 + lane] : 0;
+		double v = 0.0;
+		if (primer_lockstep(ltab, wb, row_off, s, have, pbase, plen, bound, v))
+			consider(v, s, have);
+		if (p0 + 64 < count)
+			raise();
 	}
 	// first maximum across lanes: the larger value, the smaller index among equals
 	const u64 got = ballot(besti != 0);
@@ -945,8 +918,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 #ifdef PAMD_FK_DEBUG
 					note(P, (which == 0 ? s0f : s0r) < 0 ? 8 : 9, lane);
 #endif
-					const PamdPrimerCodes &pk = P.primer_codes[which];
-					const int r = primer_settle(ltab, wb, which == 0 ? L::F : L::R, which == 0 ? L::FC : L::RC, which == 0 ? L::CAREF : L::CARER, which == 0 ? flen : rlen, (which == 0 ? primer_bases : primer_bases >> 8) & 0xFFu, pk.code[0], pk.code[1], pk.counts[0], pk.counts[1], which == 0 ? fpl : rpl, which == 0 ? thr_f : thr_r, inv_err_t, lane, which == 0 ? s0f : s0r, which == 0 ? sumf : sumr);
+					const int r = primer_settle(ltab, wb, which == 0 ? L::F : L::R, which == 0 ? flen : rlen, (which == 0 ? primer_bases : primer_bases >> 8) & 0xFFu, which == 0 ? pkf : pkr, which == 0 ? fpl : rpl, which == 0 ? thr_f : thr_r, inv_err_t, lane, which == 0 ? s0f : s0r, which == 0 ? sumf : sumr);
 					if (which == 0)
 						rf = r;
 					else
