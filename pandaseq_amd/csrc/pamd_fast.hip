@@ -216,7 +216,8 @@ __device__ __forceinline__ int stage(const uint2 v, const int len, int lane, uns
 // N flags (bit 2k forward, 2k+1 reverse; a base that does not exist reads as N), whether one is outside the lean domain;
 // the nt and the quality bytes for the caller.  The arithmetic of stage() above.
 template <bool FORWARD>
-__device__ __forceinline__ void pack4(unsigned x, unsigned y, int cnt, unsigned &codes, unsigned &nmap, unsigned &weird, unsigned &n4, unsigned &q4) {
+__device__ __forceinline__ void pack4(unsigned x, unsigned y, int cnt, unsigned &codes, unsigned &nmap, unsigned &weird, unsigned &skip4, unsigned &q4) {
+	unsigned n4;
 	n4 = __builtin_amdgcn_perm(y, x, 0x06040200u);
 	q4 = __builtin_amdgcn_perm(y, x, 0x07050301u);
 	const unsigned sel = n4 & 0x07070707u;
@@ -228,6 +229,7 @@ __device__ __forceinline__ void pack4(unsigned x, unsigned y, int cnt, unsigned 
 	const unsigned wq = (((q4 & 0x7F7F7F7Fu) + 0x51515151u) | q4) & 0x80808080u;
 	weird |= ((r4 & 0x08080808u) | wq | (n4 & 0xF0F0F0F0u)) & bm;
 	const unsigned c4 = r4 & 0x03030303u, isn4 = (r4 >> 2) & 0x01010101u;
+	skip4 = isn4 | ~bm;	// (bit 0 of a byte: an N, or no base at all)
 	const unsigned cy = c4 | (c4 >> 6), ny = isn4 | (isn4 >> 6);
 	const unsigned in2 = (1u << (2 * cnt)) - 1u;
 	codes = (cy | (cy >> 12)) & in2;
@@ -237,11 +239,9 @@ __device__ __forceinline__ void pack4(unsigned x, unsigned y, int cnt, unsigned 
 
 // which of four bases count in the primer scan's filter (bit 2k+1): a definite base of quality >= qthr that exists; an N,
 // a low quality or the end of the read agrees with anything there
-__device__ __forceinline__ unsigned care4(unsigned n4, unsigned q4, unsigned qadd, int cnt) {
-	const unsigned ge = (((q4 & 0x7F7F7F7Fu) + qadd) >> 7) & 0x01010101u;	// 1 where quality >= qthr (qadd = (0x80 - qthr) in every byte)
-	const unsigned isn = (n4 & (n4 >> 1) & (n4 >> 2) & (n4 >> 3)) & 0x01010101u;	// 1 where nt == 15
-	const unsigned in1 = (unsigned) ((0x01010101ull << (8 * cnt)) >> 32);	// 1 in the bytes of the bases that exist
-	const unsigned f = ge & ~isn & in1;
+__device__ __forceinline__ unsigned care4(unsigned skip4, unsigned q4, unsigned qadd) {
+	const unsigned ge = ((q4 & 0x7F7F7F7Fu) + qadd) >> 7;	// bit 0 of a byte: quality >= qthr (qadd = (0x80 - qthr) in every byte)
+	const unsigned f = ge & ~skip4 & 0x01010101u;
 	const unsigned y = f | (f >> 6);
 	return ((y | (y >> 12)) & 0x55u) << 1;
 }
@@ -269,7 +269,7 @@ __device__ __forceinline__ int stage8(const uint4 v, const int len, int lane, un
 		reinterpret_cast<uint16_t *>(wb + (FORWARD ? L::FC : L::RC))[lane] = (uint16_t) (ca | (cb << 8));
 		reinterpret_cast<uint16_t *>(wb + (FORWARD ? L::FN : L::RN))[lane] = (uint16_t) (na | (nb << 8));
 		if (PRIM)
-			reinterpret_cast<uint16_t *>(wb + (FORWARD ? L::CAREF : L::CARER))[lane] = (uint16_t) (care4(n4a, q4a, qadd, c0) | (care4(n4b, q4b, qadd, c1) << 8));
+			reinterpret_cast<uint16_t *>(wb + (FORWARD ? L::CAREF : L::CARER))[lane] = (uint16_t) (care4(n4a, q4a, qadd) | (care4(n4b, q4b, qadd) << 8));
 	}
 	// the usual read does not end in quality 2: two lane reads settle it
 	const int li = (len - 1) >> 3, lb = (len - 1) & 7;
