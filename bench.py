@@ -288,6 +288,12 @@ def main():
     }
     if ctr["rejected"][0] or ctr["rejected"][1]:
         out["stat"]["rejected"] = ctr["rejected"][:2]
+    # which build was measured (the GPU box has no .git: tools/refresh_profiles.sh writes the commit next to the sources)
+    build_id = os.environ.get("PAMD_BUILD")
+    if not build_id and os.path.exists(os.path.join(ROOT, ".build_id")):
+        build_id = open(os.path.join(ROOT, ".build_id")).read().strip()
+    if build_id:
+        out["build"] = build_id
 
     # ---- CPU baseline: the oracle (a scalar C port of the reference path) on this host's cores ----
     # pool.c:140-167 gives every thread an assembler of its own over its share of the input; so does this leg (po_bench_mt:

@@ -173,6 +173,8 @@ void panda_algorithm_unref(PandaAlgorithm algo);
 bool panda_algorithm_is_a(PandaAlgorithm algo, PandaAlgorithmClass clazz);
 PandaAlgorithmClass panda_algorithm_class(PandaAlgorithm algo);
 void *panda_algorithm_data(PandaAlgorithm algo);
+/* algo.c:27-32: log probability of one overlap position given the two bases; built-in classes answer from the host copy of the tables */
+double panda_algorithm_quality_compare(PandaAlgorithm algorithm, const panda_qual *a, const panda_qual *b);
 PandaAlgorithm panda_algorithm_simple_bayes_new(void);
 double panda_algorithm_simple_bayes_get_error_estimation(PandaAlgorithm algorithm);
 void panda_algorithm_simple_bayes_set_error_estimation(PandaAlgorithm algorithm, double q);
@@ -232,6 +234,13 @@ void panda_assembler_set_primer_penalty(PandaAssembler assembler, double thresho
 /* ---- per-base helpers plugins call on the results they are handed (pandaseq-nt.h:76-88, nt.c:120-150) ---- */
 double panda_quality_log_probability(const panda_qual *q);	/* qual_score[PHREDCLAMP(q->qual)] */
 char panda_result_phred(const panda_result *r);			/* the reference's bisection over qual_score, quirks included */
+double panda_quality_probability(const panda_qual *q);		/* nt.c:116-119 */
+/* offset.c:35-38, :103-112, :124-133: the primer scans for a caller's own rows (plugins call them; the assembler's run on the device) */
+double panda_log1mexp(double p);
+size_t panda_compute_offset_qual(double threshold, double penalty, bool reverse, const panda_qual *haystack, size_t haystack_length, const panda_nt *needle, size_t needle_length);
+size_t panda_compute_offset_result(double threshold, double penalty, bool reverse, const panda_result *haystack, size_t haystack_length, const panda_nt *needle, size_t needle_length);
+int panda_api_version(void);		/* misc.c:33-36 */
+char const *panda_version(void);	/* misc.c:28-31 */
 
 /* ---- extensions (not in the reference) ---- */
 /* Which GPU a new assembler is created on, in this order: the calling thread's own choice

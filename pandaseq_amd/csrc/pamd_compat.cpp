@@ -771,6 +771,42 @@ inline int host_clampq(int q) {	// PHREDCLAMP, prob.h:23
 	return q > 46 ? 46 : (q < 0 ? 0 : q);
 }
 
+}	// namespace
+
+// algo.c:27-32: the log probability one overlap position contributes to the merged base, for any algorithm object.  A class
+// the caller registered is asked through its own function; the seven built-in classes carry none here (their merge runs on
+// the device) and answer from the host copy of the tables, each by its own rule (algo_simple_bayes.c:68-75, algo_pear.c:61-68,
+// algo_rdp_mle.c:29-41, algo_uparse.c:68-75, algo_flash.c:66-86, algo_ea_util.c:60-69, algo_stitch.c:60-67).
+double panda_algorithm_quality_compare(PandaAlgorithm algorithm, const panda_qual *a, const panda_qual *b) {
+	const bool match = (a->nt & b->nt) != 0;
+	const struct panda_algorithm_class *cls = panda_algorithm_class(algorithm);
+	if (cls->match_probability != nullptr)
+		return cls->match_probability(panda_algorithm_data(algorithm), match, a->qual, b->qual);
+	const PamdTables &T = host_tables();
+	const int qa = host_clampq(a->qual), qb = host_clampq(b->qual), at = qa * PAMD_NQ + qb;
+	const int larger = host_clampq(a->qual > b->qual ? a->qual : b->qual);	// (compared before clamping, as the reference compares)
+	switch (device_algo_of(algorithm)) {
+	case PAMD_ALGO_PEAR:
+		return match ? T.match_pear[at] : T.mismatch_pear[at];
+	case PAMD_ALGO_RDP_MLE:
+		return match ? T.score[host_clampq(a->qual >= b->qual ? a->qual : b->qual)] : T.mismatch_rdp_asm[at];
+	case PAMD_ALGO_UPARSE:
+		return match ? T.match_uparse[at] : T.mismatch_uparse[at];
+	case PAMD_ALGO_FLASH: {
+		if (match)
+			return T.score[larger];
+		const int d = qa > qb ? qa - qb : qb - qa;
+		return T.score[d < 2 ? 2 : d];
+	}
+	case PAMD_ALGO_EA_UTIL:
+		return T.score[larger];
+	default:	// simple_bayesian; stitch borrows its tables
+		return match ? T.match_sb[at] : T.mismatch_sb[at];
+	}
+}
+
+namespace {
+
 inline unsigned kmer_code(panda_nt nt) {	// misc.h:41
 	return nt == 8 ? 3u : (nt == 4 ? 2u : (nt == 2 ? 1u : 0u));
 }
@@ -1697,6 +1733,49 @@ char panda_result_phred(const panda_result *r) {
 	}
 	return (char) lo;
 }
+
+// ---- the rest of what callers and plugins reach for around the assembler (standalone build only: in a build that links the
+// reference's objects, nt.c, offset.c and misc.c bring their own) ----
+#ifndef PAMD_WITH_REFERENCE_OBJECTS
+double panda_quality_probability(const panda_qual *q) {	// nt.c:116-119
+	return exp(panda_quality_log_probability(q));
+}
+
+double panda_log1mexp(double p) {	// offset.c:35-38, with the host's libm as the reference uses it
+	return (p > M_LN2) ? log1p(-exp(-p)) : log(-expm1(-p));
+}
+
+// offset.c:103-112 / :124-133 for a caller's own rows (plugins such as the reference's other_primer and hang filters call
+// these; the assembler's scans run in the kernels): the same circular-bucket walk the host path uses, `reverse` reading the
+// sequence from its end
+size_t panda_compute_offset_qual(double threshold, double penalty, bool reverse, const panda_qual *haystack, size_t haystack_length, const panda_nt *needle, size_t needle_length) {
+	const PamdTables &T = host_tables();
+	return host_primer_offset(threshold, penalty, haystack_length, [&](size_t i, panda_nt &nt, double &p, double &notp) {
+		const panda_qual &b = haystack[reverse ? haystack_length - i - 1 : i];
+		const int q = host_clampq(b.qual);
+		nt = b.nt;
+		p = T.score[q];
+		notp = T.score_err[q];
+	}, needle, needle_length);
+}
+
+size_t panda_compute_offset_result(double threshold, double penalty, bool reverse, const panda_result *haystack, size_t haystack_length, const panda_nt *needle, size_t needle_length) {
+	return host_primer_offset(threshold, penalty, haystack_length, [&](size_t i, panda_nt &nt, double &p, double &notp) {
+		const panda_result &b = haystack[reverse ? haystack_length - i - 1 : i];
+		nt = b.nt;
+		p = b.p;
+		notp = panda_log1mexp(b.p);
+	}, needle, needle_length);
+}
+
+int panda_api_version(void) {	// misc.c:33-36
+	return PANDA_API;
+}
+
+char const *panda_version(void) {	// misc.c:28-31 (PACKAGE_STRING there)
+	return "pandaseq_amd (assembler core of pandaseq 2.11 on MI355X)";
+}
+#endif
 
 void pamd_compat_set_device(int device) {
 	g_device.store(device);

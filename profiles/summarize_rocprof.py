@@ -25,6 +25,15 @@ for db in argv:
         rows = list(con.execute("select name, start, end, grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count from kernels where name like ? order by start", (LIKE,)))
         for r in rows:
             print(f"   {r[0][:60]:60s} dur_ns={r[2]-r[1]} grid={r[3]} wg={r[4]} lds={r[5]} vgpr={r[6]} sgpr={r[7]}")
+        # the stats table above averages EVERY dispatch of a kernel, bench.py's small start-up launch included: the timed
+        # launches are the full-size ones
+        by = {}
+        for r in rows:
+            by.setdefault(r[0], []).append(r[2] - r[1])
+        print("-- full-size dispatches (at least half the longest) of the selected kernels: name, n, avg_us")
+        for name, durs in by.items():
+            full = [d for d in durs if 2 * d >= max(durs)]
+            print(f"   {name[:60]:60s} n={len(full):3d} avg_us={sum(full) / len(full) / 1e3:.0f}")
     except sqlite3.Error as e:
         print("   (n/a)", e)
     print("-- PMC counters summed over the selected kernels' dispatches: kernel, counter, dispatches, sum")

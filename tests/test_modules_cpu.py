@@ -105,6 +105,91 @@ def test_algorithm_registry(lib):
     assert got.count(b"middle") == 1 and got == sorted(got)
 
 
+def test_quality_compare_of_the_builtin_classes(lib):
+    """panda_algorithm_quality_compare (algo.c:27-32) for the seven built-in classes, whose merge runs on the device and whose
+    class structs carry no host function here: every (match, qual a, qual b) in and around the clamp against the oracle's
+    match_probability -- host tables only, no GPU."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle as po
+
+    class Qual(ctypes.Structure):
+        _fields_ = [("nt", ctypes.c_ubyte), ("qual", ctypes.c_byte)]
+    lib.panda_algorithm_quality_compare.restype = ctypes.c_double
+    lib.panda_algorithm_quality_compare.argtypes = [ctypes.c_void_p, ctypes.POINTER(Qual), ctypes.POINTER(Qual)]
+    lib.panda_algorithm_unref.argtypes = [ctypes.c_void_p]
+    quals = list(range(-3, 50)) + [-128, 127]
+    for algo, ctor in (("simple_bayesian", "simple_bayes"), ("pear", "pear"), ("rdp_mle", "rdp_mle"), ("uparse", "uparse"), ("flash", "flash"),
+                       ("ea_util", "ea_util"), ("stitch", "stitch")):
+        new = getattr(lib, "panda_algorithm_%s_new" % ctor)
+        new.restype = ctypes.c_void_p
+        a = new()
+        cfg = po.make_config(algo)
+        for match, nts in ((1, (1, 1)), (1, (3, 2)), (0, (1, 2)), (0, (4, 8))):
+            for qa in quals:
+                for qb in quals:
+                    got = lib.panda_algorithm_quality_compare(a, ctypes.byref(Qual(nts[0], qa)), ctypes.byref(Qual(nts[1], qb)))
+                    want = po.lib().po_match_probability(ctypes.byref(cfg), ctypes.byref(po.tables()), match, qa, qb)
+                    assert got == want, (algo, match, qa, qb, got, want)
+        lib.panda_algorithm_unref(a)
+
+
+def test_exported_primer_scans(lib):
+    """panda_compute_offset_qual / _result and panda_log1mexp (offset.c:35-38,103-133) as plugins call them on rows of their own:
+    random reads with a primer planted, damaged or absent, both directions, with and without a penalty, against the oracle's
+    scans -- host code only, no GPU."""
+    import sys
+
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle as po
+
+    class Result(ctypes.Structure):
+        _fields_ = [("nt", ctypes.c_ubyte), ("p", ctypes.c_double)]
+    lib.panda_compute_offset_qual.restype = ctypes.c_size_t
+    lib.panda_compute_offset_qual.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_bool, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    lib.panda_compute_offset_result.restype = ctypes.c_size_t
+    lib.panda_compute_offset_result.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_bool, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    lib.panda_log1mexp.restype = ctypes.c_double
+    lib.panda_log1mexp.argtypes = [ctypes.c_double]
+    L = po.lib()
+    L.po_compute_offset_result.restype = ctypes.c_size_t
+    L.po_compute_offset_result.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    assert ctypes.sizeof(Result) == 16
+    rng = np.random.default_rng(11)
+    score = po.tables_np()["score"]
+    found = 0
+    for case in range(300):
+        n, plen = int(rng.integers(1, 120)), int(rng.integers(1, 25))
+        primer = rng.choice(np.array([1, 2, 4, 8, 3, 12, 15], np.uint8), plen)
+        seq = np.zeros((n, 2), np.uint8)
+        seq[:, 0] = rng.choice(np.array([1, 2, 4, 8, 15], np.uint8), n, p=[.24, .24, .24, .24, .04])
+        seq[:, 1] = rng.integers(0, 42, n).astype(np.uint8)
+        if plen <= n and case % 4:
+            at = int(rng.integers(0, n - plen + 1))
+            seq[at:at + plen, 0] = np.where(rng.random(plen) < 0.08, seq[at:at + plen, 0], [int(rng.choice([b for b in (1, 2, 4, 8) if b & c])) for c in primer])
+        thr, penalty = float(np.log(rng.choice([0.6, 0.9, 0.3]))), float(rng.choice([0.0, 0.0, 0.01]))
+        for reverse in (False, True):
+            view = np.ascontiguousarray(seq[::-1] if reverse else seq)
+            want = L.po_compute_offset_qual(ctypes.byref(po.tables()), thr, penalty, view.ctypes.data, n, primer.ctypes.data, plen)
+            got = lib.panda_compute_offset_qual(thr, penalty, reverse, seq.ctypes.data, n, primer.ctypes.data, plen)
+            assert got == want, (case, reverse, n, plen, got, want)
+            found += got != 0
+            rows = (Result * n)()
+            ps = score[np.minimum(seq[:, 1], 46)].copy()
+            for i in range(n):
+                rows[i].nt, rows[i].p = int(seq[i, 0]), float(ps[i])
+            nts = np.ascontiguousarray(seq[:, 0])
+            want = L.po_compute_offset_result(thr, penalty, int(reverse), nts.ctypes.data, ps.ctypes.data, n, primer.ctypes.data, plen)
+            got = lib.panda_compute_offset_result(thr, penalty, reverse, ctypes.byref(rows), n, primer.ctypes.data, plen)
+            assert got == want, (case, reverse, n, plen, got, want)
+    assert found > 100
+    import math
+    for p in (1e-9, 0.1, math.log(2), 0.7, 3.0, 40.0):
+        want = math.log1p(-math.exp(-p)) if p > math.log(2) else math.log(-math.expm1(-p))
+        assert lib.panda_log1mexp(p) == want
+
+
 def test_device_selection_is_per_thread(built):
     """Which GPU a new assembler gets: the calling thread's own choice, else PAMD_DEVICES round robin, else the process
     default -- decided without shared mutable state that two threads creating assemblers could race on (pool.c:140-160
