@@ -239,6 +239,15 @@ double panda_quality_probability(const panda_qual *q);		/* nt.c:116-119 */
 double panda_log1mexp(double p);
 size_t panda_compute_offset_qual(double threshold, double penalty, bool reverse, const panda_qual *haystack, size_t haystack_length, const panda_nt *needle, size_t needle_length);
 size_t panda_compute_offset_result(double threshold, double penalty, bool reverse, const panda_result *haystack, size_t haystack_length, const panda_nt *needle, size_t needle_length);
+/* nt.c:46-114,152-173: IUPAC letters <-> base sets */
+panda_nt panda_nt_from_ascii(char c);
+panda_nt panda_nt_from_ascii_complement(char c);
+panda_nt panda_nt_complement(panda_nt nt);
+char panda_nt_to_ascii(panda_nt val);
+/* proxy.c:141-162, standalone build: to stderr whatever the proxy (the log proxy itself is the reference's) */
+void panda_log_proxy_write_str(PandaLogProxy proxy, const char *str);
+void panda_log_proxy_write_f(PandaLogProxy proxy, const char *format, ...);
+void panda_log_proxy_perror(PandaLogProxy proxy, const char *prefix);
 int panda_api_version(void);		/* misc.c:33-36 */
 char const *panda_version(void);	/* misc.c:28-31 */
 

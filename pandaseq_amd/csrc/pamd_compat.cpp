@@ -5,6 +5,7 @@
 // merges or sums anything.
 #include <hip/hip_runtime_api.h>
 #include <dlfcn.h>
+#include <stdarg.h>
 #include <sched.h>
 #include <atomic>
 #include <cctype>
@@ -1766,6 +1767,50 @@ size_t panda_compute_offset_result(double threshold, double penalty, bool revers
 		p = b.p;
 		notp = panda_log1mexp(b.p);
 	}, needle, needle_length);
+}
+
+// nt.c:46-114,152-173: IUPAC letters <-> base sets, indexed as the reference indexes them (c & 0x1F: either case; U reads as T,
+// X as N, any other character as the empty set).  The device parser carries the same table (pamd_io.hip, nt_table)
+static const unsigned char iupac_sets[32] = { 0, 1, 14, 2, 13, 0, 0, 4, 11, 0, 0, 12, 0, 3, 15, 0, 0, 0, 5, 6, 8, 8, 7, 9, 15, 10, 0, 0, 0, 0, 0, 0 };
+
+panda_nt panda_nt_from_ascii(char c) {
+	return (panda_nt) iupac_sets[(int) c & 0x1F];
+}
+
+panda_nt panda_nt_from_ascii_complement(char c) {	// iupac_reverse, nt.c:81-114: every base of the set complemented = the four bits in reverse order
+	const unsigned v = iupac_sets[(int) c & 0x1F];
+	return (panda_nt) (((v & 1u) << 3) | ((v & 2u) << 1) | ((v & 4u) >> 1) | ((v & 8u) >> 3));
+}
+
+panda_nt panda_nt_complement(panda_nt nt) {	// complementary_nt, nt.c:27-44, entry for entry: V and H both come back as V there
+	static const unsigned char table[16] = { 0, 8, 4, 12, 2, 10, 6, 7, 1, 9, 5, 7, 3, 11, 7, 15 };
+	return (panda_nt) table[(unsigned) nt & 15u];
+}
+
+char panda_nt_to_ascii(panda_nt val) {
+	return (unsigned) val > 15u ? 'N' : "NACMGRSVTWYHKDBN"[(unsigned) val];
+}
+
+// proxy.c:141-162: what plugins say while they are set up.  The log proxy itself (proxy.c, writer.c) is not part of this
+// library -- a PandaLogProxy is passed through to callbacks untouched --, so in the standalone build these go to stderr
+// whatever the proxy; a program that links the reference's proxy.c gets the reference's
+void panda_log_proxy_write_str(PandaLogProxy proxy, const char *str) {
+	(void) proxy;
+	fprintf(stderr, "%s\n", str);
+}
+
+void panda_log_proxy_write_f(PandaLogProxy proxy, const char *format, ...) {
+	(void) proxy;
+	va_list va;
+	va_start(va, format);
+	vfprintf(stderr, format, va);
+	va_end(va);
+	fputc('\n', stderr);
+}
+
+void panda_log_proxy_perror(PandaLogProxy proxy, const char *prefix) {
+	(void) proxy;
+	perror(prefix);
 }
 
 int panda_api_version(void) {	// misc.c:33-36

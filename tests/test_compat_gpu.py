@@ -1,6 +1,7 @@
 """The reference's own per-assembler API (panda_assembler_next / _assemble), re-linked against
 libpandaseq_amd.so by a plain-C client, compared with the oracle."""
 import json
+import ctypes
 import os
 import struct
 import subprocess
@@ -138,6 +139,41 @@ def test_reference_host_plugins(built, tmp_path, plugin, args):
     assert counters[8] == len(ok) - len(expected)
     if plugin == "completely_miss_the_point":
         assert counters[8] > 0, "the filter must reject something for the test to mean anything"
+
+
+def test_reference_plugin_that_calls_back_into_the_library(built, tmp_path):
+    """plugin_other_primer.c, the reference's own binary: its opener parses the primer with panda_nt_from_ascii and its precheck
+    runs panda_compute_offset_qual(log 0.9, 0.01, ...) on every forward read -- both now functions of this library (nt.c:152-155,
+    offset.c:103-112) -- and a pair in whose forward read the primer is found never reaches the device."""
+    import math
+
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    client = os.path.join(REF_DIR, "refclient")
+    so = os.path.join(REF_DIR, "other_primer.so")
+    if not (os.path.exists(client) and os.path.exists(so)):
+        pytest.skip("oracle/_ref was not built (needs /root/reference at build time: make -C oracle ref)")
+    spec = synth.config_spec(2)     # reads that begin with the forward primer, a tenth of them after 1-3 stray bases
+    n = 2000
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 4000, n)
+    rng = np.random.default_rng(5)
+    wipe = rng.random(n) < 0.4      # the primer destroyed in four reads of ten: those pass the filter
+    fwd[wipe, :24, 0] = rng.choice(np.array([1, 2, 4, 8], np.uint8), (int(wipe.sum()), 24))
+    rlen = np.minimum(rlen, flen)
+    pin, out = tmp_path / "pairs.bin", tmp_path / "out.bin"
+    _write_pairs(pin, fwd, rev, flen, rlen)
+    subprocess.check_call([client, str(pin), str(out), "pear", "3", so + ":f:" + spec.fprimer], timeout=300)
+    got, counters, _ = _parse_output(out.read_bytes())
+    primer = synth.nt_codes(spec.fprimer)
+    L = po.lib()
+    found = np.array([L.po_compute_offset_qual(ctypes.byref(po.tables()), math.log(0.9), 0.01, np.ascontiguousarray(fwd[i]).ctypes.data, int(flen[i]),
+                                                primer.ctypes.data, len(primer)) for i in range(n)])
+    o_res = po.assemble_batch(po.make_config("pear"), fwd, rev, flen, rlen)[0]
+    passed = [i for i in range(n) if found[i] == 0 and flen[i] >= 2 and rlen[i] >= 2]
+    expected = [i for i in passed if o_res["status"][i] == 0]
+    assert [g["index"] for g in got] == expected
+    assert 0 < len(expected) < n and (found != 0).sum() > n // 3
+    assert counters[8] == int(((found != 0) & (flen >= 2) & (rlen >= 2)).sum())     # module.c:138-154 counts a precheck's rejections
 
 
 def test_loaded_plugin_file(built, tmp_path):

@@ -190,6 +190,33 @@ def test_exported_primer_scans(lib):
         assert lib.panda_log1mexp(p) == want
 
 
+def test_nt_letters(lib):
+    """panda_nt_from_ascii / _from_ascii_complement / _complement / _to_ascii (nt.c:27-114,152-173): IUPAC sets by letter, either
+    case, U as T, X as N, anything else empty; the complement of a SET as the reference's table has it (V and H both give V --
+    sic, nt.c:35,39), while the complemented LETTER table is right for every letter."""
+    for f in ("panda_nt_from_ascii", "panda_nt_from_ascii_complement"):
+        getattr(lib, f).restype = ctypes.c_ubyte
+        getattr(lib, f).argtypes = [ctypes.c_char]
+    lib.panda_nt_complement.restype = ctypes.c_ubyte
+    lib.panda_nt_complement.argtypes = [ctypes.c_ubyte]
+    lib.panda_nt_to_ascii.restype = ctypes.c_char
+    lib.panda_nt_to_ascii.argtypes = [ctypes.c_ubyte]
+    sets = {"A": "A", "C": "C", "G": "G", "T": "T", "U": "T", "R": "AG", "Y": "CT", "S": "CG", "W": "AT", "K": "GT", "M": "AC",
+            "B": "CGT", "D": "AGT", "H": "ACT", "V": "ACG", "N": "ACGT", "X": "ACGT"}
+    bit = {"A": 1, "C": 2, "G": 4, "T": 8}
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    for c in map(chr, range(64, 96)):
+        want = sum(bit[b] for b in sets.get(c, ""))
+        want_c = sum(bit[comp[b]] for b in sets.get(c, ""))
+        for letter in (c, c.lower()):
+            assert lib.panda_nt_from_ascii(letter.encode("latin1")) == want, letter
+            assert lib.panda_nt_from_ascii_complement(letter.encode("latin1")) == want_c, letter
+    table = [0, 8, 4, 12, 2, 10, 6, 7, 1, 9, 5, 7, 3, 11, 7, 15]
+    assert [lib.panda_nt_complement(v) for v in range(16)] == table
+    assert b"".join(lib.panda_nt_to_ascii(v) for v in range(16)) == b"NACMGRSVTWYHKDBN"
+    assert lib.panda_nt_to_ascii(16) == b"N" and lib.panda_nt_to_ascii(255) == b"N"
+
+
 def test_device_selection_is_per_thread(built):
     """Which GPU a new assembler gets: the calling thread's own choice, else PAMD_DEVICES round robin, else the process
     default -- decided without shared mutable state that two threads creating assemblers could race on (pool.c:140-160
