@@ -1058,12 +1058,150 @@ __device__ __forceinline__ int result_phred_io(const double *score, double p) {
 	return lower;
 }
 
+// The same function without the walk.  The walk's answer depends only on where p lies among the 47 table values: on one of
+// them (exact[k]), or strictly between two (mid[k]: between entries k and k+1; mid[46]: above the last) -- both small tables
+// are made by the walk itself when the kernel starts.  Where p lies follows from arithmetic, qual_score[k] being
+// log(1 - 10^(-k/10)): k = -10 log10(1 - e^p) in single precision is off by far less than one, so p lies in one of two
+// neighbouring intervals and three table reads (one round trip instead of six dependent ones) say which.  If they do not --
+// it has not happened -- the walk decides.
+__device__ __forceinline__ int result_phred_fast(const double *score, const uint8_t *exact, const uint8_t *mid, double p) {
+	if (p <= score[0])
+		return 1;
+	const float x = (float) p;
+	const float y = x > -0.01f ? -x * (1.0f + x * (0.5f + x * (1.0f / 6.0f))) : 1.0f - __expf(x);
+	const float kf = -3.01029995664f * __log2f(y);
+	int r0 = kf > 46.0f ? 46 : (int) kf;	// (p = 0: y = 0, kf = +inf)
+	r0 = r0 < 1 ? 1 : r0;
+	const double s_lo = score[r0 - 1], s_mid = score[r0], s_hi = score[r0 + 1];	// score[47] = +inf
+	if (!(p > s_lo && p <= s_hi))
+		return result_phred_io(score, p);
+	const bool low = p <= s_mid;
+	const int r = low ? r0 : r0 + 1;	// score[r - 1] < p <= score[r]
+	return p == (low ? s_mid : s_hi) ? exact[r] : mid[r - 1];
+}
+
+// ---- the writer ----
+// Lanes of one wavefront exchange data through LDS: the LDS unit executes one wave's operations in issue order, so ordering
+// the compiler is all that is needed.
+// (not a fence: a release fence would also wait for every global store issued so far -- the pairs written before this one)
+__device__ __forceinline__ void io_wave_sync() {
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	__builtin_amdgcn_wave_barrier();
+}
+
+// sixteen bytes to any address: text has no alignment, and a store of a packed type is one global_store_dwordx4 (the ROCm
+// runtime runs compute queues with unaligned access enabled, which is what the compiler assumes for this target)
+struct __attribute__((packed, aligned(1))) Text16 {
+	unsigned x, y, z, w;
+};
+__device__ __forceinline__ void store16(uint8_t *dst, unsigned x, unsigned y, unsigned z, unsigned w) {
+	Text16 t;
+	t.x = x;
+	t.y = y;
+	t.z = z;
+	t.w = w;
+	*reinterpret_cast<Text16 *>(dst) = t;
+}
+
+// panda_nt_to_ascii, nt.c:167-173 ("NACMGRSVTWYHKDBN"; anything outside 0..15 prints N): one nt / four nts of a word
+__device__ __forceinline__ unsigned ascii1(unsigned v) {
+	return v > 15u ? (unsigned) 'N' : (unsigned) ((v < 8u ? ASCII_LO >> (8u * v) : ASCII_HI >> (8u * (v - 8u))) & 0xFFu);
+}
+__device__ __forceinline__ unsigned ascii4(unsigned w) {
+	const unsigned sel = w & 0x07070707u;
+	const unsigned lo = __builtin_amdgcn_perm((unsigned) (ASCII_LO >> 32), (unsigned) ASCII_LO, sel);
+	const unsigned hi = __builtin_amdgcn_perm((unsigned) (ASCII_HI >> 32), (unsigned) ASCII_HI, sel);
+	const unsigned b3 = (w >> 3) & 0x01010101u, m3 = (b3 << 8) - b3;	// 0xFF where nt >= 8
+	const unsigned r = (hi & m3) | (lo & ~m3);
+	const unsigned big = w & 0xF0F0F0F0u;
+	const unsigned nz = (((big & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | big) & 0x80808080u, mb = (nz >> 7) * 255u;	// 0xFF where nt > 15
+	return (r & ~mb) | (0x4E4E4E4Eu & mb);
+}
+
+// a pair's header line, byte by byte into `h` (LDS or the output itself); returns its length
+template <typename Sink>
+__device__ __forceinline__ unsigned compose_header(Sink *h, const FormatParams &P, const IdView &v, u64 i, u64 my_off, unsigned qlo, unsigned qhi) {
+	unsigned n = 0;
+	h[n++] = P.fastq ? '@' : '>';
+	const uint8_t *src = P.hdr_text + v.hdr;
+	for (unsigned k = 0; k < v.instr_len; k++)
+		h[n++] = src[k];
+	if (v.sra >= 0)
+		n += put_dec(h + n, v.sra);
+	h[n++] = ':';
+	for (unsigned k = 0; k < v.run_len; k++)
+		h[n++] = src[v.run_off + k];
+	h[n++] = ':';
+	for (unsigned k = 0; k < v.fc_len; k++)
+		h[n++] = src[v.fc_off + k];
+	h[n++] = ':';
+	n += put_dec(h + n, v.lane);
+	h[n++] = ':';
+	n += put_dec(h + n, v.tile);
+	h[n++] = ':';
+	n += put_dec(h + n, v.x);
+	h[n++] = ':';
+	n += put_dec(h + n, v.y);
+	h[n++] = ':';
+	for (unsigned k = 0; k < v.tag_len; k++)
+		h[n++] = src[v.tag_off + k];
+	// ";%f" of exp(quality) (output.c:93,111): six decimals of a value in [0, 1]
+	union {
+		double d;
+		unsigned u[2];
+	} q;
+	q.u[0] = qlo;
+	q.u[1] = qhi;
+	const double e = exp(q.d);
+	const double s = e * 1e6;
+	const double fl = floor(s);
+	const double frac = s - fl;
+	unsigned m = (unsigned) fl + (frac > 0.5 ? 1u : 0u);
+	if (fabs(frac - 0.5) < 4e-9) {
+		// too close to a rounding boundary to trust this device's exp(): the host re-prints it
+		const unsigned slot = atomicAdd(P.n_fixups, 1u);
+		if (slot < P.max_fixups) {
+			P.fixups[2 * slot] = my_off + n + 1;
+			P.fixups[2 * slot + 1] = i;
+		}
+	}
+	h[n++] = ';';
+	h[n++] = (uint8_t) ('0' + m / 1000000u);
+	h[n++] = '.';
+	m %= 1000000u;
+	unsigned div = 100000u;
+	for (int k = 0; k < 6; k++) {
+		h[n++] = (uint8_t) ('0' + m / div);
+		m %= div;
+		div /= 10u;
+	}
+	h[n++] = '\n';
+	return n;
+}
+
+// Header lines are composed one pair per lane -- into LDS, where a lane's single bytes cost nothing (straight into the output
+// they were sixty scattered one-byte writes per pair, each its own memory transaction) -- and leave with the pair's bases, one
+// pair per wave: the header as contiguous bytes, bases and qualities sixteen per lane in one store each.
+constexpr unsigned HDR_SLOT = 92;	// bytes between two lanes' slots (23 words, odd: the lanes' writes spread over the banks)
+constexpr unsigned HDR_MAX = 88;	// a longer header line goes straight to the output
+constexpr unsigned QUAL_BLOCK = 512;	// qualities staged per round (26 KB of LDS per workgroup in all: six workgroups per CU)
+
 __global__ __launch_bounds__(256) void fmt_write_kernel(const FormatParams P) {
 	// one workgroup = 4 waves = 256 pairs (a quarter of a fmt_len_kernel group); each wave owns 64 pairs
 	__shared__ double score[48];
+	__shared__ uint8_t ph_exact[48], ph_mid[48];	// result_phred_fast's two tables
+	__shared__ __attribute__((aligned(16))) uint8_t hdrs[4][64 * HDR_SLOT];
+	__shared__ __attribute__((aligned(16))) uint8_t quals[4][2][QUAL_BLOCK];	// two pairs' qualities: one being written out, one being made
+	__shared__ __attribute__((aligned(16))) uint8_t tails[4][16];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	if (threadIdx.x < 47)
-		score[threadIdx.x] = P.score[threadIdx.x];
+	if (threadIdx.x < 48)
+		score[threadIdx.x] = threadIdx.x < 47 ? P.score[threadIdx.x] : INFINITY;
+	__syncthreads();
+	if (P.fastq && threadIdx.x < 47) {	// what the walk answers on every table value and between any two
+		const int t = threadIdx.x;
+		ph_exact[t] = (uint8_t) result_phred_io(score, score[t]);
+		ph_mid[t] = (uint8_t) result_phred_io(score, t < 46 ? 0.5 * (score[t] + score[t + 1]) : 0.5 * score[46]);
+	}
 	__syncthreads();
 	const u64 i0 = (u64) blockIdx.x * 256ull + (u64) wv * 64ull;
 	if (i0 >= P.n_pairs)
@@ -1086,11 +1224,11 @@ __global__ __launch_bounds__(256) void fmt_write_kernel(const FormatParams P) {
 			incl += v;
 	}
 	const u64 my_off = P.wg_sums[i0 >> 10] + before + (u64) (incl - len);
-	// ---- header lines, one pair per lane, byte by byte straight into the output (L2 gathers the
-	// partial lines; the bases that follow complete them) ----
+	// ---- header lines, one pair per lane ----
 	unsigned hlen = 0;
 	unsigned seq_len = 0;
 	u64 seq_off = 0;
+	bool direct = false;
 	if (len != 0 && my_off + len > P.out_capacity)
 		len = 0;	// does not fit: reported by the host from the total
 	if (len != 0) {
@@ -1099,80 +1237,109 @@ __global__ __launch_bounds__(256) void fmt_write_kernel(const FormatParams P) {
 		const uint4 ra = r[0], rb = r[1];
 		seq_off = (u64) rb.x | ((u64) rb.y << 32);
 		seq_len = rb.z & 0xFFFFu;
-		uint8_t *h = P.out + my_off;
-		unsigned n = 0;
-		h[n++] = P.fastq ? '@' : '>';
-		const uint8_t *src = P.hdr_text + v.hdr;
-		for (unsigned k = 0; k < v.instr_len; k++)
-			h[n++] = src[k];
-		if (v.sra >= 0)
-			n += put_dec(h + n, v.sra);
-		h[n++] = ':';
-		for (unsigned k = 0; k < v.run_len; k++)
-			h[n++] = src[v.run_off + k];
-		h[n++] = ':';
-		for (unsigned k = 0; k < v.fc_len; k++)
-			h[n++] = src[v.fc_off + k];
-		h[n++] = ':';
-		n += put_dec(h + n, v.lane);
-		h[n++] = ':';
-		n += put_dec(h + n, v.tile);
-		h[n++] = ':';
-		n += put_dec(h + n, v.x);
-		h[n++] = ':';
-		n += put_dec(h + n, v.y);
-		h[n++] = ':';
-		for (unsigned k = 0; k < v.tag_len; k++)
-			h[n++] = src[v.tag_off + k];
-		// ";%f" of exp(quality) (output.c:93,111): six decimals of a value in [0, 1]
-		union {
-			double d;
-			unsigned u[2];
-		} q;
-		q.u[0] = ra.x;
-		q.u[1] = ra.y;
-		const double e = exp(q.d);
-		const double s = e * 1e6;
-		const double fl = floor(s);
-		const double frac = s - fl;
-		unsigned m = (unsigned) fl + (frac > 0.5 ? 1u : 0u);
-		if (fabs(frac - 0.5) < 4e-9) {
-			// too close to a rounding boundary to trust this device's exp(): the host re-prints it
-			const unsigned slot = atomicAdd(P.n_fixups, 1u);
-			if (slot < P.max_fixups) {
-				P.fixups[2 * slot] = my_off + n + 1;
-				P.fixups[2 * slot + 1] = i;
+		direct = 1u + id_text_len(v) + 10u > HDR_MAX;
+		if (direct)
+			hlen = compose_header(P.out + my_off, P, v, i, my_off, ra.x, ra.y);
+		else
+			hlen = compose_header(&hdrs[wv][lane * HDR_SLOT], P, v, i, my_off, ra.x, ra.y);
+	}
+	io_wave_sync();
+	// ---- header, bases (and qualities), one pair per wave ----
+	// Software-pipelined over the wave's pairs: the NEXT pair's row loads are issued before this pair's stores, and used
+	// after them.  vmcnt counts loads and stores in one in-order queue: a pair that loaded its log-p row after the previous
+	// pair's stores would wait for those stores to be acknowledged before it could look at a single value (measured: the
+	// FASTQ form ran 35 % slower with wide stores than with the one-byte stores it had, until the loads moved ahead).
+	constexpr int NP = (int) (QUAL_BLOCK / 64u);
+	struct Row {
+		unsigned hj, sl;
+		bool dj, chunky;
+		u64 off, so;
+	};
+	auto row_of = [&](int j) {
+		Row r;
+		r.hj = (unsigned) __builtin_amdgcn_readlane((int) hlen, j);
+		r.sl = (unsigned) __builtin_amdgcn_readlane((int) seq_len, j);
+		r.dj = __builtin_amdgcn_readlane((int) direct, j) != 0;
+		r.off = (u64) (unsigned) __builtin_amdgcn_readlane((int) (unsigned) my_off, j) | ((u64) (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (my_off >> 32), j) << 32);
+		r.so = (u64) (unsigned) __builtin_amdgcn_readlane((int) (unsigned) seq_off, j) | ((u64) (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (seq_off >> 32), j) << 32);
+		// sixteen bases per lane from one aligned load: rows of the assembler's arenas are 16-byte aligned and padded
+		r.chunky = ((reinterpret_cast<uintptr_t>(P.seq_nt + r.so)) & 15u) == 0 && r.sl <= 1024u;
+		return r;
+	};
+	auto issue_loads = [&](const Row &r, uint4 &ntv, double (&pv)[NP]) {
+		ntv = make_uint4(0u, 0u, 0u, 0u);
+		if (r.chunky && 16u * (unsigned) lane < r.sl)
+			ntv = reinterpret_cast<const uint4 *>(P.seq_nt + r.so)[lane];
+		if (P.fastq) {
+			const double *p = P.seq_p + r.so;
+#pragma unroll
+			for (int q = 0; q < NP; q++) {
+				const unsigned k = 64u * (unsigned) q + (unsigned) lane;
+				pv[q] = k < r.sl ? p[k] : 0.0;
 			}
 		}
-		h[n++] = ';';
-		h[n++] = (uint8_t) ('0' + m / 1000000u);
-		h[n++] = '.';
-		m %= 1000000u;
-		unsigned div = 100000u;
-		for (int k = 0; k < 6; k++) {
-			h[n++] = (uint8_t) ('0' + m / div);
-			m %= div;
-			div /= 10u;
+	};
+	auto stage_quals = [&](const Row &r, const double (&pv)[NP], uint8_t *qb) {
+		if (P.fastq) {
+#pragma unroll
+			for (int q = 0; q < NP; q++) {
+				const unsigned k = 64u * (unsigned) q + (unsigned) lane;
+				if (k < r.sl)
+					qb[k] = (uint8_t) (33 + result_phred_fast(score, ph_exact, ph_mid, pv[q]));
+			}
 		}
-		h[n++] = '\n';
-		hlen = n;
+	};
+	u64 todo = __ballot(len != 0);
+	if (todo == 0)
+		return;
+	int j = __builtin_ctzll(todo);
+	todo &= todo - 1;
+	Row cur = row_of(j);
+	uint4 ntc;
+	int buf = 0;
+	{
+		double pv[NP];
+		issue_loads(cur, ntc, pv);
+		stage_quals(cur, pv, quals[wv][0]);
 	}
-	// ---- bases (and qualities), one pair per wave ----
-	const int npairs = (int) (P.n_pairs - i0 < 64ull ? P.n_pairs - i0 : 64ull);
-	for (int j = 0; j < npairs; j++) {
-		const unsigned lj = (unsigned) __builtin_amdgcn_readlane((int) len, j);
-		if (lj == 0)
-			continue;
-		const unsigned hj = (unsigned) __builtin_amdgcn_readlane((int) hlen, j);
-		const unsigned sl = (unsigned) __builtin_amdgcn_readlane((int) seq_len, j);
-		const u64 off = (u64) (unsigned) __builtin_amdgcn_readlane((int) (unsigned) my_off, j) | ((u64) (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (my_off >> 32), j) << 32);
-		const u64 so = (u64) (unsigned) __builtin_amdgcn_readlane((int) (unsigned) seq_off, j) | ((u64) (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (seq_off >> 32), j) << 32);
-		uint8_t *dst = P.out + off + hj;
-		const uint8_t *nt = P.seq_nt + so;
-		for (unsigned k = lane; k < sl; k += 64) {
-			const unsigned v = nt[k];
-			// panda_nt_to_ascii, nt.c:167-173 ("NACMGRSVTWYHKDBN"; anything outside 0..15 prints N)
-			dst[k] = v > 15u ? (uint8_t) 'N' : (uint8_t) ((v < 8u ? ASCII_LO >> (8u * v) : ASCII_HI >> (8u * (v - 8u))) & 0xFFu);
+	io_wave_sync();
+	for (;;) {
+		const bool more = todo != 0;
+		Row nxt = cur;
+		int jn = j;
+		uint4 ntn = ntc;
+		double pn[NP];
+		if (more) {
+			jn = __builtin_ctzll(todo);
+			todo &= todo - 1;
+			nxt = row_of(jn);
+			issue_loads(nxt, ntn, pn);
+		}
+		// ---- this pair's text ----
+		const unsigned sl = cur.sl;
+		uint8_t *dst = P.out + cur.off;
+		if (!cur.dj) {
+			const uint8_t *hs = &hdrs[wv][j * HDR_SLOT];
+			for (unsigned k = lane; k < cur.hj; k += 64)
+				dst[k] = hs[k];
+		}
+		dst += cur.hj;
+		if (cur.chunky) {
+			const unsigned full = sl >> 4, t0 = full << 4;
+			const unsigned a0 = ascii4(ntc.x), a1 = ascii4(ntc.y), a2 = ascii4(ntc.z), a3 = ascii4(ntc.w);
+			if ((unsigned) lane < full)
+				store16(dst + 16u * (unsigned) lane, a0, a1, a2, a3);
+			if (t0 < sl) {	// the last, partial chunk leaves byte by byte, through LDS
+				if ((unsigned) lane == full)
+					*reinterpret_cast<uint4 *>(tails[wv]) = make_uint4(a0, a1, a2, a3);
+				io_wave_sync();
+				if (t0 + (unsigned) lane < sl)
+					dst[t0 + lane] = tails[wv][lane];
+			}
+		} else {
+			const uint8_t *nt = P.seq_nt + cur.so;
+			for (unsigned k = lane; k < sl; k += 64)
+				dst[k] = (uint8_t) ascii1(nt[k]);
 		}
 		if (lane == 0)
 			dst[sl] = '\n';
@@ -1183,10 +1350,27 @@ __global__ __launch_bounds__(256) void fmt_write_kernel(const FormatParams P) {
 				dst[1] = '\n';
 				dst[2 + sl] = '\n';
 			}
-			const double *p = P.seq_p + so;
-			for (unsigned k = lane; k < sl; k += 64)
-				dst[2 + k] = (uint8_t) (33 + result_phred_io(score, p[k]));
+			uint8_t *dq = dst + 2;
+			const uint8_t *qb = quals[wv][buf];
+			const unsigned nb = sl < QUAL_BLOCK ? sl : QUAL_BLOCK, full = nb >> 4, t0 = full << 4;
+			if ((unsigned) lane < full) {
+				const uint4 v = reinterpret_cast<const uint4 *>(qb)[lane];
+				store16(dq + 16u * (unsigned) lane, v.x, v.y, v.z, v.w);
+			}
+			if (t0 + (unsigned) lane < nb)
+				dq[t0 + lane] = qb[t0 + lane];
+			const double *p = P.seq_p + cur.so;	// (a row longer than the staged block: the rest straight from memory)
+			for (unsigned k = QUAL_BLOCK + lane; k < sl; k += 64)
+				dq[k] = (uint8_t) (33 + result_phred_fast(score, ph_exact, ph_mid, p[k]));
 		}
+		if (!more)
+			break;
+		stage_quals(nxt, pn, quals[wv][buf ^ 1]);
+		io_wave_sync();
+		cur = nxt;
+		j = jn;
+		ntc = ntn;
+		buf ^= 1;
 	}
 }
 

@@ -201,6 +201,41 @@ def test_format_with_rejections_and_fastq_phred_range(io):
     assert bytes(text) == want
 
 
+def test_fastq_phred_of_every_kind_of_value(io):
+    """The FASTQ writer's quality characters over log-p values chosen to sit on, next to and between the 47 table values
+    (panda_result_phred's walk, nt.c:126-150, is replaced on the device by arithmetic plus three table reads): every table
+    value, its two neighbouring doubles, the midpoints, 0, tiny and large negatives, and a dense random cover."""
+    import torch
+    pa, textio, parser, formatter = io
+    spec = synth.config_spec(1)
+    n = 600
+    f, r, fl, rl = synth.generate_numpy(spec, 100, n)
+    ft, rt = synth.render_fastq(f, r, fl, rl)
+    ftd = textio.text_to_device(ft)
+    rows, st = parser.parse(ftd, textio.text_to_device(rt), n + 1, spec.row_stride())
+    asm, b = _assemble(pa, rows, n, "simple_bayesian", ())
+    score = po.tables_np()["score"]
+    rng = np.random.default_rng(3)
+    special = np.concatenate([score, np.nextafter(score, 0.0), np.nextafter(score, -10.0), 0.5 * (score[:-1] + score[1:]),
+                              [0.0, -0.0, -1e-300, -1e-12, -2.4e-5, -2.6e-5, -1.9999999, -2.0000001, -5.0, -50.0, -745.0],
+                              -np.exp(rng.uniform(np.log(1e-6), np.log(3.0), 4000)), rng.uniform(-2.2, 0.0, 4000)])
+    m = b.seq_p.numel()
+    vals = np.resize(rng.permutation(special), m)
+    b.seq_p.copy_(torch.from_numpy(vals).to(b.seq_p.device))
+    out, nbytes, fixups = formatter.format(b, rows["ids"], ftd, textio.OUT_FASTQ)
+    text = bytearray(out[:nbytes].cpu().numpy().tobytes())
+    res = b.results_numpy()
+    textio.apply_fixups(text, fixups, res["quality"])
+    pf, pr, pfl, prl, oids, ost = po.fastq_read(ft, rt, stride=spec.row_stride())
+    nt = b.seq_nt.cpu().numpy()
+    want = []
+    for i in range(n):
+        if res["status"][i] == 0:
+            o, k = int(res["seq_offset"][i]), int(res["seq_len"][i])
+            want.append(po.output_fastq(oids[i], float(res["quality"][i]), nt[o:o + k], vals[o:o + k]))
+    assert len(want) > n // 2 and bytes(text) == b"".join(want)
+
+
 def test_io_golden_fixture(io):
     """The committed fixture tests/golden/io/mixed.npz: text -> rows -> assembly -> FASTA / FASTQ on the device
     against the stored bytes."""
