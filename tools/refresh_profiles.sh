@@ -4,7 +4,8 @@
 # bench lines of configs 1 (fast sums with the CPU baseline and the end-to-end leg; exact sums), 2, 3, 4; rocprofv3
 # --kernel-trace --stats of the default bench command; SQ counters and the per-phase ablation of the lean kernel, SQ counters of
 # config 2's two kernels; the HBM
-# traffic passes of tools/traffic_probe.py (FETCH_SIZE and WRITE_SIZE in separate passes, calibrated on a 1 GiB copy).
+# traffic passes of tools/traffic_probe.py (FETCH_SIZE and WRITE_SIZE in separate passes, calibrated on a 1 GiB copy);
+# the other scorers, `-a`, and the data-format rows (bench.py --io, rocprofv3 of tools/bench_io.py).
 TAG=${1:-run}
 export TMPDIR=/tmp
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -38,5 +39,11 @@ for c in 1 2 3 4; do bash tools/pmc_fk.sh 8000000 $c > "$OUT/pmc_config${c}_fast
 ls "$ROOT"/pandaseq_amd/libpandaseq_amd_fkstop5.so > /dev/null 2>&1 || bash tools/fk_phases.sh build > "$OUT/phases_build.log" 2>&1
 bash tools/fk_phases.sh 8000000 1 > "$OUT/phases_config1_fast.txt" 2>&1
 bash tools/fk_phases.sh 8000000 2 > "$OUT/phases_config2_fast.txt" 2>&1
+# the other scorers on config-1 data, primers after assembly, and the data-format rows (not bench lines: DESIGN.md sections 8 and 9)
+for a in uparse flash ea_util stitch pear rdp_mle; do python3 bench.py --algo $a --no-cpu --no-e2e --steps 3 --warmup 1 2> /dev/null | tail -1 > "$OUT/bench_algo_$a.json"; done
+python3 bench.py --config 2 --primers-after --no-cpu --no-e2e --steps 3 --warmup 1 2> /dev/null | tail -1 > "$OUT/bench_config2_primers_after.json"
+python3 bench.py --io --no-e2e --cpu-seconds 0 --steps 3 --warmup 1 2> /dev/null | tail -1 | python3 -c "import json,sys; json.dump(json.load(sys.stdin)['io'], open(sys.argv[1], 'w'), indent=1)" "$OUT/io_bench.json"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_io" -o t -- python3 "$ROOT/tools/bench_io.py" --pairs 4000000 > "$OUT/prof_io.log" 2>&1)
+python3 profiles/summarize_rocprof.py --like '%f%_kernel%' $(find "$OUT/prof_io" -name '*_results.db' | head -1) > "$OUT/io_rocprof.txt"
 for f in "$OUT"/bench_*.json; do python3 -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1].split('/')[-1], round(d['value']/1e6,1), 'M pairs/s', round(d['roofline']['frac'],4))" $f; done
 for f in "$OUT"/traffic_config*.json; do python3 -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1].split('/')[-1], round(d['hbm_bytes_per_pair'],1), 'B/pair')" $f; done
