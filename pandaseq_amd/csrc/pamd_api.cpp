@@ -86,6 +86,8 @@ struct pamd_assembler {
 	unsigned long long *d_phase = nullptr;
 	void *hb_ptr[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };	// pamd_assemble_host staging
 	size_t hb_cap[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	void *small_h = nullptr, *small_d = nullptr;	// pamd_assemble_host, a few pairs: one pinned block and its device twin
+	size_t small_cap = 0;
 	double *d_scratch = nullptr;	// parked score terms (pear / rdp_mle), sized for the largest launch so far
 	size_t scratch_rows = 0;	// 10 words, only written by -DPAMD_PHASE_TIMING builds
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -209,6 +211,10 @@ void pamd_assembler_destroy(pamd_assembler *a) {
 		(void) hipFree(a->d_count_table);
 	if (a->d_defer_count)
 		(void) hipFree(a->d_defer_count);
+	if (a->small_h)
+		(void) hipHostFree(a->small_h);
+	if (a->small_d)
+		(void) hipFree(a->small_d);
 	for (void *q : a->hb_ptr)
 		if (q)
 			(void) hipFree(q);
@@ -895,6 +901,73 @@ int pamd_assemble_host(pamd_assembler *a, const pamd_batch *hb) {
 	pamd_batch d = *hb;
 	void *dfwd, *drev, *dfl, *drl, *dres, *dnt, *dp, *dcur, *dctr;
 	int rc;
+	// A few pairs (panda_assembler_assemble() sends one: what panda_diff calls per pair, diff.c:26-99): the cost is the number
+	// of runtime calls, not the bytes.  Inputs and the zeroed cursor / counters go up in ONE copy from a pinned block laid out
+	// like its device twin, results, rows, cursor, counters and the overflow word come back in ONE, and the host waits once.
+	{
+		auto up16 = [](size_t v) { return (v + 15) & ~(size_t) 15; };
+		const size_t o_fwd = 0, o_rev = o_fwd + up16(n * hb->fwd_stride * 2), o_fl = o_rev + up16(n * hb->rev_stride * 2), o_rl = o_fl + up16(n * 2);
+		const size_t o_cur = o_rl + up16(n * 2), o_ctr = o_cur + 16, o_err = o_ctr + up16(PAMD_NUM_COUNTERS * 8), o_res = o_err + 16;
+		const size_t o_nt = o_res + up16(n * sizeof(pamd_pair_result)), o_p = o_nt + up16(cap + 16), total = o_p + up16((cap + 16) * sizeof(double));
+		if (total <= ((size_t) 1 << 20)) {
+			if (a->small_cap < total) {
+				if (a->small_h)
+					HIP_TRY(hipHostFree(a->small_h));
+				if (a->small_d)
+					HIP_TRY(hipFree(a->small_d));
+				a->small_h = a->small_d = nullptr;
+				a->small_cap = 0;
+				const size_t want = total + total / 2 + 4096;
+				HIP_TRY(hipHostMalloc(&a->small_h, want, hipHostMallocDefault));
+				HIP_TRY(hipMalloc(&a->small_d, want));
+				a->small_cap = want;
+			}
+			char *h = static_cast<char *>(a->small_h), *dv = static_cast<char *>(a->small_d);
+			memcpy(h + o_fwd, hb->fwd, n * hb->fwd_stride * 2);
+			memcpy(h + o_rev, hb->rev, n * hb->rev_stride * 2);
+			memcpy(h + o_fl, hb->flen, n * 2);
+			memcpy(h + o_rl, hb->rlen, n * 2);
+			memset(h + o_cur, 0, o_res - o_cur);	// cursor, counters, overflow word
+			HIP_TRY(hipMemcpyAsync(dv, h, o_res, hipMemcpyHostToDevice, nullptr));
+			d.fwd = reinterpret_cast<const pamd_qual *>(dv + o_fwd);
+			d.rev = reinterpret_cast<const pamd_qual *>(dv + o_rev);
+			d.flen = reinterpret_cast<const uint16_t *>(dv + o_fl);
+			d.rlen = reinterpret_cast<const uint16_t *>(dv + o_rl);
+			d.results = reinterpret_cast<pamd_pair_result *>(dv + o_res);
+			d.seq_nt = reinterpret_cast<uint8_t *>(dv + o_nt);
+			d.seq_p = reinterpret_cast<double *>(dv + o_p);
+			d.seq_cursor = reinterpret_cast<uint64_t *>(dv + o_cur);
+			d.counters = reinterpret_cast<int64_t *>(dv + o_ctr);
+			d.seq_capacity = cap;
+			unsigned long long *const own_error = a->d_error;
+			a->d_error = reinterpret_cast<unsigned long long *>(dv + o_err);	// (this launch reports an overflow into the block)
+			rc = pamd_assemble_device(a, &d, nullptr);
+			a->d_error = own_error;
+			if (rc != PAMD_OK)
+				return rc;
+			HIP_TRY(hipMemcpyAsync(h + o_cur, dv + o_cur, total - o_cur, hipMemcpyDeviceToHost, nullptr));
+			HIP_TRY(hipStreamSynchronize(nullptr));
+			unsigned long long cur = 0, overflow = 0;
+			memcpy(&cur, h + o_cur, 8);
+			memcpy(&overflow, h + o_err, 8);
+			const size_t used = hb->seq_stride == 0 ? (cur < cap ? (size_t) cur : cap) : cap;
+			memcpy(hb->results, h + o_res, n * sizeof(pamd_pair_result));
+			memcpy(hb->seq_nt, h + o_nt, used);
+			memcpy(hb->seq_p, h + o_p, used * sizeof(double));
+			if (hb->seq_cursor)
+				memcpy(hb->seq_cursor, &cur, 8);
+			if (hb->counters) {
+				const int64_t *c = reinterpret_cast<const int64_t *>(h + o_ctr);
+				for (int i = 0; i < PAMD_NUM_COUNTERS; i++)
+					hb->counters[i] += c[i];
+			}
+			if (overflow) {
+				pamd_set_error("output arena too small: %llu assembled pairs did not fit in seq_capacity=%zu bases", overflow, cap);
+				return PAMD_EINVAL;
+			}
+			return PAMD_OK;
+		}
+	}
 	if ((rc = host_buf(a, 0, n * hb->fwd_stride * 2, &dfwd)) || (rc = host_buf(a, 1, n * hb->rev_stride * 2, &drev)) || (rc = host_buf(a, 2, n * 2, &dfl)) || (rc = host_buf(a, 3, n * 2, &drl)) || (rc = host_buf(a, 4, n * sizeof(pamd_pair_result), &dres)) || (rc = host_buf(a, 5, cap + 16, &dnt)) || (rc = host_buf(a, 6, (cap + 16) * sizeof(double), &dp)) || (rc = host_buf(a, 7, 8, &dcur)) || (rc = host_buf(a, 8, PAMD_NUM_COUNTERS * 8, &dctr)))
 		return rc;
 	HIP_TRY(hipMemcpy(dfwd, hb->fwd, n * hb->fwd_stride * 2, hipMemcpyHostToDevice));

@@ -402,7 +402,10 @@ __device__ __forceinline__ int primer_shortcut(const double *ltab, unsigned char
 	u64 l0 = ballot((int) (packed & 31u) <= K), l1 = ballot((int) ((packed >> 5) & 31u) <= K), l2 = ballot((int) ((packed >> 10) & 31u) <= K);
 	u64 l3 = ballot((int) ((packed >> 15) & 31u) <= K), l4 = ballot((int) ((packed >> 20) & 31u) <= K);
 	const int nleft = __popcll(l0) + __popcll(l1) + __popcll(l2) + __popcll(l3) + __popcll(l4);
-	if (nleft == 1) {	// the usual read: only the alignment already summed is left (it always is: it reaches the bound it set)
+	// the usual read: only the alignment already summed is left.  (It is among what is left whenever the bound is its own value
+	// -- it reaches the bound it set --; when the bound is the threshold, which it does not reach, the one left is another
+	// alignment: summed below like any other.)
+	if (nleft == 1 && kv > thr) {
 		if (sum0 > (thr + 1e-9) * (double) n0)
 			return n0;
 		if (sum0 < (thr - 1e-9) * (double) n0)

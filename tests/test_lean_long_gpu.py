@@ -113,6 +113,57 @@ def test_primer_scan_inside_the_lean_kernel(built, plen, algo, sums):
     assert (st == 0).sum() > n // 4 and ((st == 2) | (st == 3)).sum() > 0 or plen < 8
 
 
+def sweep_case(rnd):
+    """One round of tests/primer_sweep.py (a randomized campaign; rounds that found something are pinned below): primers of
+    random length and content planted at the start of the read, anywhere or nowhere, damaged at random rates and on random
+    shares of poor qualities; every fourth round with ragged read lengths."""
+    from pandaseq_amd import synth
+    codes = np.array([1, 2, 4, 8, 1, 2, 4, 8, 3, 5, 10, 12, 7, 14, 15], np.uint8)
+    rng = np.random.default_rng(7000 + rnd)
+    spec = synth.config_spec(2 if rnd % 3 else 1)
+    L = spec.read_len
+    n = 3000
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, int(rng.integers(0, 40_000_000)), n)
+    fwd[:, :, 0] = np.where(np.arange(fwd.shape[1])[None, :] < L, fwd[:, :, 0], 0)
+    fplen, rplen = int(rng.integers(1, 25)), int(rng.integers(1, 25))
+    fp = rng.choice(codes if rnd % 2 else codes[:4], fplen)
+    rp = rng.choice(codes[:4], rplen)
+    anywhere = rng.choice([0.0, 0.1, 0.4, 1.0])
+    wf = np.where(rng.random(n) < 0.9, rng.integers(0, max(1, L - fplen), n) * (rng.random(n) < anywhere), -1)
+    wr = np.where(rng.random(n) < 0.9, rng.integers(0, max(1, L - rplen), n) * (rng.random(n) < anywhere), -1)
+    subst, lowq = rng.choice([0.0, 0.03, 0.08, 0.2]), rng.choice([0.0, 0.1, 0.3, 0.7])
+    _plant(rng, fwd, flen, fp, wf, subst, lowq)
+    _plant(rng, rev, rlen, rp, wr, subst, lowq)
+    if rnd % 4 == 3:    # ragged lengths: the scan's last alignments, reads shorter than the primer
+        flen[:] = rng.integers(1, L + 1, n)
+        rlen[:] = rng.integers(1, L + 1, n)
+    algo = ["pear", "simple_bayesian", "rdp_mle"][rnd % 3]
+    if algo == "pear":
+        rlen = np.minimum(rlen, flen)
+    thr = float(rng.choice([0.6, 0.6, 0.9, 0.3]))
+    return dict(algo=algo, fwd=fwd, rev=rev, flen=flen, rlen=rlen, fp=fp, rp=rp, thr=thr,
+                what=f"{algo} plen {fplen}/{rplen} anywhere {anywhere} subst {subst} lowq {lowq} thr {thr}")
+
+
+@pytest.mark.parametrize("rnd", [91, 3, 27])
+def test_primer_sweep_rounds_that_found_something(built, rnd, sums):
+    """Round 91 (a two-base primer under threshold 0.9 in ragged reads): the first good alignment does not reach the threshold,
+    exactly one OTHER alignment survives the filter -- and the shortcut took "one left" to mean the one it had summed: NORP
+    where the reference finds the primer.  Rounds 3 and 27: the same shapes of input on the other two scorers."""
+    import pandaseq_amd as pa
+    c = sweep_case(rnd)
+    asm = pa.Assembler(0)
+    asm.set_algorithm(c["algo"])
+    asm.set_exact_sums(sums == "exact")
+    asm.set_threshold(c["thr"])
+    asm.set_forward_primer(c["fp"])
+    asm.set_reverse_primer(c["rp"])
+    b = _run(asm, c["fwd"], c["rev"], c["flen"], c["rlen"])
+    o = _oracle(c["algo"], c["fwd"], c["rev"], c["flen"], c["rlen"], fprimer=c["fp"], rprimer=c["rp"], threshold=c["thr"])
+    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+    compare_counters(b.counters_dict(), o[3])
+
+
 def test_primers_the_lean_kernel_does_not_serve(built):
     """A primer of 25 bases, or a penalty: the launch goes to the primer kernel and the general kernel whole, results unchanged."""
     import pandaseq_amd as pa
