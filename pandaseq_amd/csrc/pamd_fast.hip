@@ -1402,7 +1402,12 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		uint8_t *const row_nt = k_nt + (store ? off : 0);
 		double *const row_p = k_p + (store ? off : 0);
 		double qacc = 0.0;	// this lane's share of the quality sum, any order
-		double pmin = 0.0;	// PHRED: this lane's smallest log-p (every log-p is <= 0)
+		// PHRED: panda_result_phred (nt.c:126-150) answers 1 at or below qual_score[0], 0 between qual_score[0] and [1] (sic) and
+		// does not decrease from there on: the row's smallest phred follows from "any log-p at or below qual_score[0]" and the
+		// smallest log-p ABOVE it -- not from the smallest log-p alone (a row holding both -3.7 and -1.8 has a phred 0)
+		double pmin = 0.0;	// this lane's smallest log-p above qual_score[0] (every log-p is <= 0)
+		bool plow = false;	// ... and whether it saw one at or below it
+		const double qs0 = PHRED ? ltab[PAMD_LT_SCORE] : 0.0;
 		// One pass over the output row, 64 bases per round: lane l of round r makes base j = 64r + l, from forward base j
 		// (j < flen: the forward-only bases [0, A), assembler.c:162-173, and the overlap [A, A + novl), assembler.c:181-228) and
 		// from reverse base rlen - 1 - (j - A) (j >= A: the overlap and the reverse-only bases [A + novl, seqlen),
@@ -1501,8 +1506,12 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				if (lane < lim - 64 * (R0 + k)) {
 					gP[64 * (R0 + k)] = pv[k];
 					qacc += pv[k];
-					if (PHRED)
-						pmin = pv[k] < pmin ? pv[k] : pmin;
+					if (PHRED) {
+						const bool low = pv[k] <= qs0;
+						plow |= low;
+						const double above = low ? 0.0 : pv[k];
+						pmin = above < pmin ? above : pmin;
+					}
 				}
 				degen += __popcll(ballot((ntv[k] & 0xFFu) == 15u));	// PANDA_NT_IS_DEGN: only N here
 			}
@@ -1529,14 +1538,17 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		if (store && lane * 16 < seqlen)
 			((gbl_u128 *) row_nt)[lane] = reinterpret_cast<const u32x4 *>(nts)[lane];
 		if (PHRED) {
-			// panda_result_phred (nt.c:126-150) is 1 at or below qual_score[0] and does not decrease above it, so the row's
-			// smallest phred is that of its smallest log-p: one bisection per pair instead of one per base
+			// one bisection per pair instead of one per base (see above)
 			for (int o = 32; o > 0; o >>= 1) {
 				const double other = __shfl_xor(pmin, o);
 				pmin = other < pmin ? other : pmin;
 			}
 			const double lowest = uni_f64(pmin);
-			phmin = seqlen > 0 ? result_phred(ltab + PAMD_LT_SCORE, lowest) : 127;	// an empty row passes any threshold
+			phmin = result_phred(ltab + PAMD_LT_SCORE, lowest);
+			if (ballot(plow) != 0 && phmin > 1)
+				phmin = 1;
+			if (seqlen <= 0)
+				phmin = 127;	// an empty row passes any threshold
 		}
 		if (!EXACT) {
 			qsum = wave_sum_any_order(qacc);	// divided by len in finish64() ...

@@ -143,6 +143,44 @@ def test_config3_rdp_with_modules(built, sums):
         assert sum(o[3]["rejected"]) > 0
 
 
+@pytest.mark.parametrize("algo", ["simple_bayesian", "uparse"])
+def test_min_phred_one_on_rows_with_both_kinds_of_low_p(built, algo, sums):
+    """panda_result_phred (nt.c:126-150) answers 1 at or below qual_score[0] and 0 just above it (sic): a row that holds a log-p of
+    each kind has a phred 0 although its smallest log-p has phred 1, and `min_phred:1` rejects it.  (Found by
+    tests/parity_sweep.py wide, round 3: the lean kernel took the phred of the smallest log-p.)"""
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 9000, 3000)
+    plain = _oracle(algo, fwd, rev, flen, rlen)
+    # two disagreeing positions planted in every second pair's overlap: qualities (3, 7) give a log-p between qual_score[0] and
+    # [1] under simple_bayesian and (5, 4) under uparse, qualities (4, 30) / (0, 1) one at or below qual_score[0]
+    band, low = ((3, 7), (4, 30)) if algo == "simple_bayesian" else ((5, 4), (0, 1))
+    for i in range(0, len(flen), 2):
+        ov = int(plain[0]["overlap"][i])
+        if plain[0]["status"][i] != 0 or ov < 40:
+            continue
+        for k, (qf, qr) in ((11, band), (23, low)):
+            fi, ri = int(flen[i]) - ov + k, int(rlen[i]) - 1 - k
+            fwd[i, fi] = (1, qf)
+            rev[i, ri] = (2, qr)
+    for mods in ([("min_phred", 1)], [("min_phred", 1), ("min_overlapbits", 5)]):
+        asm = _asm_for(algo, modules=[f"{k}:{v}" for k, v in mods], exact=sums == "exact")
+        b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
+        o = _oracle(algo, fwd, rev, flen, rlen, modules=mods)
+        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+        compare_counters(b.counters_dict(), o[3])
+    s0, s1 = po.tables_np()["score"][:2]
+    plain = _oracle(algo, fwd, rev, flen, rlen)
+    both = 0
+    for i in np.nonzero(plain[0]["status"] == 0)[0]:
+        p = plain[2][i, :int(plain[0]["seq_len"][i])]
+        both += bool((p <= s0).any() and ((p > s0) & (p < s1)).any())
+    want = 500 if algo == "simple_bayesian" else 5     # (uparse accepts few overlaps that disagree twice)
+    assert both > want, "the data must hold rows of the kind the test is about"
+    assert o[3]["rejected"][0] > want and asm.last_deferred() < 1500
+
+
 @pytest.mark.parametrize("settings", [
     dict(minimum_overlap=10), dict(minimum_overlap=60, maximum_overlap=100), dict(maximum_overlap=400),
     dict(threshold=0.9), dict(threshold=0.3), dict(forward_trim=5, reverse_trim=11), dict(maximum_overlap=120, forward_trim=30),
