@@ -78,7 +78,7 @@ typedef struct {
 	int32_t stop_code;	/* PAMD_FQ_*: why record n_good failed; PAMD_FQ_END when n_good == n_records */
 	int32_t stop_in_reverse;	/* the failing read was the reverse one */
 	int32_t seen_under_64;	/* fastq.c:88-90,141-144: feeds the PHRED-offset hint of fastq.c:203-207 */
-	uint32_t max_flen, max_rlen;	/* longest reads among the good records */
+	uint32_t max_flen, max_rlen;	/* longest reads among the pairs kept (good records that were not dropped) */
 	uint32_t reserved;
 } pamd_fastq_status;
 

@@ -872,8 +872,9 @@ __global__ __launch_bounds__(256) void fq_final_kernel(const ParseParams P, Fina
 	const u64 tid = (u64) blockIdx.x * blockDim.x + threadIdx.x, nt = (u64) gridDim.x * blockDim.x;
 	unsigned dropped = 0, mf = 0, mr = 0;
 	for (u64 i = tid; i < n_good; i += nt) {
-		dropped += P.flags[i] == 1 ? 1u : 0u;
-		const unsigned a = P.flen[i], b = P.rlen[i];
+		const unsigned flag = P.flags[i];
+		dropped += flag == 1 ? 1u : 0u;
+		const unsigned a = flag == 0 ? P.flen[i] : 0u, b = flag == 0 ? P.rlen[i] : 0u;	// (a dropped record's other read does not count)
 		mf = a > mf ? a : mf;
 		mr = b > mr ? b : mr;
 	}
