@@ -4,7 +4,7 @@ random length and content planted at the start of the read, anywhere or nowhere,
 shares of poor qualities -- the reads the shortcut settles, the ones left to the list fallback, the ones deferred -- against
 the oracle on every record, row and counter.
 
-    python tests/primer_sweep.py [rounds [first round [after]]]        # ~6 s per round on one MI355X + the oracle on the host's cores
+    python tests/primer_sweep.py [rounds [first round [after|penalty]]]        # ~6 s per round on one MI355X + the oracle on the host's cores
 """
 import os
 import sys
@@ -22,10 +22,14 @@ from util import compare_counters, compare_results
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 after = len(sys.argv) > 3 and sys.argv[3] == "after"      # `-a`: the primers are looked for in the merged sequence (the general kernel)
+penalty = 0.0
+if len(sys.argv) > 3 and sys.argv[3] == "penalty":     # a primer penalty (-T): the careful primer kernel, compared after exp()
+    penalty = None
 bad = 0
 for rnd in range(first, first + rounds):
     c = sweep_case(rnd)
-    o = _oracle(c["algo"], c["fwd"], c["rev"], c["flen"], c["rlen"], fprimer=c["fp"], rprimer=c["rp"], threshold=c["thr"], primers_after=after)
+    pen = penalty if penalty is not None else float(np.random.default_rng(rnd).choice([0.001, 0.01, 0.05]))
+    o = _oracle(c["algo"], c["fwd"], c["rev"], c["flen"], c["rlen"], fprimer=c["fp"], rprimer=c["rp"], threshold=c["thr"], primers_after=after, primer_penalty=pen)
     for exact in (False, True):
         asm = pa.Assembler(0)
         asm.set_algorithm(c["algo"])
@@ -35,6 +39,8 @@ for rnd in range(first, first + rounds):
         asm.set_reverse_primer(c["rp"])
         if after:
             asm.set_primers_after(True)
+        if pen != 0.0:
+            asm.set_primer_penalty(pen)
         b = _run(asm, c["fwd"], c["rev"], c["flen"], c["rlen"])
         try:
             compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=exact)
