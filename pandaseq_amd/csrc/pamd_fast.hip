@@ -715,6 +715,13 @@ struct WaveArena {
 
 // the registers a wave carries from one pair to the next (software prefetch): the lengths and this lane's share of the two
 // rows -- four bases (8 bytes), or eight (16 bytes) in the LONG geometry
+// v_min_f64 itself (no NaNs where it is used)
+__device__ __forceinline__ double min_f64(double a, double b) {
+	double r;
+	asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+
 template <bool LONG>
 struct Carry;
 template <>
@@ -1406,7 +1413,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		// does not decrease from there on: the row's smallest phred follows from "any log-p at or below qual_score[0]" and the
 		// smallest log-p ABOVE it -- not from the smallest log-p alone (a row holding both -3.7 and -1.8 has a phred 0)
 		double pmin = 0.0;	// this lane's smallest log-p above qual_score[0] (every log-p is <= 0)
-		bool plow = false;	// ... and whether it saw one at or below it
+		double pall = 0.0;	// ... and its smallest log-p of all: at or below qual_score[0] if it saw such a one
 		const double qs0 = PHRED ? ltab[PAMD_LT_SCORE] : 0.0;
 		// One pass over the output row, 64 bases per round: lane l of round r makes base j = 64r + l, from forward base j
 		// (j < flen: the forward-only bases [0, A), assembler.c:162-173, and the overlap [A, A + novl), assembler.c:181-228) and
@@ -1507,10 +1514,13 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 					gP[64 * (R0 + k)] = pv[k];
 					qacc += pv[k];
 					if (PHRED) {
-						const bool low = pv[k] <= qs0;
-						plow |= low;
-						const double above = low ? 0.0 : pv[k];
-						pmin = above < pmin ? above : pmin;
+						// (a log-p at or below qual_score[0] loses its high word: what is left is a tiny positive number, which
+						// no minimum of values <= 0 takes -- one select instead of two; the minimum as the bare instruction:
+						// the builtin canonicalises both operands first, two more instructions per base)
+						pall = min_f64(pall, pv[k]);
+						const u64 bits = (u64) __double_as_longlong(pv[k]);
+						const double above = __hiloint2double(pv[k] <= qs0 ? 0 : (int) (bits >> 32), (int) (unsigned) bits);
+						pmin = min_f64(pmin, above);
 					}
 				}
 				degen += __popcll(ballot((ntv[k] & 0xFFu) == 15u));	// PANDA_NT_IS_DEGN: only N here
@@ -1545,7 +1555,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			}
 			const double lowest = uni_f64(pmin);
 			phmin = result_phred(ltab + PAMD_LT_SCORE, lowest);
-			if (ballot(plow) != 0 && phmin > 1)
+			if (ballot(pall <= qs0) != 0 && phmin > 1)
 				phmin = 1;
 			if (seqlen <= 0)
 				phmin = 127;	// an empty row passes any threshold
