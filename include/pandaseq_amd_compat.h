@@ -23,6 +23,7 @@
 
 #include <stdbool.h>
 #include <stddef.h>
+#include <stdio.h>
 
 #ifndef PANDA_API
 #	define PANDA_API 3	/* pandaseq.h:61: the plugin ABI version panda_module_load() demands */
@@ -248,6 +249,15 @@ char panda_nt_to_ascii(panda_nt val);
 void panda_log_proxy_write_str(PandaLogProxy proxy, const char *str);
 void panda_log_proxy_write_f(PandaLogProxy proxy, const char *format, ...);
 void panda_log_proxy_perror(PandaLogProxy proxy, const char *prefix);
+/* seqid.c:46-127: the identifier of a result -- compare, copy, print (parsing header lines is the device parser's job) */
+typedef void (*PandaPrintf) (void *data, const char *format, ...);	/* pandaseq-common.h:530-534 */
+void panda_seqid_clear(panda_seq_identifier *id);
+int panda_seqid_compare(const panda_seq_identifier *one, const panda_seq_identifier *two);
+bool panda_seqid_equal(const panda_seq_identifier *one, const panda_seq_identifier *two);
+void panda_seqid_copy(const panda_seq_identifier *src, panda_seq_identifier *dest);
+void panda_seqid_xprint(const panda_seq_identifier *id, PandaPrintf xprintf, void *x);
+void panda_seqid_print(const panda_seq_identifier *id, FILE *file);
+const char *panda_seqid_str(const panda_seq_identifier *id);
 int panda_api_version(void);		/* misc.c:33-36 */
 char const *panda_version(void);	/* misc.c:28-31 */
 

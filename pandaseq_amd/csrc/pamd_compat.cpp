@@ -1813,6 +1813,66 @@ void panda_log_proxy_perror(PandaLogProxy proxy, const char *prefix) {
 	perror(prefix);
 }
 
+// seqid.c:46-127: what a client does with the identifier of a result -- compare, copy, print.  (Parsing a header line is the
+// device parser's job, pamd_io.hip; the per-string panda_seqid_parse stays the reference's.)
+void panda_seqid_clear(panda_seq_identifier *id) {
+	id->instrument[0] = id->run[0] = id->flowcell[0] = id->tag[0] = '\0';
+	id->lane = id->tile = id->x = id->y = 0;
+}
+
+int panda_seqid_compare(const panda_seq_identifier *one, const panda_seq_identifier *two) {	// fields in the order they print
+	int r = strncmp(one->instrument, two->instrument, sizeof one->instrument);
+	if (r == 0)
+		r = strncmp(one->run, two->run, sizeof one->run);
+	if (r == 0)
+		r = strncmp(one->flowcell, two->flowcell, sizeof one->flowcell);
+	if (r == 0)
+		r = one->lane - two->lane;
+	if (r == 0)
+		r = one->tile - two->tile;
+	if (r == 0)
+		r = one->x - two->x;
+	if (r == 0)
+		r = one->y - two->y;
+	if (r == 0)
+		r = strncmp(one->tag, two->tag, sizeof one->tag);
+	return r;
+}
+
+bool panda_seqid_equal(const panda_seq_identifier *one, const panda_seq_identifier *two) {
+	return one->lane == two->lane && one->tile == two->tile && one->x == two->x && one->y == two->y && strncmp(one->instrument, two->instrument, sizeof one->instrument) == 0
+		&& strncmp(one->run, two->run, sizeof one->run) == 0 && strncmp(one->flowcell, two->flowcell, sizeof one->flowcell) == 0 && strncmp(one->tag, two->tag, sizeof one->tag) == 0;
+}
+
+void panda_seqid_copy(const panda_seq_identifier *src, panda_seq_identifier *dest) {
+	dest->lane = src->lane;
+	dest->tile = src->tile;
+	dest->x = src->x;
+	dest->y = src->y;
+	strncpy(dest->instrument, src->instrument, sizeof dest->instrument);
+	strncpy(dest->run, src->run, sizeof dest->run);
+	strncpy(dest->flowcell, src->flowcell, sizeof dest->flowcell);
+	strncpy(dest->tag, src->tag, sizeof dest->tag);
+}
+
+void panda_seqid_xprint(const panda_seq_identifier *id, PandaPrintf xprintf, void *x) {	// seqid.c:109-116
+	if (id != nullptr)
+		xprintf(x, "%s:%s:%s:%d:%d:%d:%d:%s", id->instrument, id->run, id->flowcell, id->lane, id->tile, id->x, id->y, id->tag);
+}
+
+void panda_seqid_print(const panda_seq_identifier *id, FILE *file) {
+	if (id != nullptr)
+		fprintf(file, "%s:%s:%s:%d:%d:%d:%d:%s", id->instrument, id->run, id->flowcell, id->lane, id->tile, id->x, id->y, id->tag);
+}
+
+const char *panda_seqid_str(const panda_seq_identifier *id) {	// a buffer per thread, as the reference's (buffer.c)
+	static thread_local char text[sizeof(panda_seq_identifier) + 64];
+	if (id == nullptr)
+		return nullptr;
+	snprintf(text, sizeof text, "%s:%s:%s:%d:%d:%d:%d:%s", id->instrument, id->run, id->flowcell, id->lane, id->tile, id->x, id->y, id->tag);
+	return text;
+}
+
 int panda_api_version(void) {	// misc.c:33-36
 	return PANDA_API;
 }

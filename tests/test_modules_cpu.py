@@ -217,6 +217,28 @@ def test_nt_letters(lib):
     assert lib.panda_nt_to_ascii(16) == b"N" and lib.panda_nt_to_ascii(255) == b"N"
 
 
+def test_seqid_helpers(lib):
+    """panda_seqid_clear / _copy / _equal / _compare / _str (seqid.c:46-127): what a client does with a result's identifier."""
+    class SeqId(ctypes.Structure):
+        _fields_ = [("instrument", ctypes.c_char * 100), ("run", ctypes.c_char * 100), ("flowcell", ctypes.c_char * 100), ("lane", ctypes.c_int),
+                    ("tile", ctypes.c_int), ("x", ctypes.c_int), ("y", ctypes.c_int), ("tag", ctypes.c_char * 50)]
+    lib.panda_seqid_str.restype = ctypes.c_char_p
+    lib.panda_seqid_equal.restype = ctypes.c_bool
+    a = SeqId(b"M01271", b"5", b"000000000-A1B2C", 1, 1101, 15589, 1332, b"ACGTAC")
+    assert lib.panda_seqid_str(ctypes.byref(a)) == b"M01271:5:000000000-A1B2C:1:1101:15589:1332:ACGTAC"
+    b = SeqId()
+    lib.panda_seqid_copy(ctypes.byref(a), ctypes.byref(b))
+    assert lib.panda_seqid_equal(ctypes.byref(a), ctypes.byref(b)) and lib.panda_seqid_compare(ctypes.byref(a), ctypes.byref(b)) == 0
+    b.x = 15590
+    assert not lib.panda_seqid_equal(ctypes.byref(a), ctypes.byref(b)) and lib.panda_seqid_compare(ctypes.byref(a), ctypes.byref(b)) < 0
+    b.x, b.tag = a.x, b"ACGTAA"
+    assert lib.panda_seqid_compare(ctypes.byref(a), ctypes.byref(b)) > 0
+    b.instrument = b"M01272"
+    assert lib.panda_seqid_compare(ctypes.byref(a), ctypes.byref(b)) < 0     # the instrument is compared first
+    lib.panda_seqid_clear(ctypes.byref(b))
+    assert lib.panda_seqid_str(ctypes.byref(b)) == b":::0:0:0:0:" and lib.panda_seqid_str(None) is None
+
+
 def test_device_selection_is_per_thread(built):
     """Which GPU a new assembler gets: the calling thread's own choice, else PAMD_DEVICES round robin, else the process
     default -- decided without shared mutable state that two threads creating assemblers could race on (pool.c:140-160
