@@ -480,7 +480,9 @@ static int upload_tables(pamd_assembler *a, hipStream_t st) {
 	return PAMD_OK;
 }
 
-int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
+// `error_flag`: the device word this launch counts its overflowing rows into (the assembler's own, or -- the small-batch path
+// of pamd_assemble_host -- a word of the block that comes back with the results)
+static int assemble_device_impl(pamd_assembler *a, const pamd_batch *b, void *stream, unsigned long long *error_flag) {
 	if (a == nullptr || b == nullptr) {
 		pamd_set_error("pamd_assemble_device: null argument");
 		return PAMD_EINVAL;
@@ -524,7 +526,7 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	p.seq_p = b->seq_p;
 	p.seq_cursor = reinterpret_cast<unsigned long long *>(b->seq_cursor);
 	p.counters = reinterpret_cast<unsigned long long *>(b->counters);
-	p.error_flag = a->d_error;
+	p.error_flag = error_flag;
 	p.phase_cycles = a->d_phase;
 	if (const char *dp = getenv("PAMD_DEBUG_PAIR")) {	// -DPAMD_FK_DEBUG builds: dump the lean kernel's LDS for one pair
 		if (g_debug_buf == nullptr && hipMalloc(&g_debug_buf, 4 * 8192) != hipSuccess)
@@ -780,6 +782,10 @@ int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
 	return PAMD_OK;
 }
 
+int pamd_assemble_device(pamd_assembler *a, const pamd_batch *b, void *stream) {
+	return assemble_device_impl(a, b, stream, a != nullptr ? a->d_error : nullptr);
+}
+
 int pamd_assemble_device_range(pamd_assembler *a, const pamd_batch *b, size_t first, size_t count, void *stream) {
 	if (a == nullptr || b == nullptr || first > b->n_pairs || count > b->n_pairs - first) {
 		pamd_set_error("pamd_assemble_device_range: range outside the batch");
@@ -939,10 +945,7 @@ int pamd_assemble_host(pamd_assembler *a, const pamd_batch *hb) {
 			d.seq_cursor = reinterpret_cast<uint64_t *>(dv + o_cur);
 			d.counters = reinterpret_cast<int64_t *>(dv + o_ctr);
 			d.seq_capacity = cap;
-			unsigned long long *const own_error = a->d_error;
-			a->d_error = reinterpret_cast<unsigned long long *>(dv + o_err);	// (this launch reports an overflow into the block)
-			rc = pamd_assemble_device(a, &d, nullptr);
-			a->d_error = own_error;
+			rc = assemble_device_impl(a, &d, nullptr, reinterpret_cast<unsigned long long *>(dv + o_err));	// (this launch reports an overflow into the block)
 			if (rc != PAMD_OK)
 				return rc;
 			HIP_TRY(hipMemcpyAsync(h + o_cur, dv + o_cur, total - o_cur, hipMemcpyDeviceToHost, nullptr));

@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <sched.h>
 #include <atomic>
+#include <cassert>
 #include <cctype>
 #include <emmintrin.h>
 #include <chrono>
@@ -650,40 +651,50 @@ int push_config(PandaAssembler a) {
 		pamd_set_error("algorithm %s has no device implementation", a->algo ? panda_algorithm_class(a->algo)->name : "(null)");
 		return PAMD_EUNSUPPORTED;
 	}
-	for (pamd_assembler *d : a->devs) {
-	if (d == nullptr)
-		continue;
-	pamd_set_exact_sums(d, compat_exact_sums());
-	pamd_set_algorithm(d, algo, param);
-	pamd_set_primers_after(d, a->post_primers ? 1 : 0);
-	pamd_set_log_threshold(d, a->threshold);	// the stored logarithm itself (assembler_support.c:395): no exp / log round trip
-	pamd_set_minimum_overlap(d, a->minoverlap);
-	pamd_set_maximum_overlap(d, a->maxoverlap);
-	pamd_set_primer_penalty(d, a->primer_penalty);
-	if (a->forward_primer_length > 0)
-		pamd_set_forward_primer(d, reinterpret_cast<const uint8_t *>(a->forward_primer), a->forward_primer_length);
-	else
-		pamd_set_forward_trim(d, a->forward_trim);
-	if (a->reverse_primer_length > 0)
-		pamd_set_reverse_primer(d, reinterpret_cast<const uint8_t *>(a->reverse_primer), a->reverse_primer_length);
-	else
-		pamd_set_reverse_trim(d, a->reverse_trim);
 	// only a leading run of kernel-implemented modules can be fused without changing which module
 	// gets the blame for a rejection (module.c:128-134 stops at the first failure)
-	pamd_clear_modules(d);
 	a->fused_prefix = 0;
 	for (PandaModule m : a->modules) {
-		if (m->fused_kind == 1 && a->fused_prefix < PAMD_MAX_MODULES)
-			pamd_add_module_min_phred(d, m->fused_phred);
-		else if (m->fused_kind == 2 && a->fused_prefix < PAMD_MAX_MODULES)
-			pamd_add_module_min_overlapbits(d, m->fused_bits);
-		else
+		if (m->fused_kind == 0 || a->fused_prefix >= PAMD_MAX_MODULES)
 			break;
 		a->fused_prefix++;
 	}
 	// (a kernel-implemented module that FOLLOWS a host-callback module runs on the host too, from the same definitions:
 	// host_module_check() below)
-	}	// both device assemblers
+	// A `check` that runs on the host reads `quality` and `estimated_overlap_probability` and may compare them with a threshold
+	// of its own -- min_overlapbits behind a host module does, a caller's callback may --: the kernel's guard (a fused verdict
+	// within 1e-6 of its threshold is re-made from sums in the reference's order) does not reach it, so such an assembler sums
+	// in the reference's order throughout.
+	bool host_check = false;
+	for (size_t m = a->fused_prefix; m < a->modules.size(); m++)
+		host_check |= a->modules[m]->fused_kind != 0 || a->modules[m]->check != nullptr;
+	const int exact = (compat_exact_sums() || host_check) ? 1 : 0;
+	for (pamd_assembler *d : a->devs) {
+		if (d == nullptr)
+			continue;
+		pamd_set_exact_sums(d, exact);
+		pamd_set_algorithm(d, algo, param);
+		pamd_set_primers_after(d, a->post_primers ? 1 : 0);
+		pamd_set_log_threshold(d, a->threshold);	// the stored logarithm itself (assembler_support.c:395): no exp / log round trip
+		pamd_set_minimum_overlap(d, a->minoverlap);
+		pamd_set_maximum_overlap(d, a->maxoverlap);
+		pamd_set_primer_penalty(d, a->primer_penalty);
+		if (a->forward_primer_length > 0)
+			pamd_set_forward_primer(d, reinterpret_cast<const uint8_t *>(a->forward_primer), a->forward_primer_length);
+		else
+			pamd_set_forward_trim(d, a->forward_trim);
+		if (a->reverse_primer_length > 0)
+			pamd_set_reverse_primer(d, reinterpret_cast<const uint8_t *>(a->reverse_primer), a->reverse_primer_length);
+		else
+			pamd_set_reverse_trim(d, a->reverse_trim);
+		pamd_clear_modules(d);
+		for (size_t m = 0; m < a->fused_prefix; m++) {
+			if (a->modules[m]->fused_kind == 1)
+				pamd_add_module_min_phred(d, a->modules[m]->fused_phred);
+			else
+				pamd_add_module_min_overlapbits(d, a->modules[m]->fused_bits);
+		}
+	}	// every slot's device assembler
 	{
 		a->image.assign(8192, 0.0);
 		size_t used = 0;
@@ -759,8 +770,7 @@ bool host_module_check(PandaModule mod, const panda_result_seq *res) {
 // A class registered by the caller (algo.c:106-120) scores an overlap and a merged base through its own function pointers
 // (pandaseq-common.h:594-605), which cannot run on the device.  An assembler given such an algorithm assembles on the caller's
 // thread, pair by pair, as assemble_seq() / align() do (assembler.c:48-348), calling those pointers where the reference calls
-// them; the seven classes of this library never take this path (their pointers are NULL here: the kernels are their
-// implementation), except under pamd_compat_force_host_callbacks(), which tests/ uses with a class of its own.
+// them.
 const PamdTables &host_tables() {
 	static PamdTables t;
 	static std::once_flag once;
@@ -862,6 +872,7 @@ struct host_scratch {
 
 // align(), assembler.c:48-250
 bool host_align(PandaAssembler a, panda_result_seq &res, host_scratch &sc) {
+	assert(a->num_kmers == 2);	// two slots per k-mer below (panda_assembler_new_kmer admits nothing else)
 	const PamdTables &T = host_tables();
 	const struct panda_algorithm_class *cls = panda_algorithm_class(a->algo);
 	void *data = panda_algorithm_data(a->algo);
@@ -1094,12 +1105,6 @@ const panda_result_seq *host_assemble(PandaAssembler a, const panda_seq_identifi
 	if (a->longest_overlap < res.overlap)
 		a->longest_overlap = res.overlap;
 	return &res;
-}
-
-// does this assembler's algorithm score through its own function pointers?
-bool uses_host_callbacks(PandaAssembler a) {
-	const struct panda_algorithm_class *cls = a->algo != nullptr ? panda_algorithm_class(a->algo) : nullptr;
-	return cls != nullptr && cls->overlap_probability != nullptr && cls->match_probability != nullptr;
 }
 
 // Replay staged pair `i` the way assemble_seq() would have (assembler.c:252-348).  Returns the

@@ -1715,6 +1715,11 @@ int pamd_fast_supports(const PamdKernelParams &p) {
 			return 0;
 		if (p.ftrim < 0 || p.rtrim < 0 || p.ftrim > Lay<true>::MAXLEN || p.rtrim > Lay<true>::MAXLEN)
 			return 0;
+		// The lean scan compares alignments before exp() (offset.c:59,72-74 compare after it).  With plen * threshold near
+		// exp()'s underflow both sides of the reference's comparison are 0 or denormal and nothing is found; the careful primer
+		// kernel, which compares after exp(), takes such a launch.
+		if ((double) p.fprimer_len * p.threshold < -700.0 || (double) p.rprimer_len * p.threshold < -700.0)
+			return 0;
 		return PAMD_FAST_PRIM;
 	}
 	if (p.smax <= (uint32_t) Lay<false>::MAXLEN)

@@ -19,36 +19,42 @@ from pandaseq_amd import synth
 from test_lean_long_gpu import _oracle, _run, sweep_case
 from util import compare_counters, compare_results
 
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-after = len(sys.argv) > 3 and sys.argv[3] == "after"      # `-a`: the primers are looked for in the merged sequence (the general kernel)
-penalty = 0.0
-if len(sys.argv) > 3 and sys.argv[3] == "penalty":     # a primer penalty (-T): the careful primer kernel, compared after exp()
-    penalty = None
-bad = 0
-for rnd in range(first, first + rounds):
-    c = sweep_case(rnd)
-    pen = penalty if penalty is not None else float(np.random.default_rng(rnd).choice([0.001, 0.01, 0.05]))
-    o = _oracle(c["algo"], c["fwd"], c["rev"], c["flen"], c["rlen"], fprimer=c["fp"], rprimer=c["rp"], threshold=c["thr"], primers_after=after, primer_penalty=pen)
-    for exact in (False, True):
-        asm = pa.Assembler(0)
-        asm.set_algorithm(c["algo"])
-        asm.set_exact_sums(exact)
-        asm.set_threshold(c["thr"])
-        asm.set_forward_primer(c["fp"])
-        asm.set_reverse_primer(c["rp"])
-        if after:
-            asm.set_primers_after(True)
-        if pen != 0.0:
-            asm.set_primer_penalty(pen)
-        b = _run(asm, c["fwd"], c["rev"], c["flen"], c["rlen"])
-        try:
-            compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=exact)
-            compare_counters(b.counters_dict(), o[3])
-        except AssertionError as e:
-            bad += 1
-            print(f"MISMATCH round {rnd} exact {exact} {c['what']}: {str(e)[:300]}", flush=True)
-    st = o[0]["status"]
-    print(f"round {rnd}: {c['what']}: ok {(st == 0).sum()} nofp {(st == 2).sum()} norp {(st == 3).sum()} deferred {asm.last_deferred()}", flush=True)
-print("mismatching launches:", bad)
-sys.exit(1 if bad else 0)
+
+def run(rounds=10, first=0, mode="plain", log=print):
+    """mode: plain | after (`-a`: the primers are looked for in the merged sequence) | penalty (a primer penalty, -T: the careful
+    primer kernel, compared after exp()) -> (mismatching launches, launches compared)"""
+    bad = 0
+    done = 0
+    after = mode == "after"
+    for rnd in range(first, first + rounds):
+        c = sweep_case(rnd)
+        pen = 0.0 if mode != "penalty" else float(np.random.default_rng(rnd).choice([0.001, 0.01, 0.05]))
+        o = _oracle(c["algo"], c["fwd"], c["rev"], c["flen"], c["rlen"], fprimer=c["fp"], rprimer=c["rp"], threshold=c["thr"], primers_after=after, primer_penalty=pen)
+        for exact in (False, True):
+            asm = pa.Assembler(0)
+            asm.set_algorithm(c["algo"])
+            asm.set_exact_sums(exact)
+            asm.set_threshold(c["thr"])
+            asm.set_forward_primer(c["fp"])
+            asm.set_reverse_primer(c["rp"])
+            if after:
+                asm.set_primers_after(True)
+            if pen != 0.0:
+                asm.set_primer_penalty(pen)
+            b = _run(asm, c["fwd"], c["rev"], c["flen"], c["rlen"])
+            done += 1
+            try:
+                compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=exact)
+                compare_counters(b.counters_dict(), o[3])
+            except AssertionError as e:
+                bad += 1
+                log(f"MISMATCH round {rnd} exact {exact} {c['what']}: {str(e)[:300]}")
+        st = o[0]["status"]
+        log(f"round {rnd}: {c['what']}: ok {(st == 0).sum()} nofp {(st == 2).sum()} norp {(st == 3).sum()} deferred {asm.last_deferred()}")
+    return bad, done
+
+
+if __name__ == "__main__":
+    bad, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 10, int(sys.argv[2]) if len(sys.argv) > 2 else 0, sys.argv[3] if len(sys.argv) > 3 else "plain")
+    print("mismatching launches:", bad)
+    sys.exit(1 if bad else 0)
