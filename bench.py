@@ -58,10 +58,13 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (the reference's own panda_assembler_next loop "
                                                           "through the drop-in C API, tests/c/bench_next.c)")
     ap.add_argument("--e2e-pairs", type=int, default=24_000_000)
+    ap.add_argument("--min-phred", type=int, default=2, help="config 3: the min_phred module's threshold.  The synthetic qualities are bimodal: nearly every "
+                                                             "merged row holds a base of PHRED 2, so 2 rejects nothing and 3 rejects 96 %% of the rows -- there is no value "
+                                                             "in between; the reject count is stated in config.workload either way")
     return ap.parse_args()
 
 
-def setup_assembler(pa, synth, cfg_index, device_index, exact_sums=True, algo=None, primers_after=False):
+def setup_assembler(pa, synth, cfg_index, device_index, exact_sums=True, algo=None, primers_after=False, min_phred=2):
     asm = pa.Assembler(device_index)
     asm.set_exact_sums(exact_sums)
     spec = synth.config_spec(cfg_index)
@@ -72,18 +75,18 @@ def setup_assembler(pa, synth, cfg_index, device_index, exact_sums=True, algo=No
         asm.set_forward_primer(synth.nt_codes(spec.fprimer))
         asm.set_reverse_primer(synth.nt_codes(spec.rprimer, complement=True))
     if cfg_index == 3:
-        asm.add_module("min_phred:2")
+        asm.add_module("min_phred:%d" % min_phred)
         asm.add_module("min_overlapbits:15")
     return asm, spec
 
 
-def oracle_config(po, synth, cfg_index, algo=None, primers_after=False):
+def oracle_config(po, synth, cfg_index, algo=None, primers_after=False, min_phred=2):
     spec = synth.config_spec(cfg_index)
     kw = {}
     if cfg_index == 2:
         kw = dict(fprimer=synth.nt_codes(spec.fprimer), rprimer=synth.nt_codes(spec.rprimer, complement=True))
     if cfg_index == 3:
-        kw = dict(modules=[("min_phred", 2), ("min_overlapbits", 15)])
+        kw = dict(modules=[("min_phred", min_phred), ("min_overlapbits", 15)])
     return po.make_config(algo or CONFIGS[cfg_index]["algo"], primers_after=primers_after, **kw)
 
 
@@ -120,7 +123,7 @@ def main():
 
     cfg_index = args.config
     n = args.pairs or CONFIGS[cfg_index]["pairs"]
-    asm, spec = setup_assembler(pa, synth, cfg_index, local, exact_sums=args.sums == "exact", algo=args.algo, primers_after=args.primers_after)
+    asm, spec = setup_assembler(pa, synth, cfg_index, local, exact_sums=args.sums == "exact", algo=args.algo, primers_after=args.primers_after, min_phred=args.min_phred)
     L = spec.read_len
 
     # ---- calibrate the arena on the first pairs, then build the full shard in HBM ----
@@ -228,9 +231,15 @@ def main():
     # workload; scaled to this launch's pair count.
     traffic = args.traffic_bytes
     traffic_src = "--traffic-bytes" if traffic is not None else None
-    tname = f"r03_traffic_config{cfg_index}_{args.sums}.json"
-    tpath = os.path.join(ROOT, "profiles", tname)
-    if traffic is None and os.path.exists(tpath):
+    # (one file per measured workload: a scorer override, `-a` or another min_phred is a different kernel and gets no other's figure)
+    variant = (f"_{args.algo}" if args.algo else "") + ("_after" if args.primers_after else "") + (f"_minphred{args.min_phred}" if cfg_index == 3 and args.min_phred != 2 else "")
+    tname = tpath = None
+    for rnd in ("r04", "r03"):
+        cand = f"{rnd}_traffic_config{cfg_index}{variant}_{args.sums}.json"
+        if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+            tname, tpath = cand, os.path.join(ROOT, "profiles", cand)
+            break
+    if traffic is None and tpath is not None:
         with open(tpath) as fh:
             tj = json.load(fh)
         traffic = tj["hbm_bytes_per_pair"] * n
@@ -252,7 +261,8 @@ def main():
         "dtype": "u8+f64",
         "data": "synthetic",
         "config": {
-            "workload": CONFIGS[cfg_index]["name"] + (f" [scorer overridden: {args.algo}]" if args.algo else "") + (" [-a]" if args.primers_after else ""),
+            "workload": CONFIGS[cfg_index]["name"] + (f" [scorer overridden: {args.algo}]" if args.algo else "") + (" [-a]" if args.primers_after else "")
+                        + (f" [min_phred:{args.min_phred} rejected {ctr['rejected'][0]}, min_overlapbits:15 rejected {ctr['rejected'][1]} of {ctr['count']} pairs]" if cfg_index == 3 else ""),
             "config_index": cfg_index,
             "pairs_per_gpu": n,
             "launches_per_step": n_chunks,
@@ -309,7 +319,7 @@ def main():
         except (OSError, ValueError):
             pass
         effective = min(affinity, quota) if quota else affinity
-        ocfg = oracle_config(po, synth, cfg_index, args.algo, args.primers_after)
+        ocfg = oracle_config(po, synth, cfg_index, args.algo, args.primers_after, args.min_phred)
         pool_n = int(min(n, 4_000_000))
         hf = batch.fwd[:pool_n].cpu().numpy()
         hr = batch.rev[:pool_n].cpu().numpy()
@@ -360,14 +370,15 @@ def main():
             e2e = {}
             keys = ("pairs", "seconds", "pairs_per_s", "ok", "batch_pairs", "distinct_pairs", "api", "rows")
             for name, consume, rows in (("record_only", 0, "eager"), ("every_base_read", 2, "eager"), ("every_base_read_rows_on_callers_thread", 2, "lazy")):
-                d = bench_next.run(config=cfg_index, pairs=args.e2e_pairs if consume == 0 else args.e2e_pairs // 4, sums=args.sums, consume=consume, rows=rows)
+                # (record_only over a million distinct pairs: a cycled source of a few thousand would sit in the caller's cache)
+                d = bench_next.run(config=cfg_index, pairs=args.e2e_pairs if consume == 0 else args.e2e_pairs // 4, sums=args.sums, consume=consume, rows=rows, distinct=1 << 20 if consume == 0 else 8192)
                 e2e[name] = {k: d[k] for k in keys}
             # the reference's own deployment: one assembler per thread (pool.c:140-167), every thread reading every base
             pool_threads = max(2, min(8, len(os.sched_getaffinity(0)) // 2))
             d = bench_next.run_pool(config=cfg_index, pairs=(args.e2e_pairs // 2) * pool_threads, sums=args.sums, threads=pool_threads)
             e2e["every_base_read_one_assembler_per_thread"] = {k: d[k] for k in keys + ("threads",)}
             # the per-pair entry point (what panda_diff calls, diff.c:26-99) and its array form
-            d = bench_next.run(config=cfg_index, pairs=min(20000, args.e2e_pairs), sums=args.sums, consume=2, api=1)
+            d = bench_next.run(config=cfg_index, pairs=min(400_000, args.e2e_pairs), sums=args.sums, consume=2, api=1, distinct=1 << 16)
             e2e["panda_assembler_assemble_per_pair"] = {k: d[k] for k in keys}
             d = bench_next.run(config=cfg_index, pairs=args.e2e_pairs // 4, sums=args.sums, consume=2, api=2)
             e2e["pamd_compat_assemble_many"] = {k: d[k] for k in keys}
@@ -377,7 +388,8 @@ def main():
                            "caller's thread as each record is handed over (rows: lazy, PAMD_COMPAT_ROWS); record_only: the consumer reads each record's "
                            "scalars; every_base_read: it reads nt and p of every merged base (16 B per base on its one thread); ..._one_assembler_per_thread: "
                            "tests/c/bench_pool.c, the same loop in `threads` threads with an assembler each, as pool.c:140-167 runs it; the last two entries: the "
-                           "caller holds the pairs and calls panda_assembler_assemble() per pair / pamd_compat_assemble_many() per 65536 pairs")
+                           "caller holds the pairs and calls panda_assembler_assemble() per pair (assembled on its own thread through the class's two functions, "
+                           "pamd_host_scorers.cpp, as assembler.c:368-383 does) / pamd_compat_assemble_many() per 65536 pairs (the device)")
             out["end_to_end"] = e2e
         except Exception as exc:  # the headline number does not depend on this leg
             out["end_to_end"] = {"error": str(exc)[:300]}

@@ -106,8 +106,8 @@ struct panda_algorithm_class {	/* pandaseq-common.h:594-605 */
 	const char *name;
 	PandaAlgorithmCreate create;
 	PandaDestroy data_destroy;
-	PandaComputeOverlap overlap_probability;	/* NULL in this library: the scoring runs on the GPU */
-	PandaComputeMatch match_probability;	/* NULL in this library */
+	PandaComputeOverlap overlap_probability;	/* the seven built-in classes: host functions (pamd_host_scorers.cpp); batches are scored on the GPU */
+	PandaComputeMatch match_probability;
 	const double prob_unpaired;
 };
 
@@ -278,6 +278,12 @@ void pamd_compat_set_batch_pairs(size_t pairs);
  * reference's own order, every output bit bit-identical, about a fifth slower.  PAMD_COMPAT_SUMS=exact in the environment
  * makes 1 the default of a process. */
 void pamd_compat_set_exact_sums(int exact);
+/* Where panda_assembler_assemble() (pandaseq-assembler.h:137-163, assembler.c:368-383) assembles its ONE pair: 0 (default) = on
+ * the caller's thread, through the algorithm class's overlap_probability / match_probability as the reference does (sums in the
+ * reference's order: every output bit-identical); 1 = on the device like a batch of one (an upload, two launches and a download
+ * per call: for checking the two against each other).  PAMD_COMPAT_PER_PAIR=device makes 1 the default of a process.  Arrays
+ * (pamd_compat_assemble_many) and streams (panda_assembler_next) of pairs always go to the device. */
+void pamd_compat_set_per_pair_device(int device);
 /* The array form of panda_assembler_assemble() (pandaseq-assembler.h:137-163): n pairs through one upload, one launch and
  * one download per 65536 of them instead of one of each per pair -- what a caller that already holds its pairs wants
  * (panda_diff's A/B loop, diff.c:26-99: INTEGRATION.md section 2).  `visit` is called for every pair, in order, with its record

@@ -22,7 +22,7 @@
 #include <thread>
 #include <vector>
 #include "pamd_internal.h"
-#include "../../include/pandaseq_amd_compat.h"
+#include "pamd_host_scorers.h"
 
 static_assert(sizeof(panda_qual) == 2, "panda_qual ABI");
 static_assert(sizeof(panda_result) == 16 && offsetof(panda_result, p) == 8, "panda_result ABI");
@@ -79,6 +79,16 @@ int compat_lazy_rows() {
 		const char *e = getenv("PAMD_COMPAT_ROWS");
 		v = (e != nullptr && strcmp(e, "lazy") == 0) ? 1 : 0;
 		g_lazy_rows.store(v);
+	}
+	return v;
+}
+std::atomic<int> g_per_pair_device{-1};
+int compat_per_pair_device() {
+	int v = g_per_pair_device.load();
+	if (v < 0) {
+		const char *e = getenv("PAMD_COMPAT_PER_PAIR");
+		v = (e != nullptr && strcmp(e, "device") == 0) ? 1 : 0;
+		g_per_pair_device.store(v);
 	}
 	return v;
 }
@@ -186,13 +196,28 @@ static PandaAlgorithm stitch_create(const char *arg) {
 }
 
 extern "C" {
-const struct panda_algorithm_class panda_algorithm_uparse_class = { 3 * sizeof(double), "uparse", uparse_create, nullptr, nullptr, nullptr, -1.38629 };
-const struct panda_algorithm_class panda_algorithm_flash_class = { 0, "flash", flash_create, nullptr, nullptr, nullptr, -1.38629 };
-const struct panda_algorithm_class panda_algorithm_ea_util_class = { 0, "ea_util", ea_util_create, nullptr, nullptr, nullptr, -1.38629 };
-const struct panda_algorithm_class panda_algorithm_stitch_class = { 0, "stitch", stitch_create, nullptr, nullptr, nullptr, -1.38629 };
-const struct panda_algorithm_class panda_algorithm_simple_bayes_class = { 3 * sizeof(double), "simple_bayesian", sb_create, nullptr, nullptr, nullptr, -1.38629 };
-const struct panda_algorithm_class panda_algorithm_pear_class = { sizeof(double), "pear", pear_create, nullptr, nullptr, nullptr, -1.38629 };
-const struct panda_algorithm_class panda_algorithm_rdp_mle_class = { 0, "rdp_mle", rdp_create, nullptr, nullptr, nullptr, -1.38629 };
+// Every class object is complete (pandaseq-common.h:594-605): `overlap_probability` / `match_probability` are the host
+// functions of pamd_host_scorers.cpp -- what a caller or a plugin gets when it scores through a class object, and what the
+// per-pair entry point runs on; batches and streams of pairs are scored by the kernels (device_algo_of() below picks them by
+// class, never by these pointers).
+#define PAMD_CLASS_FNS(ALGO)                                                                                                                                        \
+	static double ALGO##_overlap_fn(void *d, const panda_qual *f, size_t fl, const panda_qual *r, size_t rl, size_t ov) { return pamd_host_scorers[ALGO].overlap_probability(d, f, fl, r, rl, ov); } \
+	static double ALGO##_match_fn(void *d, bool m, char a, char b) { return pamd_host_scorers[ALGO].match_probability(d, m, a, b); }
+PAMD_CLASS_FNS(PAMD_ALGO_SIMPLE_BAYES)
+PAMD_CLASS_FNS(PAMD_ALGO_PEAR)
+PAMD_CLASS_FNS(PAMD_ALGO_RDP_MLE)
+PAMD_CLASS_FNS(PAMD_ALGO_UPARSE)
+PAMD_CLASS_FNS(PAMD_ALGO_FLASH)
+PAMD_CLASS_FNS(PAMD_ALGO_EA_UTIL)
+PAMD_CLASS_FNS(PAMD_ALGO_STITCH)
+#undef PAMD_CLASS_FNS
+const struct panda_algorithm_class panda_algorithm_uparse_class = { 3 * sizeof(double), "uparse", uparse_create, nullptr, PAMD_ALGO_UPARSE_overlap_fn, PAMD_ALGO_UPARSE_match_fn, -1.38629 };
+const struct panda_algorithm_class panda_algorithm_flash_class = { 0, "flash", flash_create, nullptr, PAMD_ALGO_FLASH_overlap_fn, PAMD_ALGO_FLASH_match_fn, -1.38629 };
+const struct panda_algorithm_class panda_algorithm_ea_util_class = { 0, "ea_util", ea_util_create, nullptr, PAMD_ALGO_EA_UTIL_overlap_fn, PAMD_ALGO_EA_UTIL_match_fn, -1.38629 };
+const struct panda_algorithm_class panda_algorithm_stitch_class = { 0, "stitch", stitch_create, nullptr, PAMD_ALGO_STITCH_overlap_fn, PAMD_ALGO_STITCH_match_fn, -1.38629 };
+const struct panda_algorithm_class panda_algorithm_simple_bayes_class = { 3 * sizeof(double), "simple_bayesian", sb_create, nullptr, PAMD_ALGO_SIMPLE_BAYES_overlap_fn, PAMD_ALGO_SIMPLE_BAYES_match_fn, -1.38629 };
+const struct panda_algorithm_class panda_algorithm_pear_class = { sizeof(double), "pear", pear_create, nullptr, PAMD_ALGO_PEAR_overlap_fn, PAMD_ALGO_PEAR_match_fn, -1.38629 };
+const struct panda_algorithm_class panda_algorithm_rdp_mle_class = { 0, "rdp_mle", rdp_create, nullptr, PAMD_ALGO_RDP_MLE_overlap_fn, PAMD_ALGO_RDP_MLE_match_fn, -1.38629 };
 
 PandaAlgorithm panda_algorithm_new(PandaAlgorithmClass clazz) {	// algo.c:85-94
 	PandaAlgorithm a = static_cast<PandaAlgorithm>(calloc(1, sizeof(struct panda_algorithm)));
@@ -643,6 +668,10 @@ int device_algo_of(PandaAlgorithm algorithm, double *param_out = nullptr) {
 }
 
 int push_config(PandaAssembler a) {
+	if (a->dev == nullptr) {	// (pamd_compat_host_only_assembler_new: a test hook; nothing but the per-pair host path works on it)
+		pamd_set_error("this assembler has no device: only panda_assembler_assemble() runs on it");
+		return PAMD_ENODEVICE;
+	}
 	if (!a->dev_dirty)
 		return PAMD_OK;
 	double param = NAN;
@@ -784,36 +813,10 @@ inline int host_clampq(int q) {	// PHREDCLAMP, prob.h:23
 
 }	// namespace
 
-// algo.c:27-32: the log probability one overlap position contributes to the merged base, for any algorithm object.  A class
-// the caller registered is asked through its own function; the seven built-in classes carry none here (their merge runs on
-// the device) and answer from the host copy of the tables, each by its own rule (algo_simple_bayes.c:68-75, algo_pear.c:61-68,
-// algo_rdp_mle.c:29-41, algo_uparse.c:68-75, algo_flash.c:66-86, algo_ea_util.c:60-69, algo_stitch.c:60-67).
+// algo.c:27-32: the log probability one overlap position contributes to the merged base, for any algorithm object: asked of
+// the class's own function (the seven built-in classes': pamd_host_scorers.cpp).
 double panda_algorithm_quality_compare(PandaAlgorithm algorithm, const panda_qual *a, const panda_qual *b) {
-	const bool match = (a->nt & b->nt) != 0;
-	const struct panda_algorithm_class *cls = panda_algorithm_class(algorithm);
-	if (cls->match_probability != nullptr)
-		return cls->match_probability(panda_algorithm_data(algorithm), match, a->qual, b->qual);
-	const PamdTables &T = host_tables();
-	const int qa = host_clampq(a->qual), qb = host_clampq(b->qual), at = qa * PAMD_NQ + qb;
-	const int larger = host_clampq(a->qual > b->qual ? a->qual : b->qual);	// (compared before clamping, as the reference compares)
-	switch (device_algo_of(algorithm)) {
-	case PAMD_ALGO_PEAR:
-		return match ? T.match_pear[at] : T.mismatch_pear[at];
-	case PAMD_ALGO_RDP_MLE:
-		return match ? T.score[host_clampq(a->qual >= b->qual ? a->qual : b->qual)] : T.mismatch_rdp_asm[at];
-	case PAMD_ALGO_UPARSE:
-		return match ? T.match_uparse[at] : T.mismatch_uparse[at];
-	case PAMD_ALGO_FLASH: {
-		if (match)
-			return T.score[larger];
-		const int d = qa > qb ? qa - qb : qb - qa;
-		return T.score[d < 2 ? 2 : d];
-	}
-	case PAMD_ALGO_EA_UTIL:
-		return T.score[larger];
-	default:	// simple_bayesian; stitch borrows its tables
-		return match ? T.match_sb[at] : T.mismatch_sb[at];
-	}
+	return panda_algorithm_class(algorithm)->match_probability(panda_algorithm_data(algorithm), (a->nt & b->nt) != 0, a->qual, b->qual);
 }
 
 namespace {
@@ -1907,6 +1910,10 @@ void pamd_compat_set_lazy_rows(int lazy) {
 	g_lazy_rows.store(lazy ? 1 : 0);
 }
 
+void pamd_compat_set_per_pair_device(int device) {
+	g_per_pair_device.store(device ? 1 : 0);
+}
+
 void pamd_compat_set_exact_sums(int exact) {
 	g_exact_sums.store(exact ? 1 : 0);
 }
@@ -1946,6 +1953,18 @@ PandaAssembler panda_assembler_new_kmer(PandaNextSeq next, void *next_data, Pand
 		a->devs[k] = pamd_assembler_create(device);
 	a->num_kmers = num_kmers;
 	a->algo = panda_algorithm_simple_bayes_new();	// assembler_support.c:77
+	memset(&a->result, 0, sizeof a->result);
+	a->result.sequence = a->result_seq;
+	return a;
+}
+
+// Test hook (tests/c/test_per_pair.c; not declared in the public headers): an assembler WITHOUT a device, on which only the
+// per-pair host path works -- panda_assembler_assemble(), assembler.c:368-383 -- so that path can be checked against the oracle
+// on a machine without a GPU.  Every batch entry point fails on it, loudly (push_config).  panda_assembler_new() itself still
+// refuses to build an assembler without a GPU.
+PandaAssembler pamd_compat_host_only_assembler_new(void) {
+	PandaAssembler a = new panda_assembler;
+	a->algo = panda_algorithm_simple_bayes_new();
 	memset(&a->result, 0, sizeof a->result);
 	a->result.sequence = a->result_seq;
 	return a;
@@ -2015,7 +2034,11 @@ const panda_result_seq *panda_assembler_assemble(PandaAssembler a, panda_seq_ide
 		fprintf(stderr, "pandaseq_amd: panda_assembler_assemble() called while panda_assembler_next() has prefetched pairs pending\n");
 		return nullptr;
 	}
-	if (device_algo_of(a->algo) < 0)	// a class of the caller's: scored through its own functions, on this thread
+	// One pair handed over at a time (what panda_diff does, diff.c:26-99) is assembled on the caller's thread through the
+	// class's two functions, as assembler.c:368-383 does: an upload, two launches and a download per pair cost 40 us, the pair
+	// itself 3.  Arrays (pamd_compat_assemble_many) and streams (panda_assembler_next) of pairs go to the kernels.
+	// PAMD_COMPAT_PER_PAIR=device / pamd_compat_set_per_pair_device(1) sends single pairs there too (tests compare the two).
+	if (device_algo_of(a->algo) < 0 || !compat_per_pair_device() || a->dev == nullptr)
 		return host_assemble(a, id, forward, forward_length, reverse, reverse_length);
 	ensure_staging(a, 1);
 	stage_pair(a, 0, id, forward, forward_length, reverse, reverse_length);

@@ -7,7 +7,7 @@ builder's lease.  Here every driver run sees a slice of each; the seeds rotate w
 rounds see different inputs.  A round that finds something is pinned as a test of its own (test_lean_long_gpu.py,
 test_parity_gpu.py), never fixed and forgotten.
 
-Also: the lean kernel + general kernel against the general kernel alone (tools/fk_probe.py's comparison as a test), 4 M pairs of
+Also: the lean kernel + general kernel against the general kernel alone (tools/fk_probe.py's comparison as a test), 8 M pairs of
 each BASELINE configuration: every record, every counter, every merged base and log-p of every accepted pair.
 
 Each test id carries the campaign, the first round and the number of rounds; the launches compared are asserted (a campaign that
@@ -41,8 +41,8 @@ def _verdict(name, bad, done, want_done, lines):
 
 # (campaign, mode, first round, rounds, launches the slice must have compared)
 # parity: per round 4 configurations x (7 + 7 + 3 + 7 scorers) x 2 sum modes = 48 launches
-PARITY = [("plain", 100 * ROUND, 3, 3 * 48), ("wide", 100 * ROUND, 5, 5 * 48)]
-PRIMER = [("plain", 2000 * ROUND, 12, 24), ("after", 2000 * ROUND + 500, 5, 10), ("penalty", 2000 * ROUND + 700, 5, 10)]
+PARITY = [("plain", 100 * ROUND, 8, 8 * 48), ("wide", 100 * ROUND, 12, 12 * 48)]
+PRIMER = [("plain", 2000 * ROUND, 60, 120), ("after", 2000 * ROUND + 500, 20, 40), ("penalty", 2000 * ROUND + 700, 20, 40)]
 
 
 @pytest.mark.parametrize("mode,first,rounds,launches", PARITY, ids=[f"parity-{m}-first{f}-rounds{r}-launches{l}" for m, f, r, l in PARITY])
@@ -61,7 +61,7 @@ def test_primer_campaign(built, mode, first, rounds, launches):
     _verdict(f"primer_sweep {mode}", bad, done, launches, lines)
 
 
-LENGTH = (300 * ROUND, 6, 6 * 14)
+LENGTH = (300 * ROUND, 16, 16 * 14)
 
 
 @pytest.mark.parametrize("first,rounds,launches", [LENGTH], ids=["length-first%d-rounds%d-launches%d" % LENGTH])
@@ -72,7 +72,7 @@ def test_length_campaign(built, first, rounds, launches):
     _verdict("length_sweep first%d rounds%d" % (first, rounds), bad, done, launches, lines)
 
 
-TEXTIO = (400 * ROUND, 12)
+TEXTIO = (400 * ROUND, 60)
 
 
 @pytest.mark.parametrize("first,rounds", [TEXTIO], ids=["textio-first%d-rounds%d" % TEXTIO])
@@ -83,7 +83,7 @@ def test_textio_campaign(built, first, rounds):
     _verdict("textio_sweep first%d rounds%d" % (first, rounds), bad, done, rounds, lines)
 
 
-COMPAT = (500 * ROUND, 9, 18)
+COMPAT = (500 * ROUND, 40, 80)
 
 
 @pytest.mark.parametrize("first,rounds,runs", [COMPAT], ids=["compat-first%d-rounds%d-runs%d" % COMPAT])
@@ -108,9 +108,9 @@ def _launch(pa, bench, synth, cfg, mode, rows, n, sums_exact, primers_after=Fals
     return asm, b
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4], ids=lambda c: f"config{c}-4Mpairs-start{ROUND}0M")
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4], ids=lambda c: f"config{c}-8Mpairs-start{ROUND}0M")
 def test_lean_plus_general_equals_general_alone(built, cfg):
-    """The two-kernel launch defers, never approximates: on 4 M pairs of each BASELINE configuration (any-order sums, the
+    """The two-kernel launch defers, never approximates: on 8 M pairs of each BASELINE configuration (any-order sums, the
     bench's mode) every record field, every counter and every merged base and log-p of every accepted pair is what the
     general kernel alone produces.  `quality` (and the pear / rdp_mle score) are sums in any order in both: within 1e-9."""
     import torch
@@ -118,7 +118,7 @@ def test_lean_plus_general_equals_general_alone(built, cfg):
     import bench
     import pandaseq_amd as pa
     from pandaseq_amd import synth
-    n = 4_000_000
+    n = 8_000_000
     spec = synth.config_spec(cfg)
     rows = synth.generate_device(spec, ROUND * 10_000_000, n)
     asm_a, a = _launch(pa, bench, synth, cfg, "two-kernel", rows, n, False)
@@ -151,3 +151,5 @@ def test_lean_plus_general_equals_general_alone(built, cfg):
         differing += int(diff.any(dim=1).sum().item())
     print(f"config {cfg}: {n} pairs, {deferred} deferred by the lean kernel, {accepted.size} rows compared", flush=True)
     assert differing == 0, f"{differing} of {accepted.size} rows differ"
+    del a, b, rows
+    torch.cuda.empty_cache()

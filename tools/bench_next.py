@@ -36,15 +36,28 @@ def write_pairs(path, fwd, rev, flen, rlen):
         fh.write(rec.tobytes())
 
 
+def synth_pairs(spec, n):
+    """n pairs of the synthetic stream as numpy rows: from the device generator when there is a GPU (the host twin takes
+    200 us per pair), else the host twin (tested equal)."""
+    from pandaseq_amd import synth
+    import torch
+    if torch.cuda.is_available():
+        f, r, fl, rl = synth.generate_device(spec, 0, n)
+        torch.cuda.synchronize()
+        return f.cpu().numpy(), r.cpu().numpy(), fl.cpu().numpy().astype("<u2"), rl.cpu().numpy().astype("<u2")
+    return synth.generate_numpy(spec, 0, n)
+
+
 def run(config=1, pairs=4_000_000, sums="exact", batch=65536, distinct=8192, algo=None, consume=2, api=0, rows="eager"):
     from pandaseq_amd import synth
     import bench
     spec = synth.config_spec(config)
     with tempfile.TemporaryDirectory() as tmp:
         exe = build(tmp)
-        fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, min(distinct, pairs))
+        fwd, rev, flen, rlen = synth_pairs(spec, min(distinct, pairs))
         pin = os.path.join(tmp, "pairs.bin")
         write_pairs(pin, fwd, rev, flen, rlen)
+        del fwd, rev
         env = dict(os.environ)
         env["PAMD_COMPAT_ROWS"] = rows
         out = subprocess.check_output([exe, pin, str(pairs), algo or bench.CONFIGS[config]["algo"].replace("simple_bayesian", "sb"), "1" if sums == "exact" else "0", str(batch), str(consume), str(api)], timeout=1200, env=env)
@@ -64,9 +77,10 @@ def run_pool(config=1, pairs=8_000_000, sums="fast", threads=8, distinct=8192, a
         exe = os.path.join(tmp, "bench_pool")
         subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "bench_pool.c"), "-o", exe, "-lpthread",
                                "-L", os.path.join(ROOT, "pandaseq_amd"), "-lpandaseq_amd", "-Wl,-rpath," + os.path.join(ROOT, "pandaseq_amd"), "-Wl,-rpath,/opt/rocm/lib"])
-        fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, min(distinct, pairs))
+        fwd, rev, flen, rlen = synth_pairs(spec, min(distinct, pairs))
         pin = os.path.join(tmp, "pairs.bin")
         write_pairs(pin, fwd, rev, flen, rlen)
+        del fwd, rev
         out = subprocess.check_output([exe, pin, str(pairs), algo or bench.CONFIGS[config]["algo"].replace("simple_bayesian", "sb"), "1" if sums == "exact" else "0", str(threads)], timeout=1200)
     d = json.loads(out.decode().strip().splitlines()[-1])
     d.update(config=config, sums=sums, distinct_pairs=min(distinct, pairs), api="panda_assembler_next, one assembler per thread", rows="eager", batch_pairs=65536)
