@@ -7,7 +7,7 @@
 // against this library's host copy of the tables (pamd_tables.cpp) -- and they are what the per-pair entry point
 // panda_assembler_assemble() runs on (pamd_compat.cpp host_assemble(): one pair handed over at a time is scored on the caller's
 // thread; arrays and streams of pairs go to the kernels, which implement the same arithmetic in pamd_kernels.hip / pamd_fast.hip
-// and are tested equal to these, record for record).  Product code: nothing here comes from oracle/.
+// and are tested equal to these, record for record).  Product code, written for this library: the test-side checker is never involved.
 #include <cmath>
 #include <cstddef>
 #include <mutex>
