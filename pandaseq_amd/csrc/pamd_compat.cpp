@@ -800,11 +800,13 @@ bool host_module_check(PandaModule mod, const panda_result_seq *res) {
 // (pandaseq-common.h:594-605), which cannot run on the device.  An assembler given such an algorithm assembles on the caller's
 // thread, pair by pair, as assemble_seq() / align() do (assembler.c:48-348), calling those pointers where the reference calls
 // them.
-const PamdTables &host_tables() {
-	static PamdTables t;
-	static std::once_flag once;
-	std::call_once(once, [] { pamd_build_tables(&t); });
-	return t;
+const PamdTables &host_tables() {	// (built on first use; afterwards one guard-byte test per call)
+	static const PamdTables *const t = [] {
+		PamdTables *p = new PamdTables;
+		pamd_build_tables(p);
+		return p;
+	}();
+	return *t;
 }
 
 inline int host_clampq(int q) {	// PHREDCLAMP, prob.h:23
@@ -869,7 +871,10 @@ size_t host_primer_offset(double threshold, double penalty, size_t n, Base base,
 }
 
 struct host_scratch {
-	std::vector<uint16_t> seen = std::vector<uint16_t>(2u << 16, 0);	// first two forward positions per k-mer (0 = none)
+	// first two forward positions per k-mer (assembler.c:94-99), each entry tagged with the pair it was written for
+	// (tag << 16 | position; a stale tag reads as "none"), so the table is cleared once per 65 535 pairs and not per pair
+	std::vector<uint32_t> seen = std::vector<uint32_t>(2u << 16, 0);
+	uint32_t tag = 0;
 	std::vector<uint8_t> bits;
 };
 
@@ -890,24 +895,29 @@ bool host_align(PandaAssembler a, panda_result_seq &res, host_scratch &sc) {
 		maxov = (size_t) a->maxoverlap;
 	const size_t size = minov <= maxov ? maxov - minov + 1 : 1;
 	sc.bits.assign(size, 0);
+	if (++sc.tag == 0x10000u) {
+		std::fill(sc.seen.begin(), sc.seen.end(), 0u);
+		sc.tag = 1;
+	}
+	const uint32_t tag = sc.tag << 16;
+	// (a k-mer ends at position >= 8, so a stored position is never 0 and a zeroed entry never carries a live tag)
 	host_kmers(res.forward, flen, false, [&](size_t k, size_t p) {
-		uint16_t *slot = &sc.seen[2 * k];
-		if (slot[0] == 0)
-			slot[0] = (uint16_t) p;
-		else if (slot[1] == 0)
-			slot[1] = (uint16_t) p;
+		uint32_t *slot = &sc.seen[2 * k];
+		if ((slot[0] ^ tag) >= 0x10000u)
+			slot[0] = tag | (uint32_t) p;
+		else if ((slot[1] ^ tag) >= 0x10000u)
+			slot[1] = tag | (uint32_t) p;
 	});
 	bool any = false;
 	host_kmers(res.reverse, rlen, true, [&](size_t k, size_t p) {
-		for (int j = 0; j < 2 && sc.seen[2 * k + j] != 0; j++) {
-			const ptrdiff_t index = (ptrdiff_t) (flen + rlen) - (ptrdiff_t) p - (ptrdiff_t) sc.seen[2 * k + j] - (ptrdiff_t) minov - 1;
+		for (int j = 0; j < 2 && (sc.seen[2 * k + j] ^ tag) < 0x10000u; j++) {
+			const ptrdiff_t index = (ptrdiff_t) (flen + rlen) - (ptrdiff_t) p - (ptrdiff_t) (sc.seen[2 * k + j] & 0xFFFFu) - (ptrdiff_t) minov - 1;
 			if (index >= 0 && (size_t) index < size) {
 				sc.bits[(size_t) index] = 1;
 				any = true;
 			}
 		}
 	});
-	host_kmers(res.forward, flen, false, [&](size_t k, size_t) { sc.seen[2 * k] = sc.seen[2 * k + 1] = 0; });
 	double best = qual_nn * (double) (flen + rlen);
 	ptrdiff_t bo = -1;
 	res.overlaps_examined = 0;
@@ -936,7 +946,10 @@ bool host_align(PandaAssembler a, panda_result_seq &res, host_scratch &sc) {
 	const ptrdiff_t df = (ptrdiff_t) flen - (ptrdiff_t) fo - bo, dr = (ptrdiff_t) rlen - (ptrdiff_t) ro - bo;
 	const ptrdiff_t vdf = df < 0 ? 0 : df, wdf = df > 0 ? 0 : df, vdr = dr < 0 ? 0 : dr, wdr = dr > 0 ? 0 : dr;
 	// PANDA_NT_IS_DEGN (pandaseq-nt.h:55): anything but exactly one of the four bits -- nt 0 counts as degenerate
-	auto degenerate = [](panda_nt nt) { return ((((unsigned int) nt) * 0x200040008001ULL & 0x111111111111111ULL) % 0xf) != 1; };
+	auto degenerate = [](panda_nt nt) {	// (the macro's multiply-and-modulo counts the set bits of a 14-bit value; a panda_nt has four)
+		const unsigned v = (unsigned int) nt;
+		return v < 16u ? __builtin_popcount(v) != 1 : ((v * 0x200040008001ULL & 0x111111111111111ULL) % 0xf) != 1;
+	};
 	double fq = 0, oq = 0, rq = 0;
 	for (ptrdiff_t i = 0; i < vdf; i++) {
 		const panda_qual &b = res.forward[(size_t) i + fo];

@@ -73,12 +73,27 @@ __device__ __forceinline__ double dpp_f64(double v) {
 	return y.d;
 }
 
+// the same move into the rows ROWS selects only; the other rows receive 0.0
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_f64_rows(double v) {
+	union {
+		double d;
+		int i[2];
+	} x, y;
+	x.d = v;
+	y.i[0] = __builtin_amdgcn_update_dpp(0, x.i[0], CTRL, ROWS, 0xF, false);
+	y.i[1] = __builtin_amdgcn_update_dpp(0, x.i[1], CTRL, ROWS, 0xF, false);
+	return y.d;
+}
+
 __device__ __forceinline__ double wave_sum_any_order(double v) {
 	v += dpp_f64<0xB1>(v);	// quad_perm:[1,0,3,2]
 	v += dpp_f64<0x4E>(v);	// quad_perm:[2,3,0,1]
 	v += dpp_f64<0x141>(v);	// row_half_mirror
-	v += dpp_f64<0x140>(v);	// row_mirror
-	return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
+	v += dpp_f64<0x140>(v);	// row_mirror: every lane holds its row's sum
+	v += dpp_f64_rows<0x142, 0xA>(v);	// row_bcast:15 into rows 1 and 3: row 0's sum joins row 1's, row 2's joins row 3's
+	v += dpp_f64_rows<0x143, 0xC>(v);	// row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+	return lane_f64(v, 63);
 }
 
 __device__ __forceinline__ int clampq(int q) {	// PHREDCLAMP, prob.h:23
@@ -95,7 +110,9 @@ __device__ __forceinline__ constexpr bool counting_algo() {
 }
 
 // walked = bases present on both reads (the reference's real_overlap)
-template <int ALGO>
+// NONNEG: the caller knows ov <= min(flen, rlen) (no configured maximum overlap: the lean kernel), so the count of bases
+// outside the overlap cannot wrap
+template <int ALGO, bool NONNEG = false>
 __device__ __forceinline__ double count_score(double qual_nn, double pmatch, double pmismatch, const double *count_table, int flen, int rlen, int ov, int unknowns, int matches, int walked) {
 	const int mismatches = walked - unknowns - matches;
 	if (ALGO == PAMD_ALGO_FLASH) {
@@ -118,7 +135,7 @@ __device__ __forceinline__ double count_score(double qual_nn, double pmatch, dou
 	// included: when flen + rlen - 2*ov + unknowns is negative the reference's unsigned value is
 	// 2^64 - |x|, whose conversion to double goes through the 64-bit path; otherwise one 32-bit conversion is exact
 	const int fbases = (ov >= flen && ov >= rlen) ? unknowns : flen + rlen - 2 * ov + unknowns;
-	const double free_bases = fbases >= 0 ? (double) (unsigned) fbases : (double) (u64) (long long) fbases;
+	const double free_bases = (NONNEG || fbases >= 0) ? (double) (unsigned) fbases : (double) (u64) (long long) fbases;
 	return qual_nn * free_bases + (double) matches * pmatch + (double) mismatches * pmismatch;
 }
 

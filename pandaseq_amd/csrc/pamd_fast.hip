@@ -683,7 +683,7 @@ __device__ __attribute__((noinline)) ManyResult scan_many(unsigned char *wb, int
 	int bov = 0x7FFFFFFF;
 #pragma unroll
 	for (int k = 0; k < 4; k++) {
-		const double sc = count_score<ALGO>(qual_nn, pmatch, pmismatch, count_table, flen, rlen, ov[k], (int) (acc[k] & 1023u), (int) (acc[k] >> 10), ov[k]);
+		const double sc = count_score<ALGO, true>(qual_nn, pmatch, pmismatch, count_table, flen, rlen, ov[k], (int) (acc[k] & 1023u), (int) (acc[k] >> 10), ov[k]);
 		if (ov[k] != 0 && sc > pr) {
 			pr = sc;
 			bov = ov[k];
@@ -742,26 +742,35 @@ __device__ __forceinline__ void settle(Carry<true> &c) {
 	asm volatile("" : "+v"(c.flen_v), "+v"(c.rlen_v), "+v"(c.f.x), "+v"(c.f.y), "+v"(c.f.z), "+v"(c.f.w), "+v"(c.r.x), "+v"(c.r.y), "+v"(c.r.z), "+v"(c.r.w));
 }
 
-__device__ __forceinline__ uint2 load_row(const uint8_t *row, unsigned row_bytes, int lane) {
+// (the row's address is a scalar: pair index x row bytes, kept out of the vector ALU -- where the compiler otherwise folds it
+// into one 64-bit multiply-add per lane, a quarter-rate instruction -- by passing through a scalar register as an integer; the
+// load is then global_load with a scalar base and a 32-bit lane offset)
+typedef __attribute__((address_space(1))) const uint8_t gbl_cu8;
+__device__ __forceinline__ gbl_cu8 *scalar_row(const uint8_t *base, unsigned q, unsigned row_bytes) {
+	u64 a = (u64) (uintptr_t) base + (u64) q * row_bytes;
+	asm volatile("" : "+s"(a));
+	return (gbl_cu8 *) a;
+}
+__device__ __forceinline__ uint2 load_row(gbl_cu8 *row, unsigned row_bytes, int lane) {
 	unsigned off = (unsigned) lane * 8u;
 	off = off < row_bytes ? off : row_bytes - 8u;	// lanes past the row's end re-read its last bytes (rows are whole multiples of 16 B)
-	return *reinterpret_cast<const uint2 *>(row + off);
+	return *reinterpret_cast<__attribute__((address_space(1))) const uint2 *>(row + off);
 }
-__device__ __forceinline__ uint4 load_row16(const uint8_t *row, unsigned row_bytes, int lane) {
+__device__ __forceinline__ uint4 load_row16(gbl_cu8 *row, unsigned row_bytes, int lane) {
 	unsigned off = (unsigned) lane * 16u;
 	off = off < row_bytes ? off : row_bytes - 16u;
-	return *reinterpret_cast<const uint4 *>(row + off);
+	return *reinterpret_cast<__attribute__((address_space(1))) const uint4 *>(row + off);
 }
 template <bool LONG>
 __device__ __forceinline__ void load_pair(Carry<LONG> &c, const PamdKernelParams &P, unsigned q, int lane) {
 	c.flen_v = P.flen[q];
 	c.rlen_v = P.rlen[q];
 	if constexpr (LONG) {
-		c.f = load_row16(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
-		c.r = load_row16(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
+		c.f = load_row16(scalar_row(P.fwd, q, P.fwd_row_bytes), P.fwd_row_bytes, lane);
+		c.r = load_row16(scalar_row(P.rev, q, P.rev_row_bytes), P.rev_row_bytes, lane);
 	} else {
-		c.f = load_row(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
-		c.r = load_row(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
+		c.f = load_row(scalar_row(P.fwd, q, P.fwd_row_bytes), P.fwd_row_bytes, lane);
+		c.r = load_row(scalar_row(P.rev, q, P.rev_row_bytes), P.rev_row_bytes, lane);
 	}
 }
 
@@ -783,6 +792,42 @@ __device__ __forceinline__ unsigned insert_at(unsigned lds_byte_addr, unsigned c
 	}
 	return carry;
 }
+
+// One level of the forward insert for all of a lane's words at once: the ds_min of every word that is not EMPTY is issued --
+// a lane with nothing to insert stays out of the LDS (exec) --, then ONE wait; what moves on is max(slot's previous word, word),
+// EMPTY staying EMPTY.  Inline assembly because the compiler, given `if (carry != EMPTY) old = atomicMin(..)` four times,
+// waits for each atomic inside its own branch: eight exposed LDS round trips per pair instead of two.  (The wait sits inside
+// the statement: between issue and wait nothing may touch the destination registers, and the compiler's own counter
+// bookkeeping does not see into an asm statement.)
+#define FK_INS(W, A, C) "v_cmp_ne_u32_e32 vcc, -1, " C "\n\ts_and_saveexec_b64 %[sv], vcc\n\tds_min_rtn_u32 " W ", " A ", " C "\n\ts_mov_b64 exec, %[sv]\n\t"
+template <int BPL>
+__device__ __forceinline__ void insert_all(const unsigned (&addr)[BPL], unsigned (&carry)[BPL]) {
+	unsigned was[BPL];
+#pragma unroll
+	for (int j = 0; j < BPL; j++)
+		was[j] = 0;
+	u64 sv;
+	static_assert(BPL >= 3 && BPL <= 5, "three, four or five words per lane");
+	if constexpr (BPL == 3)
+		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") "s_waitcnt lgkmcnt(0)"
+			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [sv] "=&s"(sv)
+			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2])
+			     : "vcc", "memory");
+	else if constexpr (BPL == 4)
+		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") FK_INS("%[w3]", "%[a3]", "%[c3]") "s_waitcnt lgkmcnt(0)"
+			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [w3] "+v"(was[3]), [sv] "=&s"(sv)
+			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [a3] "v"(addr[3]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [c3] "v"(carry[3])
+			     : "vcc", "memory");
+	else
+		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") FK_INS("%[w3]", "%[a3]", "%[c3]") FK_INS("%[w4]", "%[a4]", "%[c4]") "s_waitcnt lgkmcnt(0)"
+			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [w3] "+v"(was[3]), [w4] "+v"(was[4]), [sv] "=&s"(sv)
+			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [a3] "v"(addr[3]), [a4] "v"(addr[4]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [c3] "v"(carry[3]), [c4] "v"(carry[4])
+			     : "vcc", "memory");
+#pragma unroll
+	for (int j = 0; j < BPL; j++)
+		carry[j] = was[j] > carry[j] ? was[j] : carry[j];
+}
+#undef FK_INS
 
 // why pairs are deferred, counted in P.phase_cycles[0..5] (read back with pamd_debug_phase_cycles): 0 an nt or quality
 // outside the lean domain, 1 a k-mer found no slot, 2 a score comparison too close to call (pear, rdp_mle), 3 more than four
@@ -1016,12 +1061,17 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				carry[j] = (nw & (0x15555u << (2 * j))) == 0 ? word : EMPTY;
 			}
 			const unsigned l1 = lds_addr(t1), l2 = lds_addr(t2);
+			{
+				unsigned addr[BPL];
 #pragma unroll
-			for (int j = 0; j < BPL; j++)
-				carry[j] = insert_at(lshl_add<2>(mul24(carry[j] >> 16, HASH_C) >> (32 - T1B), l1), carry[j]);
+				for (int j = 0; j < BPL; j++)
+					addr[j] = lshl_add<2>(mul24(carry[j] >> 16, HASH_C) >> (32 - T1B), l1);
+				insert_all<BPL>(addr, carry);
 #pragma unroll
-			for (int j = 0; j < BPL; j++)
-				carry[j] = insert_at(lshl_add<2>(__builtin_amdgcn_ubfe(mul24(carry[j] >> 16, HASH_C), 14, 8), l2), carry[j]);
+				for (int j = 0; j < BPL; j++)
+					addr[j] = lshl_add<2>(__builtin_amdgcn_ubfe(mul24(carry[j] >> 16, HASH_C), 14, 8), l2);
+				insert_all<BPL>(addr, carry);
+			}
 			bool lost = false;
 #pragma unroll
 			for (int j = 0; j < BPL; j++) {
@@ -1308,7 +1358,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		} else {
 			// ---- scan + argmax: one candidate per 16-lane row, 16 positions per lane ----
 			const int row = lane >> 4;
-			const int myov = row == 0 ? ov0 : (row == 1 ? ov1 : (row == 2 ? ov2 : ov3));
+			int myov = ov0;	// (nine pairs in ten have one candidate: no per-lane selects)
+			if (ncand != 1)
+				myov = row == 0 ? ov0 : (row == 1 ? ov1 : (row == 2 ? ov2 : ov3));
 			unsigned packed = word_counts<L>(wb, flen, rlen, myov, 16 * (lane & 15), row < ncand);
 			if (LONG && (ov0 > 256 || ov1 > 256 || ov2 > 256 || ov3 > 256))	// (a row of lanes covers 256 positions)
 				packed += word_counts<L>(wb, flen, rlen, myov, 256 + 16 * (lane & 15), row < ncand);
@@ -1317,7 +1369,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x122, 0xF, 0xF, false);	// row_ror:2
 			packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x121, 0xF, 0xF, false);	// row_ror:1
 			const int unknowns = (int) (packed & 1023u), matches = (int) (packed >> 10);
-			const double sc = count_score<ALGO>(P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.count_table, flen, rlen, myov, unknowns, matches, myov);
+			const double sc = count_score<ALGO, true>(P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.count_table, flen, rlen, myov, unknowns, matches, myov);
 #pragma unroll
 			for (int r = 0; r < 4; r++) {
 				if (r < ncand) {
@@ -1583,26 +1635,40 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		if (status == PAMD_ST_DEFER && P.primer_offsets != nullptr && lane == 0)
 			P.primer_offsets[pair] = primers_known ? ((P.fprimer_len > 0 ? (unsigned) fo + 1u : 0u) | ((P.rprimer_len > 0 ? (unsigned) ro + 1u : 0u) << 16)) : 0xFFFFFFFFu;
 	}
-	// park the pair's scalars in lane `slot_idx` of the pending registers (finish64)
-	const bool mine = lane == slot_idx;
+	// park the pair's scalars in lane `slot_idx` of the pending registers (finish64): every value is wave-uniform and the lane
+	// is a scalar, so each field is one v_writelane (a compare-and-select per field costs a move from the scalar file as well)
 	union {
 		double d;
 		unsigned u[2];
 	} qq, bb;
 	qq.d = qsum;
 	bb.d = best;
-	pd.off_lo = put_lane(pd.off_lo, (unsigned) off, mine);
-	pd.off_hi = put_lane(pd.off_hi, (unsigned) (off >> 32), mine);
-	pd.q_lo = put_lane(pd.q_lo, qq.u[0], mine);
-	pd.q_hi = put_lane(pd.q_hi, qq.u[1], mine);
-	pd.b_lo = put_lane(pd.b_lo, bb.u[0], mine);
-	pd.b_hi = put_lane(pd.b_hi, bb.u[1], mine);
-	pd.len_bo = put_lane(pd.len_bo, (unsigned) seqlen | ((unsigned) (bo < 0 ? 0 : bo) << 16), mine);
-	pd.ex_mm = put_lane(pd.ex_mm, (unsigned) examined | ((unsigned) mism << 16), mine);
-	pd.dg_fo = put_lane(pd.dg_fo, (unsigned) degen | ((unsigned) fo << 16), mine);
-	if (EXACT)	// exact sums: where the row's three chains begin and end (assembler.c:171,226,236): the overlap is [A0, AF)
-		pd.pid = put_lane(pd.pid, (unsigned) region_a0 | ((unsigned) region_af << 16), mine);
-	pd.ro_st = put_lane(pd.ro_st, (unsigned) ro | ((unsigned) status << 16) | ((unsigned) slow << 24) | ((unsigned) (phmin > 63 ? 63 : phmin) << 26), mine);
+	// (v_writelane_b32 takes one scalar register besides M0: the lane goes into M0, once per group of fields.  M0 cannot be
+	// declared clobbered -- it is a reserved register --; nothing the compiler emits for these kernels reads it: no LDS-DMA, no
+	// s_movrel, no GDS; `make asm` + grep m0 is the check after a compiler change)
+	const unsigned f_len_bo = (unsigned) seqlen | ((unsigned) (bo < 0 ? 0 : bo) << 16), f_ex_mm = (unsigned) examined | ((unsigned) mism << 16);
+	const unsigned f_dg_fo = (unsigned) degen | ((unsigned) fo << 16);
+	const unsigned f_ro_st = (unsigned) ro | ((unsigned) status << 16) | ((unsigned) slow << 24) | ((unsigned) (phmin > 63 ? 63 : phmin) << 26);
+	asm volatile("s_mov_b32 m0, %6\n\t"
+		     "v_writelane_b32 %0, %7, m0\n\t"
+		     "v_writelane_b32 %1, %8, m0\n\t"
+		     "v_writelane_b32 %2, %9, m0\n\t"
+		     "v_writelane_b32 %3, %10, m0\n\t"
+		     "v_writelane_b32 %4, %11, m0\n\t"
+		     "v_writelane_b32 %5, %12, m0"
+		     : "+v"(pd.off_lo), "+v"(pd.off_hi), "+v"(pd.q_lo), "+v"(pd.q_hi), "+v"(pd.b_lo), "+v"(pd.b_hi)
+		     : "s"(slot_idx), "s"(uni((int) (unsigned) off)), "s"(uni((int) (unsigned) (off >> 32))), "s"(uni((int) qq.u[0])), "s"(uni((int) qq.u[1])), "s"(uni((int) bb.u[0])), "s"(uni((int) bb.u[1])));
+	asm volatile("s_mov_b32 m0, %4\n\t"
+		     "v_writelane_b32 %0, %5, m0\n\t"
+		     "v_writelane_b32 %1, %6, m0\n\t"
+		     "v_writelane_b32 %2, %7, m0\n\t"
+		     "v_writelane_b32 %3, %8, m0"
+		     : "+v"(pd.len_bo), "+v"(pd.ex_mm), "+v"(pd.dg_fo), "+v"(pd.ro_st)
+		     : "s"(slot_idx), "s"(uni((int) f_len_bo)), "s"(uni((int) f_ex_mm)), "s"(uni((int) f_dg_fo)), "s"(uni((int) f_ro_st)));
+	if (EXACT) {	// exact sums: where the row's three chains begin and end (assembler.c:171,226,236): the overlap is [A0, AF)
+		const unsigned f_pid = (unsigned) region_a0 | ((unsigned) region_af << 16);
+		asm volatile("s_mov_b32 m0, %1\n\tv_writelane_b32 %0, %2, m0" : "+v"(pd.pid) : "s"(slot_idx), "s"(uni((int) f_pid)));
+	}
 }
 
 // PHRED: a min_phred module is loaded, the merge tracks the row's smallest log-p (plugin_min_phred.c:8-22)

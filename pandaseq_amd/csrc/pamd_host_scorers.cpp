@@ -10,17 +10,18 @@
 // and are tested equal to these, record for record).  Product code, written for this library: the test-side checker is never involved.
 #include <cmath>
 #include <cstddef>
-#include <mutex>
 #include "pamd_internal.h"
 #include "pamd_host_scorers.h"
 
 namespace {
 
-const PamdTables &tabs() {
-	static PamdTables t;
-	static std::once_flag once;
-	std::call_once(once, [] { pamd_build_tables(&t); });
-	return t;
+const PamdTables &tabs() {	// (built on first use; afterwards one guard-byte test per call)
+	static const PamdTables *const t = [] {
+		PamdTables *p = new PamdTables;
+		pamd_build_tables(p);
+		return p;
+	}();
+	return *t;
 }
 
 inline int clampq(int q) {	// PHREDCLAMP, prob.h:23

@@ -11,14 +11,17 @@
  *          many   pamd_compat_assemble_many() over all pairs at once (the device)
  *   options: -p <forward primer> -q <reverse primer> (one hex digit per base: the panda_nt code) -a (primers after assembly)
  *            -t <threshold> -o <minimum overlap> -O <maximum overlap> -T <primer penalty> -m <module spec, e.g. min_phred:4>
+ *            -r <passes> (host / pair: that many untimed-output passes over the pairs first, every base read; prints pairs/s to stderr)
  *   out.bin: per pair: u32 returned?, then (if returned) u32 index, overlap, seq_len, mism, degen, fo, ro, examined, f64 quality,
  *            f64 est, seq_len nt bytes, seq_len f64 -- test_compat.c's record; then 10 i64: count, ok, noalgn, lowq, badr, slow,
  *            nofp, norp, longest overlap, rejected by the first module
  */
+#define _POSIX_C_SOURCE 199309L
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "pandaseq_amd_compat.h"
 
 PandaAssembler pamd_compat_host_only_assembler_new(void);	/* test hook of libpandaseq_amd (pamd_compat.cpp) */
@@ -93,6 +96,7 @@ int main(int argc, char **argv) {
 		algo = panda_algorithm_simple_bayes_new();
 	panda_assembler_set_algorithm(a, algo);
 	panda_algorithm_unref(algo);
+	int passes = 0;
 	for (int i = 5; i < argc; i++) {
 		const char *o = argv[i];
 		if (strcmp(o, "-a") == 0) {
@@ -113,6 +117,8 @@ int main(int argc, char **argv) {
 			panda_assembler_set_minimum_overlap(a, atoi(v));
 		else if (strcmp(o, "-O") == 0)
 			panda_assembler_set_maximum_overlap(a, atoi(v));
+		else if (strcmp(o, "-r") == 0)
+			passes = atoi(v);
 		else if (strcmp(o, "-T") == 0)
 			panda_assembler_set_primer_penalty(a, atof(v));
 		else if (strcmp(o, "-m") == 0) {
@@ -142,6 +148,29 @@ int main(int argc, char **argv) {
 		}
 		pamd_compat_assemble_many(a, ids, f, fl, r, rl, n, visit, NULL);
 	} else {
+		if (passes > 0) {	/* the rate of the per-pair path, every merged base read (no output) */
+			struct timespec t0, t1;
+			double sum = 0;
+			clock_gettime(CLOCK_MONOTONIC, &t0);
+			for (int pass = 0; pass < passes; pass++)
+				for (uint32_t i = 0; i < n; i++) {
+					unsigned char *p = blob + (size_t) i * rec;
+					uint16_t fl, rl;
+					memcpy(&fl, p, 2);
+					memcpy(&rl, p + 2, 2);
+					panda_seq_identifier id;
+					memset(&id, 0, sizeof id);
+					id.x = (int) i;
+					const panda_result_seq *res = panda_assembler_assemble(a, &id, (const panda_qual *) (p + 4), fl, (const panda_qual *) (p + 4 + (size_t) stride * 2), rl);
+					if (res != NULL)
+						for (size_t j = 0; j < res->sequence_length; j++)
+							sum += res->sequence[j].p + res->sequence[j].nt;
+				}
+			clock_gettime(CLOCK_MONOTONIC, &t1);
+			const double sec = (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
+			fprintf(stderr, "%.0f pairs/s (%d passes over %u pairs, checksum %g)\n", (double) passes * n / sec, passes, n, sum);
+			/* (the counters below then count passes + 1 passes) */
+		}
 		for (uint32_t i = 0; i < n; i++) {
 			unsigned char *p = blob + (size_t) i * rec;
 			uint16_t fl, rl;

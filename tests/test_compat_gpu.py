@@ -97,16 +97,11 @@ def test_reference_plugin_binaries(built, tmp_path, algo, plugin, args):
     assert counters[8] == o_ctr["rejected"][0] and counters[8] > 0, "the filter must reject something for the test to mean anything"
     for g in got[:200]:
         i = g["index"]
-        if exact:
-            assert g["quality"] == o_res["quality"][i]
-        else:
-            assert abs(g["quality"] - o_res["quality"][i]) <= 1e-9
+        assert g["quality"] == o_res["quality"][i]
         if algo in ("ea_util", "stitch"):  # a device log() of a ratio of small integers (include/pandaseq_amd.h)
             assert abs(g["est"] - o_res["est_prob"][i]) <= 1e-14 * max(1.0, abs(o_res["est_prob"][i]))
-        elif exact or algo not in ("pear", "rdp_mle"):
-            assert g["est"] == o_res["est_prob"][i]
         else:
-            assert abs(g["est"] - o_res["est_prob"][i]) <= 1e-9 * max(1.0, abs(o_res["est_prob"][i]))
+            assert g["est"] == o_res["est_prob"][i]
         assert np.array_equal(g["nt"], o_nt[i, :g["seq_len"]]) and np.array_equal(g["p"], o_p[i, :g["seq_len"]])
 
 
