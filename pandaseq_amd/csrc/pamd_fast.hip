@@ -135,6 +135,7 @@ typedef __attribute__((address_space(3))) const double lds_cf64;
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(1))) double gbl_f64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) u32x4 gbl_u128;
 __device__ __forceinline__ unsigned lds_read_u16(unsigned addr) {
 	return *reinterpret_cast<lds_cu16 *>(addr);
@@ -754,12 +755,14 @@ __device__ __forceinline__ gbl_cu8 *scalar_row(const uint8_t *base, unsigned q, 
 __device__ __forceinline__ uint2 load_row(gbl_cu8 *row, unsigned row_bytes, int lane) {
 	unsigned off = (unsigned) lane * 8u;
 	off = off < row_bytes ? off : row_bytes - 8u;	// lanes past the row's end re-read its last bytes (rows are whole multiples of 16 B)
-	return *reinterpret_cast<__attribute__((address_space(1))) const uint2 *>(row + off);
+	const u32x2 v = *reinterpret_cast<__attribute__((address_space(1))) const u32x2 *>(row + off);
+	return make_uint2(v.x, v.y);
 }
 __device__ __forceinline__ uint4 load_row16(gbl_cu8 *row, unsigned row_bytes, int lane) {
 	unsigned off = (unsigned) lane * 16u;
 	off = off < row_bytes ? off : row_bytes - 16u;
-	return *reinterpret_cast<__attribute__((address_space(1))) const uint4 *>(row + off);
+	const u32x4 v = *reinterpret_cast<__attribute__((address_space(1))) const u32x4 *>(row + off);
+	return make_uint4(v.x, v.y, v.z, v.w);
 }
 template <bool LONG>
 __device__ __forceinline__ void load_pair(Carry<LONG> &c, const PamdKernelParams &P, unsigned q, int lane) {
