@@ -83,6 +83,7 @@ struct pamd_assembler {
 	uint8_t *d_primers = nullptr;
 	bool primers_dirty = true;
 	unsigned long long *d_error = nullptr;
+	bool notp_never_finite = false;	// of the table image on the device (upload_tables)
 	unsigned long long *d_phase = nullptr;
 	void *hb_ptr[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };	// pamd_assemble_host staging
 	size_t hb_cap[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -425,6 +426,10 @@ static int upload_tables(pamd_assembler *a, hipStream_t st) {
 		for (size_t i = 0; i < img.size(); i++)
 			notp[i] = (img[i] > M_LN2) ? std::log1p(-std::exp(-img[i])) : std::log(-std::expm1(-img[i]));
 		HIP_TRY(hipMemcpy(a->d_notp, notp.data(), sizeof(double) * notp.size(), hipMemcpyHostToDevice));
+		a->notp_never_finite = true;
+		for (size_t i = 0; i < (a->algo == PAMD_ALGO_RDP_MLE ? img.size() : (size_t) PAMD_LT_C); i++)
+			if (i != (size_t) PAMD_LT_ZERO && std::isfinite(notp[i]))	// (the spare slot holds 0.0 and is no base's log-p)
+				a->notp_never_finite = false;
 		// log-p -> index: open addressing over the distinct values of the image (the first index of a value wins)
 		const size_t n_image = a->algo == PAMD_ALGO_RDP_MLE ? img.size() : (size_t) PAMD_LT_C;
 		a->h_image.assign(img.begin(), img.begin() + n_image);
@@ -586,16 +591,16 @@ static int assemble_device_impl(pamd_assembler *a, const pamd_batch *b, void *st
 	}
 	// the lean kernel's primer scan (pamd_fast.hip): the primers as 2-bit codes of the reads' code streams, and what a
 	// disagreement costs at least
-	for (int which = 0; which < 2; which++) {
+	for (int which = 0; which < 3; which++) {
 		const int plen = which == 0 ? a->fprimer_len : a->rprimer_len;
 		const uint8_t *pr = a->primers + (which == 0 ? 0 : 456);
 		for (int w = 0; w < 2; w++) {
 			uint32_t code = 0, counts = 0;
 			for (int k = 0; k < 16; k++) {
 				const int x = 16 * w + k;
-				const unsigned nt = x < plen ? (pr[x] & 0xFu) : 15u;
+				const unsigned nt = x < plen ? (pr[which == 2 ? plen - 1 - x : x] & 0xFu) : 15u;	// [2]: the reverse primer read backwards
 				const unsigned c = nt == 8 ? 3u : (nt == 4 ? 2u : (nt == 2 ? 1u : 0u));	// misc.h:41
-				const unsigned stored = which == 0 ? c : (((c & 1u) << 1) | (c >> 1));	// the reverse stream swaps the two bits
+				const unsigned stored = which != 1 ? c : (((c & 1u) << 1) | (c >> 1));	// the reverse read's stream swaps the two bits
 				if (nt == 1 || nt == 2 || nt == 4 || nt == 8) {
 					code |= stored << (2 * k);
 					counts |= 2u << (2 * k);
@@ -605,6 +610,7 @@ static int assemble_device_impl(pamd_assembler *a, const pamd_batch *b, void *st
 			p.primer_codes[which].counts[w] = counts;
 		}
 	}
+	p.notp_never_finite = a->notp_never_finite ? 1 : 0;
 	p.primer_qthr = 22;
 	p.primer_err_t = a->tabs.score_err[22];
 	p.primer_inv_err_t = 1.0 / p.primer_err_t;

@@ -64,6 +64,9 @@ struct Lay<true> {
 	static constexpr unsigned F = 0, R = 640, FC = 1280, RC = 1376, PAD0 = 1472, FN = 1488, RN = 1584, PAD1 = 1680, FLAGS = 1696, T1 = 2080;
 	static constexpr unsigned NT = T1;				// merged-nt staging: up to 640 + 64 bytes
 	static constexpr unsigned CAREF = T1 + 16, CARER = T1 + 128, SCR = T1 + 256;	// primer scan: "counts" maps (96 bytes each), 512 bytes of f64 terms
+	// `-a` (POST): beside the merged nt row, the table index of every merged base's log-p (u16; 640 + 64 of them), and the merged
+	// sequence's own 2-bit code stream and "counts" map (160 bytes each + what a window reads past them)
+	static constexpr unsigned PIDX = NT + 704, MC = PIDX + 1408, MK = MC + 176, POST_END = MK + 176;
 	static constexpr int BPL = 5;
 	static constexpr int MAXLEN = 320;
 	static constexpr int NR = 10;
@@ -78,6 +81,7 @@ struct Geo {
 };
 static_assert(FK_NT % 16 == 0 && FK_T1 % 16 == 0 && FK_FLAGS % 16 == 0, "16-byte LDS accesses");
 static_assert(Lay<true>::T1 % 16 == 0 && Lay<true>::FLAGS % 16 == 0 && Lay<true>::R % 16 == 0, "16-byte LDS accesses");
+static_assert(Lay<true>::PIDX % 16 == 0 && Lay<true>::MC % 16 == 0 && Lay<true>::MK % 16 == 0 && Lay<true>::POST_END <= Geo<true, 9>::T3, "`-a` staging lies over the first two k-mer tables");
 template <int ALGO>
 __device__ __host__ constexpr int t1_bits() {
 	return ALGO == PAMD_ALGO_RDP_MLE ? 9 : 10;	// (512 slots for every scorer: measured 2 % slower on config 1)
@@ -588,6 +592,110 @@ __device__ __forceinline__ int primer_settle(const double *ltab, unsigned char *
 	return uni(besti);
 }
 
+// ---- `-a`: the primers are looked for in the MERGED sequence (assembler.c:300-333, offset.c:114-133) ----------------------
+// A merged base that agrees with the primer base adds its log-probability p, one that does not adds panda_log1mexp(p) -- which,
+// written for positive arguments and handed p <= 0, is NaN (-inf for p = 0): such an alignment's value is NaN and offset.c:72
+// never prefers it.  (pamd_fast_supports() admits `-a` only when the host has found that so for every entry of the table
+// image.)  So only alignments WITHOUT a disagreeing base can be returned: lanes are alignments again (primer_tier1 on the
+// merged sequence's own code stream), the ones without a disagreement among the primer's first sixteen bases are nearly always
+// one -- the primer itself -- or none, and that one is checked over the primer's whole length and summed.  Two or more send the
+// pair to the general kernel.
+
+// four merged bases, one nt byte each, of which the first `cnt` exist: 2-bit codes and "counts" flags (bit 2k+1: a definite
+// base; a merged N agrees with every primer base)
+__device__ __forceinline__ void pack_nt4(unsigned n4, int cnt, unsigned &codes, unsigned &care) {
+	const unsigned sel = n4 & 0x07070707u;
+	const unsigned b3 = (n4 >> 3) & 0x01010101u, m3 = (b3 << 8) - b3;
+	const unsigned lo = __builtin_amdgcn_perm(lut_word<true>(1), lut_word<true>(0), sel);
+	const unsigned hi = __builtin_amdgcn_perm(lut_word<true>(3), lut_word<true>(2), sel);
+	const unsigned r4 = (hi & m3) | (lo & ~m3);
+	const unsigned bm = (unsigned) ((0xFFFFFFFFull << (8 * cnt)) >> 32);
+	const unsigned c4 = r4 & 0x03030303u & bm, def4 = ~(r4 >> 2) & 0x01010101u & bm;
+	const unsigned cy = c4 | (c4 >> 6), dy = def4 | (def4 >> 6);
+	codes = (cy | (cy >> 12)) & 0xFFu;
+	care = ((dy | (dy >> 12)) & 0x55u) << 1;
+}
+
+// the merged row's code stream and "counts" map from its staged nt bytes: eight bases per lane, 512 per pass
+__device__ __forceinline__ void post_streams(unsigned char *wb, int seqlen, int lane) {
+	typedef Lay<true> L;
+#pragma unroll
+	for (int pass = 0; pass < 2; pass++) {
+		if (pass == 1 && seqlen <= 512)
+			break;
+		if (pass == 0 || lane < 16) {
+			const int b0 = 512 * pass + 8 * lane;
+			const uint2 v = *reinterpret_cast<const uint2 *>(wb + L::NT + b0);
+			int c0 = seqlen - b0, c1 = c0 - 4;
+			c0 = c0 < 0 ? 0 : (c0 > 4 ? 4 : c0);
+			c1 = c1 < 0 ? 0 : (c1 > 4 ? 4 : c1);
+			unsigned ca, ka, cb, kb;
+			pack_nt4(v.x, c0, ca, ka);
+			pack_nt4(v.y, c1, cb, kb);
+			reinterpret_cast<uint16_t *>(wb + L::MC)[64 * pass + lane] = (uint16_t) (ca | (cb << 8));
+			reinterpret_cast<uint16_t *>(wb + L::MK)[64 * pass + lane] = (uint16_t) (ka | (kb << 8));
+		}
+	}
+}
+
+// The alignments t = 0 .. nal-1 of a primer (codes pc0, counts map pk0: its first sixteen bases) on the merged sequence that
+// hold no disagreement there.  Returns their number (2 = two or more) and, for one, which.  skip0: alignment 0 is not one
+// (the reverse primer's alignments are counted from the sequence's end: offset.c:70-77 never judges the one that ends there)
+__device__ __forceinline__ int post_candidates(unsigned char *wb, int nal, unsigned pc0, unsigned pk0, bool skip0, int lane, int &which) {
+	typedef Lay<true> L;
+	int found = 0;
+	which = -1;
+#pragma unroll
+	for (int pass = 0; pass < 2; pass++) {
+		const int n = nal - 320 * pass;
+		if (n <= 0)
+			break;
+		int s0;
+		const unsigned packed = primer_tier1(lds_addr(wb + L::MC) + 80u * pass, lds_addr(wb + L::MK) + 80u * pass, n, lane, pc0, pk0, s0);
+		unsigned z = 0;
+#pragma unroll
+		for (int j = 0; j < 5; j++)
+			z |= ((packed >> (5 * j)) & 31u) == 0 ? 1u << j : 0u;
+		if (skip0 && pass == 0 && lane == 0)
+			z &= ~1u;
+		const u64 any = ballot(z != 0);
+		if (any == 0)
+			continue;
+		const int l = __builtin_ctzll(any);
+		const unsigned zl = (unsigned) __builtin_amdgcn_readlane((int) z, l);
+		if ((any & (any - 1)) != 0 || (zl & (zl - 1u)) != 0 || found != 0)
+			return 2;
+		found = 1;
+		which = 320 * pass + 5 * l + __builtin_ctz(zl);
+	}
+	return found;
+}
+
+// The alignment that starts at merged base s (reverse: at base s counted from the sequence's end, walking towards its start):
+// every primer base that is not N against its merged base (offset.c:79-87); a disagreement anywhere makes the value NaN, never
+// chosen: 0.  Else its value against the threshold (offset.c:59,72: both after exp(), which is monotone; a verdict closer than
+// 1e-9 is left to the general kernel: -1), s + plen + 1 when it passes.  pb: this lane's primer base (lane x: base x; N past
+// the primer's end)
+__device__ __forceinline__ int post_verdict(const double *ltab, const unsigned char *wb, int s, bool reverse, int len, int plen, unsigned pb, double thr, int lane) {
+	typedef Lay<true> L;
+	const bool on = lane < plen && pb != 15u;
+	const int at = reverse ? len - 1 - (s + lane) : s + lane;	// (inside the row for every lane below plen: s + plen <= len - 1)
+	unsigned nt = 0, idx = PAMD_LT_ZERO;
+	if (on) {
+		nt = wb[L::NT + at];
+		idx = reinterpret_cast<const uint16_t *>(wb + L::PIDX)[at];
+	}
+	if (ballot(on && (nt & pb) == 0) != 0)
+		return 0;
+	const double sum = wave_sum_any_order(ltab[idx]);	// (the spare slot of the error block holds 0.0)
+	const double n0 = (double) (s + plen + 1);
+	if (sum > (thr + 1e-9) * n0)
+		return s + plen + 1;
+	if (sum < (thr - 1e-9) * n0)
+		return 0;
+	return -1;
+}
+
 // counts over the 16 overlap positions i0 .. i0+15 of candidate `ov` (ov <= both read lengths, so every position
 // below ov exists on both reads): unknowns (an N on either side) in bits 0..9, matching bases in bits 10..
 // (algo_simple_bayes.c:40-59).  Forward bases flen-ov+i ascending; reverse bases rlen-1-i descending: the reverse words
@@ -743,37 +851,28 @@ __device__ __forceinline__ void settle(Carry<true> &c) {
 	asm volatile("" : "+v"(c.flen_v), "+v"(c.rlen_v), "+v"(c.f.x), "+v"(c.f.y), "+v"(c.f.z), "+v"(c.f.w), "+v"(c.r.x), "+v"(c.r.y), "+v"(c.r.z), "+v"(c.r.w));
 }
 
-// (the row's address is a scalar: pair index x row bytes, kept out of the vector ALU -- where the compiler otherwise folds it
-// into one 64-bit multiply-add per lane, a quarter-rate instruction -- by passing through a scalar register as an integer; the
-// load is then global_load with a scalar base and a 32-bit lane offset)
-typedef __attribute__((address_space(1))) const uint8_t gbl_cu8;
-__device__ __forceinline__ gbl_cu8 *scalar_row(const uint8_t *base, unsigned q, unsigned row_bytes) {
-	u64 a = (u64) (uintptr_t) base + (u64) q * row_bytes;
-	asm volatile("" : "+s"(a));
-	return (gbl_cu8 *) a;
-}
-__device__ __forceinline__ uint2 load_row(gbl_cu8 *row, unsigned row_bytes, int lane) {
+__device__ __forceinline__ uint2 load_row(const uint8_t *row, unsigned row_bytes, int lane) {
 	unsigned off = (unsigned) lane * 8u;
 	off = off < row_bytes ? off : row_bytes - 8u;	// lanes past the row's end re-read its last bytes (rows are whole multiples of 16 B)
-	const u32x2 v = *reinterpret_cast<__attribute__((address_space(1))) const u32x2 *>(row + off);
-	return make_uint2(v.x, v.y);
+	return *reinterpret_cast<const uint2 *>(row + off);
 }
-__device__ __forceinline__ uint4 load_row16(gbl_cu8 *row, unsigned row_bytes, int lane) {
+__device__ __forceinline__ uint4 load_row16(const uint8_t *row, unsigned row_bytes, int lane) {
 	unsigned off = (unsigned) lane * 16u;
 	off = off < row_bytes ? off : row_bytes - 16u;
-	const u32x4 v = *reinterpret_cast<__attribute__((address_space(1))) const u32x4 *>(row + off);
-	return make_uint4(v.x, v.y, v.z, v.w);
+	return *reinterpret_cast<const uint4 *>(row + off);
 }
+// (measured and not kept: the row's address made in the scalar ALU and the load given a scalar base -- the quarter-rate 64-bit
+// multiply-add per lane goes, a dozen more scalar registers spill into vector lanes, the rate does not move)
 template <bool LONG>
 __device__ __forceinline__ void load_pair(Carry<LONG> &c, const PamdKernelParams &P, unsigned q, int lane) {
 	c.flen_v = P.flen[q];
 	c.rlen_v = P.rlen[q];
 	if constexpr (LONG) {
-		c.f = load_row16(scalar_row(P.fwd, q, P.fwd_row_bytes), P.fwd_row_bytes, lane);
-		c.r = load_row16(scalar_row(P.rev, q, P.rev_row_bytes), P.rev_row_bytes, lane);
+		c.f = load_row16(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+		c.r = load_row16(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
 	} else {
-		c.f = load_row(scalar_row(P.fwd, q, P.fwd_row_bytes), P.fwd_row_bytes, lane);
-		c.r = load_row(scalar_row(P.rev, q, P.rev_row_bytes), P.rev_row_bytes, lane);
+		c.f = load_row(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+		c.r = load_row(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
 	}
 }
 
@@ -879,13 +978,15 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 
 // LONG: the geometry (Lay<LONG>).  PRIM (LONG only): primers (`-p` / `-q`, found by primer_quick) or trims are configured.
 // NARROW (short geometry only): reads of at most 192 bases seed three bases per lane, on windows of the code streams
-template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW>
+// POST (LONG only, any-order sums): `-a`, the primers are looked for in the merged sequence and cut off it
+template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW, bool POST>
 __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases) {
 	typedef Lay<LONG> L;
 	constexpr int BPL = NARROW ? 3 : L::BPL;
 	constexpr bool WINDOWS = BPL != 4;	// k-mers from unaligned words of the code streams (else from the neighbouring lanes' registers)
 	static_assert(!NARROW || !LONG, "three bases per lane belong to the short geometry");
 	static_assert(!PRIM || LONG, "primers and trims are served by the LONG geometry");
+	static_assert(!POST || (LONG && !PRIM && !EXACT), "`-a` is served by the LONG geometry, with any-order sums");
 	const auto fv = cur.f, rv = cur.r;
 	bool rotated = false;
 	int fo = 0, ro = 0;	// bases clipped from the reads' 5' ends (primers, trims): assembler.c:262-288
@@ -1565,7 +1666,12 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				if (k > 1 && 64 * (R0 + k) >= seqlen)
 					break;
 				lds_write_u8(nN + 64u * (R0 + k), ntv[k]);
-				if (lane < lim - 64 * (R0 + k)) {
+				if constexpr (POST) {
+					// (the row leaves once the primers are off it: until then it is its table indices, beside the nt bytes)
+					*reinterpret_cast<__attribute__((address_space(3))) uint16_t *>(lN + (L::PIDX - L::NT) + 2u * (unsigned) (64 * (R0 + k) + lane)) = (uint16_t) qi[k];
+					if (lane < seqlen - 64 * (R0 + k))
+						qacc += pv[k];
+				} else if (lane < lim - 64 * (R0 + k)) {
 					gP[64 * (R0 + k)] = pv[k];
 					qacc += pv[k];
 					if (PHRED) {
@@ -1598,6 +1704,125 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		wave_sync();
 		STOP(4);
 		DEBUG_DUMP(P, wb, pair, lane, 1, A, novl, Bn, mism, degen, seqlen);
+		if constexpr (POST) {
+			MARK("post-primers");
+			// ---- `-a` (assembler.c:300-333).  `quality` is the whole merge's (assembler.c:244 precedes the clipping): finished
+			// here, the LOWQ verdict guarded as everywhere
+			const double wsum = wave_sum_any_order(qacc), flen1 = (double) (seqlen + 1);
+			if (fabs(wsum - P.threshold * flen1) <= 1e-9 * flen1) {
+				note(P, 4, lane);
+				status = PAMD_ST_DEFER;
+				break;
+			}
+			qsum = wsum / flen1;
+			post_streams(wb, seqlen, lane);
+			wave_sync();
+			int fpl = P.fprimer_len, rpl = P.rprimer_len;
+			asm volatile("" : "+s"(fpl), "+s"(rpl));
+			int pfo = P.ftrim, pro = P.rtrim;
+			bool unsettled = false;
+			if (fpl > 0) {	// the forward primer from the sequence's first base on (offset.c:124-133)
+				int r = 0;
+				if (fpl <= seqlen) {	// (offset.c:55-57; alignments 0 .. seqlen - fpl - 1 are judged, offset.c:70-77)
+					int s1;
+					const int c = post_candidates(wb, seqlen - fpl, P.primer_codes[0].code[0], P.primer_codes[0].counts[0], false, lane, s1);
+					r = c == 0 ? 0 : (c == 1 ? post_verdict(ltab, wb, s1, false, seqlen, fpl, primer_bases & 0xFFu, (double) fpl * P.threshold, lane) : -1);
+				}
+				if (r < 0) {
+					unsettled = true;
+				} else if (r == 0) {
+					status = PAMD_ST_NOFP;
+					mism = degen = 0;	// (the record of such a pair carries neither, as the general kernel's)
+					break;
+				} else {
+					pfo = r - 1;
+				}
+			}
+			fo = pfo;
+			if (rpl > 0 && !unsettled) {	// the reverse primer from its last base backwards: alignment s from the end is alignment seqlen - rpl - s of the primer read backwards
+				int r = 0;
+				if (rpl <= seqlen) {
+					int t1;
+					const int c = post_candidates(wb, seqlen - rpl + 1, P.primer_codes[2].code[0], P.primer_codes[2].counts[0], true, lane, t1);
+					r = c == 0 ? 0 : (c == 1 ? post_verdict(ltab, wb, seqlen - rpl - t1, true, seqlen, rpl, (primer_bases >> 8) & 0xFFu, (double) rpl * P.threshold, lane) : -1);
+				}
+				if (r < 0) {
+					unsettled = true;
+				} else if (r == 0) {
+					status = PAMD_ST_NORP;
+					mism = degen = 0;
+					break;
+				} else {
+					pro = r - 1;
+				}
+			}
+			if (unsettled) {	// two alignments without a disagreement, or a verdict too close to the threshold: the general kernel's pair
+				note(P, 6, lane);
+				status = PAMD_ST_DEFER;
+				fo = 0;
+				break;
+			}
+			ro = pro;
+			if (seqlen <= pfo + pro) {	// assembler.c:323-327: counted as a missing forward primer
+				status = PAMD_ST_NOFP;
+				mism = degen = 0;
+				break;
+			}
+			const int out_len = seqlen - pfo - pro;
+			MARK("post-row-out");
+			// the kept bases leave: log-p from their table indices, 64 per round; nt sixteen per lane from wherever the forward
+			// primer ended (whole words of the staged row, shifted)
+			{
+				const unsigned lP = lN + (L::PIDX - L::NT) + 2u * (unsigned) (pfo + lane);
+				const int rounds = (out_len + 63) >> 6;
+				for (int r0 = 0; r0 < rounds; r0 += 4) {
+					unsigned ix[4];
+					double pv[4];
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						ix[k] = lds_read_u16(lP + 128u * (unsigned) (r0 + k)) & 0x1FFFu;	// (a round past the row's end reads what lies there: kept inside the LDS)
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						pv[k] = lds_read_f64(lT + 8u * ix[k]);
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						if (lane < out_len - 64 * (r0 + k)) {
+							if (store)
+								gP[64 * (r0 + k)] = pv[k];
+							if (PHRED) {
+								pall = min_f64(pall, pv[k]);
+								const u64 bits = (u64) __double_as_longlong(pv[k]);
+								const double above = __hiloint2double(pv[k] <= qs0 ? 0 : (int) (bits >> 32), (int) (unsigned) bits);
+								pmin = min_f64(pmin, above);
+							}
+						}
+					}
+				}
+				if (store && lane * 16 < out_len) {
+					const unsigned a = lN + (unsigned) pfo + 16u * (unsigned) lane, base = a & ~3u, sh = 8u * (a & 3u);
+					const unsigned w0 = lds_read_u32(base), w1 = lds_read_u32(base + 4u), w2 = lds_read_u32(base + 8u), w3 = lds_read_u32(base + 12u), w4 = lds_read_u32(base + 16u);
+					u32x4 o;
+					o.x = __builtin_amdgcn_alignbit(w1, w0, sh);
+					o.y = __builtin_amdgcn_alignbit(w2, w1, sh);
+					o.z = __builtin_amdgcn_alignbit(w3, w2, sh);
+					o.w = __builtin_amdgcn_alignbit(w4, w3, sh);
+					((gbl_u128 *) row_nt)[lane] = o;
+				}
+			}
+			if (PHRED) {	// the smallest phred of the KEPT bases (plugin_min_phred.c:8-22 sees the clipped sequence)
+				for (int o = 32; o > 0; o >>= 1) {
+					const double other = __shfl_xor(pmin, o);
+					pmin = other < pmin ? other : pmin;
+				}
+				phmin = result_phred(ltab + PAMD_LT_SCORE, uni_f64(pmin));
+				if (ballot(pall <= qs0) != 0 && phmin > 1)
+					phmin = 1;
+				if (out_len <= 0)
+					phmin = 127;
+			}
+			seqlen = out_len;	// what the record reports (assembler.c:328)
+			break;
+		}
 		MARK("row-out+sum");
 		// the nt row leaves LDS in 16-byte stores (rows are 16-base aligned)
 		if (store && lane * 16 < seqlen)
@@ -1651,7 +1876,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	// s_movrel, no GDS; `make asm` + grep m0 is the check after a compiler change)
 	const unsigned f_len_bo = (unsigned) seqlen | ((unsigned) (bo < 0 ? 0 : bo) << 16), f_ex_mm = (unsigned) examined | ((unsigned) mism << 16);
 	const unsigned f_dg_fo = (unsigned) degen | ((unsigned) fo << 16);
-	const unsigned f_ro_st = (unsigned) ro | ((unsigned) status << 16) | ((unsigned) slow << 24) | ((unsigned) (phmin > 63 ? 63 : phmin) << 26);
+	// (POST: bit 25, "the quality is final": finish64 does not divide it by the clipped length)
+	const unsigned f_ro_st = (unsigned) ro | ((unsigned) status << 16) | ((unsigned) slow << 24) | (POST ? 1u << 25 : 0u) | ((unsigned) (phmin > 63 ? 63 : phmin) << 26);
 	asm volatile("s_mov_b32 m0, %6\n\t"
 		     "v_writelane_b32 %0, %7, m0\n\t"
 		     "v_writelane_b32 %1, %8, m0\n\t"
@@ -1683,7 +1909,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 // (one 16-wave workgroup fills a CU's LDS: four waves per SIMD whatever the registers allow, so the compiler is told to
 // spend all 128 vector registers on scheduling instead of saving them for waves that cannot come -- 1 % on a 16 M-pair
 // launch, nothing measurable at 50 M)
-template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW>
+template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW, bool POST = false>
 __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const PamdKernelParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	double *ltab = reinterpret_cast<double *>(lds);
@@ -1705,7 +1931,7 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 	if constexpr (LONG) {
 		if (lane < 4)
 			reinterpret_cast<unsigned *>(wb + Lay<true>::PAD1)[lane] = 0xAAAAAAAAu;
-		if constexpr (PRIM)
+		if constexpr (PRIM || POST)
 			primer_bases = (lane < P.fprimer_len ? (unsigned) P.primers[lane] : 15u) | ((lane < P.rprimer_len ? (unsigned) P.primers[456 + lane] : 15u) << 8)
 				       | ((lane < 32 ? (lane < P.fprimer_len ? (unsigned) P.primers[lane] : 15u) : (lane - 32 < P.rprimer_len ? (unsigned) P.primers[456 + lane - 32] : 15u)) << 16);
 	}
@@ -1745,7 +1971,7 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 			// here, the lane number's derivatives are recomputed where they are used (an instruction or two each).
 			asm volatile("" : "+v"(lane_now));
 		}
-		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases);
+		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases);
 		MARK("loop");
 		npend++;
 		if (npend == 64) {
@@ -1770,14 +1996,27 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 }	// namespace
 
 // ---- host side: does the lean kernel serve this configuration, and its launch ---------------------------------
+// PAMD_FAST_POST: `-a`, reads of at most 320 bases (the LONG geometry), any-order sums.
 // 0: not served (the general kernel takes the launch whole); PAMD_FAST_SHORT: reads of at most 256 bases, no primers or
 // trims; PAMD_FAST_LONG: reads of at most 320 bases; PAMD_FAST_PRIM: the same with `-p` / `-q` primers (at most 24 bases, no
 // penalty) and / or trims.
 int pamd_fast_supports(const PamdKernelParams &p) {
-	if (p.post_primers || p.maxoverlap != 0)
+	if (p.maxoverlap != 0)
 		return 0;
 	if (p.n_pairs > 0x7FFFFFFFull)
 		return 0;	// 32-bit pair indices in the kernel and in the deferred list
+	if (p.post_primers) {
+		// `-a` (assembler.c:300-333): the lean scan sums only alignments without a disagreeing base, which is exact when a
+		// disagreement makes an alignment's value NaN or -inf (notp_never_finite); any-order sums only (the finish of the
+		// exact mode walks rows in HBM, which a clipped row no longer holds whole); no penalty; primers of at most 24 bases
+		if (!p.notp_never_finite || p.exact_sums || p.primer_penalty != 0.0 || p.smax > (uint32_t) Lay<true>::MAXLEN)
+			return 0;
+		if (p.fprimer_len > 24 || p.rprimer_len > 24 || p.ftrim < 0 || p.rtrim < 0 || p.ftrim > 2 * Lay<true>::MAXLEN || p.rtrim > 2 * Lay<true>::MAXLEN)
+			return 0;
+		if ((double) p.fprimer_len * p.threshold < -700.0 || (double) p.rprimer_len * p.threshold < -700.0)
+			return 0;
+		return PAMD_FAST_POST;
+	}
 	const bool clipped = p.fprimer_len > 0 || p.rprimer_len > 0 || p.ftrim != 0 || p.rtrim != 0;
 	if (clipped) {
 		if (p.smax > (uint32_t) Lay<true>::MAXLEN || p.primer_penalty != 0.0 || p.fprimer_len > 24 || p.rprimer_len > 24)
@@ -1812,8 +2051,9 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 	const bool narrow = p.smax <= 192;	// three bases per lane cover the reads
 #define FK_PICK3(A, PH, E) (narrow ? pamd_fast_kernel<A, E, PH, false, false, true> : pamd_fast_kernel<A, E, PH, false, false, false>)
 #define FK_PICK4(A, PH, E) (variant == PAMD_FAST_LONG ? pamd_fast_kernel<A, E, PH, true, false, false> : pamd_fast_kernel<A, E, PH, true, true, false>)
-#define FK_PICK2(A, PH) (variant == PAMD_FAST_SHORT ? (p.exact_sums ? FK_PICK3(A, PH, true) : FK_PICK3(A, PH, false)) \
-						    : (p.exact_sums ? FK_PICK4(A, PH, true) : FK_PICK4(A, PH, false)))
+#define FK_PICK2(A, PH) (variant == PAMD_FAST_POST ? pamd_fast_kernel<A, false, PH, true, false, false, true>                                         \
+						   : variant == PAMD_FAST_SHORT ? (p.exact_sums ? FK_PICK3(A, PH, true) : FK_PICK3(A, PH, false)) \
+										: (p.exact_sums ? FK_PICK4(A, PH, true) : FK_PICK4(A, PH, false)))
 #define FK_PICK(A) (p.has_min_phred ? FK_PICK2(A, true) : FK_PICK2(A, false))
 	switch (variant == 0 ? -1 : p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
