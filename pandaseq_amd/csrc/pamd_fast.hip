@@ -700,14 +700,15 @@ __device__ __forceinline__ int post_verdict(const double *ltab, const unsigned c
 // below ov exists on both reads): unknowns (an N on either side) in bits 0..9, matching bases in bits 10..
 // (algo_simple_bayes.c:40-59).  Forward bases flen-ov+i ascending; reverse bases rlen-1-i descending: the reverse words
 // are taken at the mirrored position and bit-reversed.  Reads outside a stream stay inside the wave's LDS and are masked.
-template <class L>
+// FNO / RNO: where the N maps lie (the read's own, or the copies scan_many_sums makes, in which a base of low quality is an N too)
+template <class L, unsigned FNO = L::FN, unsigned RNO = L::RN>
 __device__ __forceinline__ unsigned word_counts(const unsigned char *wb, int flen, int rlen, int ov, int i0, bool active) {
 	int hi = ov - i0;
 	hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
 	const unsigned valid = active ? ((unsigned) ((1ull << (2 * hi)) - 1ull) & 0x55555555u) : 0u;
 	const int fb = 2 * (flen - ov + i0), rb = 2 * (rlen - 16 - i0);
-	const uint32_t *fcw = reinterpret_cast<const uint32_t *>(wb + L::FC) + (fb >> 5), *fnw = reinterpret_cast<const uint32_t *>(wb + L::FN) + (fb >> 5);
-	const uint32_t *rcw = reinterpret_cast<const uint32_t *>(wb + L::RC) + (rb >> 5), *rnw = reinterpret_cast<const uint32_t *>(wb + L::RN) + (rb >> 5);
+	const uint32_t *fcw = reinterpret_cast<const uint32_t *>(wb + L::FC) + (fb >> 5), *fnw = reinterpret_cast<const uint32_t *>(wb + FNO) + (fb >> 5);
+	const uint32_t *rcw = reinterpret_cast<const uint32_t *>(wb + L::RC) + (rb >> 5), *rnw = reinterpret_cast<const uint32_t *>(wb + RNO) + (rb >> 5);
 	const unsigned fc0 = fcw[0], fc1 = fcw[1], fn0 = fnw[0], fn1 = fnw[1];
 	const unsigned rc0 = rcw[0], rc1 = rcw[1], rn0 = rnw[0], rn1 = rnw[1];
 	const unsigned f = __builtin_amdgcn_alignbit(fc1, fc0, (unsigned) fb & 31u);
@@ -813,6 +814,197 @@ __device__ __attribute__((noinline)) ManyResult scan_many(unsigned char *wb, int
 	if (pr > best) {	// strict, as every step of the ascending scan is
 		out.best = pr;
 		out.bo = bov;
+	}
+	return out;
+}
+
+// ---- pear / rdp_mle: one overlap's score, a sum of per-base table values (algo_pear.c:32-59, algo_rdp_mle.c:43-74) ------------
+// This lane's share of the terms of candidate `ov`: positions lane, lane + 64, ...; added up in any order by the caller.
+template <int ALGO, class L>
+__device__ __forceinline__ double score_share(const unsigned char *wb, const double *ltab, int flen, int rlen, int ov, double nrb, double nn, int lane) {
+	const unsigned lF = lds_addr(wb + L::F), lR = lds_addr(wb + L::R), lT = lds_addr(ltab);
+	double part = 0.0;
+#pragma unroll
+	for (int r = 0; r < L::SR; r++) {
+		const int i = 64 * r + lane;
+		if (64 * r < ov && i < ov) {
+			const int fi = flen - ov + i, ri = rlen - 1 - i;
+			const unsigned ef = lds_read_u16(lF + 2u * (unsigned) fi), er = lds_read_u16(lR + 2u * (unsigned) ri);
+			const unsigned a = ef & 0xFFu, b = er & 0xFFu, qa = ef >> 8;
+			const unsigned base = (a & b) != 0 ? PAMD_LT_A : PAMD_LT_B;
+			if (ALGO == PAMD_ALGO_PEAR) {
+				// the second index is the FORWARD read's quality at the reverse index (algo_pear.c:52,54, sic); past the forward
+				// read the reference reads beyond the array: defined as quality 0 here
+				const unsigned qb = ri < flen ? lds_read_u16(lF + 2u * (unsigned) ri) >> 8 : 0u;
+				part += (a == 15u || b == 15u) ? nrb : lds_read_f64(lT + 8u * (base + qa * PAMD_NQ + qb));
+			} else {
+				part += lds_read_f64(lT + 8u * (base + qa * PAMD_NQ + (er >> 8))) - nn;
+			}
+		}
+	}
+	return part;
+}
+
+// ---- pear / rdp_mle pairs with MANY candidates: no seeded overlap (every overlap is one) or tandem repeats -------------------
+// Walking every candidate costs what the reference pays for such a pair (it counts them as "slow").  Most need not be walked:
+// from three counts per candidate -- positions with an N or a base of quality below PAMD_STRONG_Q on either side, agreeing and
+// disagreeing bases among the rest, taken sixteen positions per step from the 2-bit code streams like the counting scorers'
+// scores -- and three maxima over the scorer's tables (PamdKernelParams::many_*) a candidate's score is bounded from above.
+// Candidates are scored best bound first, each by the whole wave (its terms added in any order, |error| < 1e-9), until no
+// bound reaches the best score found: what was not scored can neither win nor tie.  A comparison between two scored
+// candidates closer than 1e-6 is left to the general kernel, which adds in the reference's order (`ambiguous`).
+// Every lane holds up to NC candidates (as scan_many deals them: a short one travels with a long one).
+struct ManySums {
+	double best;
+	int bo, examined, ambiguous;
+};
+
+template <int ALGO, bool LONG>
+__device__ __attribute__((noinline)) ManySums scan_many_sums(unsigned char *wb, const double *ltab, int all, int size, int minov, int flen, int rlen, double nrb, double nn, double many_all, double many_match, double many_strong, double best, int lane) {
+	typedef Lay<LONG> L;
+	constexpr int NC = LONG ? 5 : 4;	// candidates per lane: 256, or 320
+	constexpr unsigned LIST = L::T1, FNQ = L::T1 + 640 + 16, RNQ = FNQ + (LONG ? 96 : 64) + 16;	// (a pad word before either map, as before the reads' own)
+	static_assert(RNQ + 96 + 16 <= L::T1 + 2048, "inside the first k-mer table");
+	uint16_t *list = reinterpret_cast<uint16_t *>(wb + LIST);	// overlap - minov of every candidate, ascending (where the k-mer tables were)
+	int total = size;
+	// the candidates, listed
+	if (!all) {
+		total = 0;
+#pragma unroll
+		for (int w = 0; w < (LONG ? 2 : 1); w++) {
+			const unsigned mine = (w == 0 || lane < 32) ? reinterpret_cast<const unsigned *>(wb + L::FLAGS + 256 * w)[lane] : 0u;	// flag bytes are 0 or 1
+			const unsigned c = (mine * 0x01010101u) >> 24;
+			unsigned before = 0;
+			int here = 0;
+#pragma unroll
+			for (int b = 0; b < 3; b++) {
+				const u64 m = ballot(((c >> b) & 1u) != 0);
+				before += (unsigned) __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u)) << b;
+				here += __popcll(m) << b;
+			}
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				if ((mine >> (8 * k)) & 1u) {
+					list[total + before] = (uint16_t) (256 * w + 4 * lane + k);
+					before++;
+				}
+			}
+			total += here;
+		}
+	}
+	// the N maps with the bases of low quality added: the forward read's from its own qualities; the reverse read's from its
+	// own (rdp_mle), or from the FORWARD read's at the same index (pear looks its second quality up there, algo_pear.c:52,54;
+	// 0 past that read)
+	{
+		constexpr unsigned QADD = (unsigned) (0x80 - PAMD_STRONG_Q) * 0x01010101u;
+		auto low4 = [&](unsigned x, unsigned y) -> unsigned {	// bit 2k: quality of base k (of the four in x, y) below PAMD_STRONG_Q
+			const unsigned q4 = __builtin_amdgcn_perm(y, x, 0x07050301u);
+			const unsigned lowq = ~(((q4 & 0x7F7F7F7Fu) + QADD) >> 7) & 0x01010101u;
+			const unsigned yb = lowq | (lowq >> 6);
+			return (yb | (yb >> 12)) & 0x55u;
+		};
+		if constexpr (LONG) {
+			if (lane < 48) {
+				const uint4 f = lane < 40 ? reinterpret_cast<const uint4 *>(wb + L::F)[lane] : make_uint4(0u, 0u, 0u, 0u);
+				const uint4 r = lane < 40 ? reinterpret_cast<const uint4 *>(wb + L::R)[lane] : make_uint4(0u, 0u, 0u, 0u);
+				const unsigned lf = low4(f.x, f.y) | (low4(f.z, f.w) << 8);
+				unsigned lr = low4(r.x, r.y) | (low4(r.z, r.w) << 8);
+				if (ALGO == PAMD_ALGO_PEAR) {
+					int c8 = flen - 8 * lane;
+					c8 = c8 < 0 ? 0 : (c8 > 8 ? 8 : c8);
+					lr = lf | (~((1u << (2 * c8)) - 1u) & 0x5555u);
+				}
+				reinterpret_cast<uint16_t *>(wb + FNQ)[lane] = (uint16_t) (reinterpret_cast<const uint16_t *>(wb + L::FN)[lane] | lf);
+				reinterpret_cast<uint16_t *>(wb + RNQ)[lane] = (uint16_t) (reinterpret_cast<const uint16_t *>(wb + L::RN)[lane] | (lr << 1));
+			}
+		} else {
+			const uint2 f = reinterpret_cast<const uint2 *>(wb + L::F)[lane], r = reinterpret_cast<const uint2 *>(wb + L::R)[lane];
+			const unsigned lf = low4(f.x, f.y);
+			unsigned lr = low4(r.x, r.y);
+			if (ALGO == PAMD_ALGO_PEAR) {
+				int c4 = flen - 4 * lane;
+				c4 = c4 < 0 ? 0 : (c4 > 4 ? 4 : c4);
+				lr = lf | (~((1u << (2 * c4)) - 1u) & 0x55u);
+			}
+			wb[FNQ + lane] = (unsigned char) (wb[L::FN + lane] | lf);
+			wb[RNQ + lane] = (unsigned char) (wb[L::RN + lane] | (lr << 1));
+		}
+		if (lane < 4) {	// what lies before a map reads as N, what lies behind it too (the reads' own maps end that way)
+			reinterpret_cast<unsigned *>(wb + FNQ - 16)[lane] = 0x55555555u;
+			reinterpret_cast<unsigned *>(wb + RNQ - 16)[lane] = 0xAAAAAAAAu;
+			reinterpret_cast<unsigned *>(wb + RNQ + (LONG ? 96 : 64))[lane] = 0xAAAAAAAAu;
+		}
+	}
+	wave_sync();
+	// this lane's candidates and the bounds of their scores
+	int ov[NC];
+	double bound[NC];
+#pragma unroll
+	for (int k = 0; k < NC; k++) {
+		const int c = k == 0 ? lane : (k == 1 ? 127 - lane : (k == 2 ? 128 + lane : (k == 3 ? 255 - lane : 256 + lane)));
+		const int idx = all ? c : (int) list[c < total ? c : 0];
+		ov[k] = c < total ? idx + minov : 0;
+	}
+#pragma unroll
+	for (int k = 0; k < NC; k++) {
+		// (lanes finish together: the k-th candidates of all lanes are walked in lockstep, to the longest of them)
+		int steps = (ov[k] + 15) >> 4;
+		for (int o = 32; o > 0; o >>= 1) {
+			const int other = __shfl_xor(steps, o);
+			steps = other > steps ? other : steps;
+		}
+		steps = uni(steps);
+		unsigned acc = 0;
+		for (int st = 0; st < steps; st++)
+			acc += word_counts<L, FNQ, RNQ>(wb, flen, rlen, ov[k], 16 * st, 16 * st < ov[k]);
+		const int unknowns = (int) (acc & 1023u), matches = (int) (acc >> 10);
+		bound[k] = ov[k] != 0 ? (double) unknowns * many_all + (double) matches * many_match + (double) (ov[k] - unknowns - matches) * many_strong : -__builtin_inf();
+	}
+	// best bound first
+	ManySums out;
+	out.best = best;
+	out.bo = -1;
+	out.examined = total;
+	out.ambiguous = 0;
+	for (;;) {
+		double b = bound[0];
+		int which = 0;
+#pragma unroll
+		for (int k = 1; k < NC; k++) {
+			if (bound[k] > b) {
+				b = bound[k];
+				which = k;
+			}
+		}
+		int o = ov[0];
+#pragma unroll
+		for (int k = 1; k < NC; k++)
+			o = which == k ? ov[k] : o;
+		// the wave's best: the largest bound (the smaller overlap among equal bounds, so that the order is fixed)
+		double wbnd = b;
+		int wov = b > -__builtin_inf() ? o : 0x7FFFFFFF;
+		for (int off = 32; off > 0; off >>= 1) {
+			const double ob = __shfl_xor(wbnd, off);
+			const int oo = __shfl_xor(wov, off);
+			if (ob > wbnd || (ob == wbnd && oo < wov)) {
+				wbnd = ob;
+				wov = oo;
+			}
+		}
+		wbnd = uni_f64(wbnd);
+		wov = uni(wov);
+		if (wov == 0x7FFFFFFF || wbnd < out.best - 1e-6)
+			break;	// nothing left, or nothing left that could reach the best score
+		const double pr = wave_sum_any_order(score_share<ALGO, L>(wb, ltab, flen, rlen, wov, nrb, nn, lane));
+		if (pr > out.best + 1e-6) {
+			out.best = pr;
+			out.bo = wov;
+		} else if (!(pr < out.best - 1e-6)) {
+			out.ambiguous = 1;
+		}
+#pragma unroll
+		for (int k = 0; k < NC; k++)
+			bound[k] = ov[k] == wov ? -__builtin_inf() : bound[k];
 	}
 	return out;
 }
@@ -1363,18 +1555,35 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			// algo_rdp_mle.c:43-74).  Lanes produce the terms.  Exact sums: lane 0 adds them in the reference's order.
 			// Any-order sums: every lane adds its own, the wave adds the lanes (|error| < 1e-9), and a comparison closer
 			// than 1e-6 -- or a min_overlapbits verdict that close -- sends the pair to the general kernel, which sums in
-			// reference order.  Pairs with many candidates go there too (a candidate per lane, each summed in order).
+			// reference order.
+			const double nrb = -P.pear_random_base, nn = P.qual_nn;
+			bool ambiguous = false;
+			int nloop = ncand;	// candidates the loop below scores
 			if (all || ncand > 4) {
-				note(P, 3, lane);
-				status = PAMD_ST_DEFER;
-				break;
+				// ---- many candidates (no seeded overlap, tandem repeats): scored best bound first (scan_many_sums) ----
+				const ManySums ms = scan_many_sums<ALGO, LONG>(wb, ltab, all ? 1 : 0, size, minov, flen, rlen, nrb, nn, P.many_all, P.many_match, P.many_strong, best, lane);
+				ncand = uni(ms.examined);
+				if (uni(ms.ambiguous) != 0) {
+					note(P, 2, lane);
+					status = PAMD_ST_DEFER;
+					break;
+				}
+				nloop = 0;
+				if (uni(ms.bo) >= 0) {
+					if (EXACT) {	// the winner's score once more, its terms added in the reference's order
+						ov0 = uni(ms.bo);
+						nloop = 1;
+					} else {
+						best = uni_f64(ms.best);
+						bo = uni(ms.bo);
+					}
+				}
+				wave_sync();
 			}
 			const unsigned lF = lds_addr(wb + L::F), lR = lds_addr(wb + L::R), lT = lds_addr(ltab);
 			double *const ps = reinterpret_cast<double *>(wb + L::T1);	// the terms of one candidate, where the k-mer tables were
 			deep_dirty = deep_dirty || EXACT;
-			const double nrb = -P.pear_random_base, nn = P.qual_nn;
-			bool ambiguous = false;
-			for (int c = 0; c < ncand; c++) {
+			for (int c = 0; c < nloop; c++) {
 				const int ov = c == 0 ? ov0 : (c == 1 ? ov1 : (c == 2 ? ov2 : ov3));
 				double part = 0.0;
 #pragma unroll
@@ -1964,7 +2173,7 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 		load_pair<LONG>(nxt, P, q, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
 		int lane_now = lane;
-		if constexpr (LONG || ALGO == PAMD_ALGO_EA_UTIL || ALGO == PAMD_ALGO_STITCH) {	// (the two table-scored counting scorers spill in the short geometry too)
+		if constexpr (LONG || ALGO == PAMD_ALGO_EA_UTIL || ALGO == PAMD_ALGO_STITCH || !counting_algo<ALGO>()) {	// (the two table-scored counting scorers spill in the short geometry too; so do pear and rdp_mle, whose many-candidate scan is a call the hot path's registers have to survive)
 			// The compiler hoists everything that depends on the lane number alone out of this loop -- multiples, shifts,
 			// LDS addresses -- and, out of registers, spills it: a reload from scratch memory then waits, vmcnt being one
 			// in-order queue, for whatever went before it, the rows just requested for the next pair among them.  Made opaque
