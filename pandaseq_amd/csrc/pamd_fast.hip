@@ -1198,7 +1198,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	uint8_t *const nts = wb + L::NT;
 
 	do {
-		if (flen < 2 || rlen < 2) {	// assembler.c:255-258
+		if (__builtin_expect(flen < 2 || rlen < 2, 0)) {	// assembler.c:255-258
 			status = PAMD_ST_BADR;
 			break;
 		}
@@ -1225,7 +1225,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			uf = stage<true>(fv, flen, lane, wb, fcodes, fnm, weird);
 			ur = stage<false>(rv, rlen, lane, wb, rcodes, rnm, weird);
 		}
-		if (ballot(weird != 0) != 0) {	// an IUPAC ambiguity code, nt 0, a quality outside 0..46: the general kernel's pair
+		if (__builtin_expect(ballot(weird != 0) != 0, 0)) {	// an IUPAC ambiguity code, nt 0, a quality outside 0..46: the general kernel's pair
 			note(P, 0, lane);
 			status = PAMD_ST_DEFER;
 			break;
@@ -1391,7 +1391,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			if (deep)
 				note(P, 5, lane);	// (two pairs in three: far too many same-address atomics for a shipped build)
 #endif
-			if (lost) {	// a k-mer found no slot (tandem repeats do this): the general kernel's unbounded table
+			if (__builtin_expect(lost, 0)) {	// a k-mer found no slot (tandem repeats do this): the general kernel's unbounded table
 				note(P, 1, lane);
 				status = PAMD_ST_DEFER;
 				break;
@@ -1458,20 +1458,20 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			const bool twice = ballot(second) != 0;	// a k-mer that occurs twice in the forward read
 			// Nearly every pair's k-mers vote for one overlap, or for that and a stray one: settled here in registers, the
 			// candidates need neither the flag bytes nor the walk over them.
-			if (!twice) {
+			if (__builtin_expect(!twice, 1)) {
 				unsigned mine = EMPTY;
 #pragma unroll
 				for (int j = BPL - 1; j >= 0; j--)
 					mine = idx1[j] != EMPTY ? idx1[j] : mine;
 				const u64 have = ballot(mine != EMPTY);
-				if (have != 0) {
+				if (__builtin_expect(have != 0, 1)) {
 					const unsigned c0 = (unsigned) __builtin_amdgcn_readlane((int) mine, __builtin_ctzll(have));
 					unsigned other = EMPTY;
 #pragma unroll
 					for (int j = 0; j < BPL; j++)
 						other = (idx1[j] != EMPTY && idx1[j] != c0) ? idx1[j] : other;
 					const u64 oth = ballot(other != EMPTY);
-					if (oth == 0) {
+					if (__builtin_expect(oth == 0, 1)) {
 						ncand = 1;
 						ov0 = (int) c0 + minov;
 						quick = true;
@@ -1490,7 +1490,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 					}
 				}
 			}
-			if (!quick) {
+			if (__builtin_expect(!quick, 0)) {
 #pragma unroll
 				for (int j = 0; j < BPL; j++)
 					if (idx1[j] != EMPTY)
@@ -1509,7 +1509,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		MARK("candidates");
 
 		// ---- the candidates (assembler.c:118-143) ----
-		if (!quick) {
+		if (__builtin_expect(!quick, 0)) {
 			wave_sync();
 			const unsigned mine = reinterpret_cast<const unsigned *>(flags)[lane];	// overlaps minov + 4*lane + 0..3
 			// (kept as scalar selects: indexed by ncand the four overlaps would live in scratch memory)
@@ -1661,7 +1661,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			note(P, 3, lane);
 			status = PAMD_ST_DEFER;
 			break;
-		} else if (!LONG && (all || ncand > 4)) {
+		} else if (!LONG && __builtin_expect(all || ncand > 4, 0)) {
 			// ---- pairs without a seeded overlap, tandem repeats: a candidate per lane (three pairs in a hundred) ----
 			const ManyResult mr = scan_many<ALGO>(wb, all ? 1 : 0, size, minov, flen, rlen, P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.count_table, best, lane);
 			best = uni_f64(mr.best);	// a function's results come back in vector registers
@@ -1683,13 +1683,21 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x121, 0xF, 0xF, false);	// row_ror:1
 			const int unknowns = (int) (packed & 1023u), matches = (int) (packed >> 10);
 			const double sc = count_score<ALGO, true>(P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.count_table, flen, rlen, myov, unknowns, matches, myov);
+			if (__builtin_expect(ncand == 1, 1)) {	// (nine pairs in ten: one compare, no walk over the rows)
+				const double pr = lane_f64(sc, 0);
+				if (pr > best) {
+					best = pr;
+					bo = ov0;
+				}
+			} else {
 #pragma unroll
-			for (int r = 0; r < 4; r++) {
-				if (r < ncand) {
-					const double pr = lane_f64(sc, 16 * r);
-					if (pr > best) {	// strict: the ascending scan keeps the smallest overlap on ties
-						best = pr;
-						bo = r == 0 ? ov0 : (r == 1 ? ov1 : (r == 2 ? ov2 : ov3));
+				for (int r = 0; r < 4; r++) {
+					if (r < ncand) {
+						const double pr = lane_f64(sc, 16 * r);
+						if (pr > best) {	// strict: the ascending scan keeps the smallest overlap on ties
+							best = pr;
+							bo = r == 0 ? ov0 : (r == 1 ? ov1 : (r == 2 ? ov2 : ov3));
+						}
 					}
 				}
 			}
@@ -1700,7 +1708,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		examined = ncand;
 		slow = examined == size;	// assembler.c:135
 		DEBUG_DUMP(P, wb, pair, lane, 2, uf, ur, ncand, ov0, ov1, bo);
-		if (bo < 0) {
+		if (__builtin_expect(bo < 0, 0)) {
 			status = PAMD_ST_NOALGN;
 			best = 0.0;	// (the record of a pair that did not align carries no score, as in the general kernel)
 			break;
@@ -1751,7 +1759,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		if (k_stride != 0) {
 			off = pair * k_stride;
 		} else {
-			if (arena.cur + need > arena.end) {
+			if (__builtin_expect(arena.cur + need > arena.end, 0)) {
 				u64 got = 0;
 				if (lane == 0)
 					got = atomicAdd(P.seq_cursor, P.arena_chunk);
@@ -2053,7 +2061,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			qsum = wave_sum_any_order(qacc);	// divided by len in finish64() ...
 			// ... unless the quotient could land within 1e-9 of the LOWQ threshold (tested without dividing): the general
 			// kernel then makes the three sums in reference order (assembler.c:171,226,236,244,334)
-			if (fabs(qsum - P.threshold * (double) (seqlen + 1)) <= 1e-9 * (double) (seqlen + 1)) {
+			if (__builtin_expect(fabs(qsum - P.threshold * (double) (seqlen + 1)) <= 1e-9 * (double) (seqlen + 1), 0)) {
 				note(P, 4, lane);
 				status = PAMD_ST_DEFER;	// (its row stays behind in the arena as a hole)
 				break;

@@ -307,6 +307,11 @@ def test_one_assembler_per_thread(built, tmp_path):
     for threads in (1, 2, 5):
         out = subprocess.check_output([exe, str(pin), str(threads)], timeout=300)
         assert [int(x) for x in out.split()] == want, (threads, out)
+    # PAMD_DEVICES: the assemblers of a process are dealt over the listed GPUs in turn (here the one GPU twice: the code path
+    # of a multi-GPU embedder).  The reference never sums its workers' STAT counters (pool.c:86-104 prints each thread's block);
+    # the client sums the getters of its assemblers, and that sum is one assembler's over all the pairs.
+    out = subprocess.check_output([exe, str(pin), "2"], timeout=300, env=dict(os.environ, PAMD_DEVICES="0,0"))
+    assert [int(x) for x in out.split()] == want, out
 
 
 def test_fused_modules_after_a_host_module(built, tmp_path):

@@ -38,6 +38,8 @@ def run(args):
     import torch
 
     import bench
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_next
     import pandaseq_amd as pa
     from pandaseq_amd import synth, textio
 
@@ -47,7 +49,7 @@ def run(args):
     stride = spec.row_stride()
     # the text: a 250k-pair rendering of the config's synthetic pairs, repeated (names repeat; parsing does not care)
     base_n = min(args.pairs, 250_000)
-    f, r, fl, rl = synth.generate_numpy(spec, 0, base_n)
+    f, r, fl, rl = bench_next.synth_pairs(spec, base_n)
     ft, rt = synth.render_fastq(f, r, fl, rl)
     reps = max(1, args.pairs // base_n)
     n = base_n * reps

@@ -29,6 +29,8 @@ def main():
     import torch
 
     import bench
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_next
     import pandaseq_amd as pa
     from pandaseq_amd import synth, textio
 
@@ -36,7 +38,7 @@ def main():
     spec = synth.config_spec(args.config)
     stride = spec.row_stride()
     base_n = min(args.pairs_per_chunk, 250_000)
-    f, r, fl, rl = synth.generate_numpy(spec, 0, base_n)
+    f, r, fl, rl = bench_next.synth_pairs(spec, base_n)
     ft, rt = synth.render_fastq(f, r, fl, rl)
     reps = max(1, args.pairs_per_chunk // base_n)
     n = base_n * reps
