@@ -1369,19 +1369,40 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				insert_all<BPL>(addr, carry);
 			}
 			bool lost = false;
+			// What found no slot in the first two tables -- a word or two, two pairs in three -- goes on to the last two, all of a
+			// lane's words under ONE test and with one round trip per level (the words of one lane used to go one after the other,
+			// each with its own test and its own two round trips).
+			{
+				bool left = false;
 #pragma unroll
-			for (int j = 0; j < BPL; j++) {
-				if (ballot(carry[j] != EMPTY) != 0) {	// rare from here on: one or two words per pair
+				for (int j = 0; j < BPL; j++)
+					left |= carry[j] != EMPTY;
+				if (ballot(left) != 0) {
 					deep = true;
-					carry[j] = insert_level(t3, slot3(carry[j] >> 16), carry[j]);
-					carry[j] = insert_level(t4, slot4(carry[j] >> 16), carry[j]);
-					if (ballot(carry[j] != EMPTY) != 0) {
+					unsigned addr[BPL];
+					const unsigned l3 = lds_addr(t3), l4 = lds_addr(t4);
+#pragma unroll
+					for (int j = 0; j < BPL; j++)
+						addr[j] = l3 + 4u * slot3(carry[j] >> 16);
+					insert_all<BPL>(addr, carry);
+#pragma unroll
+					for (int j = 0; j < BPL; j++)
+						addr[j] = l4 + 4u * slot4(carry[j] >> 16);
+					insert_all<BPL>(addr, carry);
+					left = false;
+#pragma unroll
+					for (int j = 0; j < BPL; j++)
+						left |= carry[j] != EMPTY;
+					if (__builtin_expect(ballot(left) != 0, 0)) {
 						// A word found no slot.  The words of one k-mer that did are always its smallest positions (a slot
 						// keeps its minimum), so a k-mer with two of them in the tables loses nothing the reference keeps
 						// (assembler.c:94-99 drops a third position as well): tandem repeats pass here.
-						const unsigned k = carry[j] >> 16, kk = carry[j] & 0xFFFF0000u;
-						const int kept = (int) ((t1[slot1<T1B>(k)] ^ kk) < 0x10000u) + (int) ((t2[slot2(k)] ^ kk) < 0x10000u) + (int) ((t3[slot3(k)] ^ kk) < 0x10000u) + (int) ((t4[slot4(k)] ^ kk) < 0x10000u);
-						lost |= ballot(carry[j] != EMPTY && kept < 2) != 0;
+#pragma unroll
+						for (int j = 0; j < BPL; j++) {
+							const unsigned k = carry[j] >> 16, kk = carry[j] & 0xFFFF0000u;
+							const int kept = (int) ((t1[slot1<T1B>(k)] ^ kk) < 0x10000u) + (int) ((t2[slot2(k)] ^ kk) < 0x10000u) + (int) ((t3[slot3(k)] ^ kk) < 0x10000u) + (int) ((t4[slot4(k)] ^ kk) < 0x10000u);
+							lost |= ballot(carry[j] != EMPTY && kept < 2) != 0;
+						}
 					}
 				}
 			}
