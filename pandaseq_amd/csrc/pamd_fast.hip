@@ -1314,10 +1314,15 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			wave_sync();	// the scan's streams and scratch lie where the k-mer tables are cleared now
 		}
 		{	// clear the k-mer tables and the candidate flags
-			const unsigned n16 = (deep_dirty ? G::WAVE_BYTES - L::T1 : G::T3 - L::T1) / 16u;
-			uint4 *h = reinterpret_cast<uint4 *>(wb + L::T1);
-			for (unsigned s = lane; s < n16; s += 64)
-				h[s] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+			// (the first two tables are whole kilobytes: straight-line stores, no loop counter; the last two, 384 bytes, only
+			// when the previous pair used them)
+			static_assert((G::T3 - L::T1) % 1024u == 0 && (G::WAVE_BYTES - G::T3) / 16u <= 64u, "whole rounds of 64 lanes x 16 bytes");
+			uint4 *h = reinterpret_cast<uint4 *>(wb + L::T1) + lane;
+#pragma unroll
+			for (unsigned i = 0; i < (G::T3 - L::T1) / 1024u; i++)
+				h[64u * i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+			if (deep_dirty && lane < (int) ((G::WAVE_BYTES - G::T3) / 16u))
+				reinterpret_cast<uint4 *>(wb + G::T3)[lane] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
 			if (lane < (LONG ? 24 : 16))
 				reinterpret_cast<uint4 *>(flags)[lane] = make_uint4(0u, 0u, 0u, 0u);
 			deep_dirty = false;
@@ -1369,40 +1374,21 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				insert_all<BPL>(addr, carry);
 			}
 			bool lost = false;
-			// What found no slot in the first two tables -- a word or two, two pairs in three -- goes on to the last two, all of a
-			// lane's words under ONE test and with one round trip per level (the words of one lane used to go one after the other,
-			// each with its own test and its own two round trips).
-			{
-				bool left = false;
 #pragma unroll
-				for (int j = 0; j < BPL; j++)
-					left |= carry[j] != EMPTY;
-				if (ballot(left) != 0) {
+			for (int j = 0; j < BPL; j++) {
+				// (measured and not kept, round 4: all of a lane's words sent through the last two tables under one test, one
+				// round trip per level -- every pair that needs them for one word then pays the issue for four: -2.5 %)
+				if (ballot(carry[j] != EMPTY) != 0) {	// rare from here on: one or two words per pair
 					deep = true;
-					unsigned addr[BPL];
-					const unsigned l3 = lds_addr(t3), l4 = lds_addr(t4);
-#pragma unroll
-					for (int j = 0; j < BPL; j++)
-						addr[j] = l3 + 4u * slot3(carry[j] >> 16);
-					insert_all<BPL>(addr, carry);
-#pragma unroll
-					for (int j = 0; j < BPL; j++)
-						addr[j] = l4 + 4u * slot4(carry[j] >> 16);
-					insert_all<BPL>(addr, carry);
-					left = false;
-#pragma unroll
-					for (int j = 0; j < BPL; j++)
-						left |= carry[j] != EMPTY;
-					if (__builtin_expect(ballot(left) != 0, 0)) {
+					carry[j] = insert_level(t3, slot3(carry[j] >> 16), carry[j]);
+					carry[j] = insert_level(t4, slot4(carry[j] >> 16), carry[j]);
+					if (ballot(carry[j] != EMPTY) != 0) {
 						// A word found no slot.  The words of one k-mer that did are always its smallest positions (a slot
 						// keeps its minimum), so a k-mer with two of them in the tables loses nothing the reference keeps
 						// (assembler.c:94-99 drops a third position as well): tandem repeats pass here.
-#pragma unroll
-						for (int j = 0; j < BPL; j++) {
-							const unsigned k = carry[j] >> 16, kk = carry[j] & 0xFFFF0000u;
-							const int kept = (int) ((t1[slot1<T1B>(k)] ^ kk) < 0x10000u) + (int) ((t2[slot2(k)] ^ kk) < 0x10000u) + (int) ((t3[slot3(k)] ^ kk) < 0x10000u) + (int) ((t4[slot4(k)] ^ kk) < 0x10000u);
-							lost |= ballot(carry[j] != EMPTY && kept < 2) != 0;
-						}
+						const unsigned k = carry[j] >> 16, kk = carry[j] & 0xFFFF0000u;
+						const int kept = (int) ((t1[slot1<T1B>(k)] ^ kk) < 0x10000u) + (int) ((t2[slot2(k)] ^ kk) < 0x10000u) + (int) ((t3[slot3(k)] ^ kk) < 0x10000u) + (int) ((t4[slot4(k)] ^ kk) < 0x10000u);
+						lost |= ballot(carry[j] != EMPTY && kept < 2) != 0;
 					}
 				}
 			}
