@@ -2161,6 +2161,21 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 	}
 	__syncthreads();
 
+#ifdef FK_SETPRIO	/* experiment: the four waves of a SIMD at four static priorities (waves w, w+4, w+8, w+12 share one) */
+	switch ((wave >> 2) & 3) {
+	case 1:
+		__builtin_amdgcn_s_setprio(1);
+		break;
+	case 2:
+		__builtin_amdgcn_s_setprio(2);
+		break;
+	case 3:
+		__builtin_amdgcn_s_setprio(3);
+		break;
+	default:
+		break;
+	}
+#endif
 	WaveArena arena;
 	arena.cur = 0;
 	arena.end = 0;

@@ -26,6 +26,8 @@ ap.add_argument("--algo", default=None)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--sums", default="fast")
 ap.add_argument("--no-compare", action="store_true")
+ap.add_argument("--primers-after", action="store_true", help="`-a` (config 2 has primers)")
+ap.add_argument("--min-phred", type=int, default=2)
 ap.add_argument("--only", default=None, help="two-kernel or general: run just that mode (implies --no-compare)")
 args = ap.parse_args()
 
@@ -36,9 +38,9 @@ out = {}
 if args.only:
     args.no_compare = True
 for mode in ((args.only,) if args.only else ("two-kernel", "general")):
-    asm, _ = bench.setup_assembler(pa, synth, args.config, 0, exact_sums=args.sums == "exact", algo=args.algo)
+    asm, _ = bench.setup_assembler(pa, synth, args.config, 0, exact_sums=args.sums == "exact", algo=args.algo, primers_after=args.primers_after or os.environ.get("PAMD_PRIMERS_AFTER") == "1", min_phred=args.min_phred)
     asm.set_fast_path(mode == "two-kernel")
-    outs = pa.alloc_outputs(n, n * 440 + (1 << 28), "cuda:0")
+    outs = pa.alloc_outputs(n, n * (620 if args.config == 2 else 440) + (1 << 28), "cuda:0")
     b = pa.DeviceBatch(n=n, fwd=f, rev=r, flen=fl, rlen=rl, **outs)
     best = 1e30
     for _ in range(args.reps):

@@ -33,15 +33,28 @@ traffic 1 exact 50000000
 traffic 2 fast 20000000
 traffic 3 fast 20000000
 traffic 4 fast 40000000
+# `-a` on config 2 (its own kernel instantiation: its own traffic file, bench.py looks for the _after name)
+export PAMD_PRIMERS_AFTER=1
+traffic 2 fast 20000000
+mv "$OUT/traffic_config2_fast.json" "$OUT/traffic_config2_after_fast.json"
+bash tools/pmc_fk.sh 8000000 2 > "$OUT/pmc_config2_after_fast.txt" 2>&1
+unset PAMD_PRIMERS_AFTER
+traffic 2 fast 20000000
 for c in 1 2 3 4; do bash tools/pmc_fk.sh 8000000 $c > "$OUT/pmc_config${c}_fast.txt" 2>&1; done
 # the per-phase ablation wants six more builds of the library: make them BEFORE going to the GPU box (bash tools/fk_phases.sh build);
 # built there only if they did not travel
 ls "$ROOT"/pandaseq_amd/libpandaseq_amd_fkstop5.so > /dev/null 2>&1 || bash tools/fk_phases.sh build > "$OUT/phases_build.log" 2>&1
 bash tools/fk_phases.sh 8000000 1 > "$OUT/phases_config1_fast.txt" 2>&1
 bash tools/fk_phases.sh 8000000 2 > "$OUT/phases_config2_fast.txt" 2>&1
+PAMD_PRIMERS_AFTER=1 bash tools/fk_phases.sh 8000000 2 > "$OUT/phases_config2_after_fast.txt" 2>&1
 # the other scorers on config-1 data, primers after assembly, and the data-format rows (not bench lines: DESIGN.md sections 8 and 9)
 for a in uparse flash ea_util stitch pear rdp_mle; do python3 bench.py --algo $a --no-cpu --no-e2e --steps 3 --warmup 1 2> /dev/null | tail -1 > "$OUT/bench_algo_$a.json"; done
 python3 bench.py --config 2 --primers-after --no-cpu --no-e2e --steps 3 --warmup 1 2> /dev/null | tail -1 > "$OUT/bench_config2_primers_after.json"
+# config 3 with a min_phred value that rejects (the synthetic qualities know no value between "nothing" and "96 %")
+python3 bench.py --config 3 --min-phred 3 --no-cpu --no-e2e --steps 3 --warmup 1 2> /dev/null | tail -1 > "$OUT/bench_config3_minphred3.json"
+# PCIe-inclusive: text -> text through pinned host memory, file -> file through the plain-C pipe, the per-pair entry point
+python3 tools/pipeline_pcie.py --out "$OUT/pipeline_pcie.json" > "$OUT/pipeline_pcie.log" 2>&1
+python3 tools/pipe_file_rate.py --out "$OUT/pipe_file_rate.json" > "$OUT/pipe_file_rate.log" 2>&1
 python3 bench.py --io --no-e2e --cpu-seconds 0 --steps 3 --warmup 1 2> /dev/null | tail -1 | python3 -c "import json,sys; json.dump(json.load(sys.stdin)['io'], open(sys.argv[1], 'w'), indent=1)" "$OUT/io_bench.json"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_io" -o t -- python3 "$ROOT/tools/bench_io.py" --pairs 4000000 > "$OUT/prof_io.log" 2>&1)
 python3 profiles/summarize_rocprof.py --like '%f%_kernel%' $(find "$OUT/prof_io" -name '*_results.db' | head -1) > "$OUT/io_rocprof.txt"

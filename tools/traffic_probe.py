@@ -23,7 +23,8 @@ import bench
 
 cfg = int(os.environ.get("PAMD_CONFIG", "1"))
 n = int(os.environ.get("PAMD_PAIRS", "8000000"))
-asm, spec = bench.setup_assembler(pa, synth, cfg, 0, exact_sums=os.environ.get("PAMD_SUMS", "exact") == "exact")
+asm, spec = bench.setup_assembler(pa, synth, cfg, 0, exact_sums=os.environ.get("PAMD_SUMS", "exact") == "exact",
+                                  primers_after=os.environ.get("PAMD_PRIMERS_AFTER", "0") == "1", min_phred=int(os.environ.get("PAMD_MIN_PHRED", "2")))
 asm.set_fast_path(os.environ.get("PAMD_FAST_PATH", "1") == "1")
 f, r, fl, rl = synth.generate_device(spec, 0, n)
 outs = pa.alloc_outputs(n, n * (620 if cfg == 2 else 440) + (1 << 28), "cuda:0")
