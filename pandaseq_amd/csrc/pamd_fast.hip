@@ -824,7 +824,7 @@ template <int ALGO, class L>
 __device__ __forceinline__ double score_share(const unsigned char *wb, const double *ltab, int flen, int rlen, int ov, double nrb, double nn, int lane) {
 	const unsigned lF = lds_addr(wb + L::F), lR = lds_addr(wb + L::R), lT = lds_addr(ltab);
 	double part = 0.0;
-#pragma unroll
+#pragma unroll 1	/* (only the many-candidate scan calls this: it is cold, and its registers are what the hot path cannot keep across the call) */
 	for (int r = 0; r < L::SR; r++) {
 		const int i = 64 * r + lane;
 		if (64 * r < ov && i < ov) {
@@ -859,12 +859,16 @@ struct ManySums {
 	int bo, examined, ambiguous;
 };
 
+// (At most 56 vector registers: what this function clobbers the caller cannot keep across the call, and the caller is the
+// hot path, with 128 registers of its own in use -- given all of them, this function cost config 2's kernel a 16-byte
+// spill per lane and pair in the middle of `vmcnt`'s queue, 480 B of HBM writes per pair.  It may spill itself: it is cold.)
 template <int ALGO, bool LONG>
 __device__ __attribute__((noinline)) ManySums scan_many_sums(unsigned char *wb, const double *ltab, int all, int size, int minov, int flen, int rlen, double nrb, double nn, double many_all, double many_match, double many_strong, double best, int lane) {
 	typedef Lay<LONG> L;
 	constexpr int NC = LONG ? 5 : 4;	// candidates per lane: 256, or 320
 	constexpr unsigned LIST = L::T1, FNQ = L::T1 + 640 + 16, RNQ = FNQ + (LONG ? 96 : 64) + 16;	// (a pad word before either map, as before the reads' own)
-	static_assert(RNQ + 96 + 16 <= L::T1 + 2048, "inside the first k-mer table");
+	constexpr unsigned BND = RNQ + 96 + 16;	// the candidates' bounds, a float per candidate: [k][lane]
+	static_assert(BND % 16 == 0 && BND + 4u * 64u * NC <= L::T1 + 3072, "inside the first two k-mer tables");
 	uint16_t *list = reinterpret_cast<uint16_t *>(wb + LIST);	// overlap - minov of every candidate, ascending (where the k-mer tables were)
 	int total = size;
 	// the candidates, listed
@@ -936,29 +940,36 @@ __device__ __attribute__((noinline)) ManySums scan_many_sums(unsigned char *wb, 
 		}
 	}
 	wave_sync();
-	// this lane's candidates and the bounds of their scores
-	int ov[NC];
-	double bound[NC];
-#pragma unroll
-	for (int k = 0; k < NC; k++) {
-		const int c = k == 0 ? lane : (k == 1 ? 127 - lane : (k == 2 ? 128 + lane : (k == 3 ? 255 - lane : 256 + lane)));
+	// This lane's candidates k = 0 .. NC-1 (number lane, 127 - lane, 128 + lane, 255 - lane, 256 + lane of the ascending list) and
+	// the bounds of their scores.  Bounds live in LDS as floats rounded UP, candidates are re-read from the list where needed, and
+	// no loop over k is unrolled: this function is cold, and every vector register it uses is one the hot path cannot keep
+	// across the call (with all of them at its disposal it cost config 2's kernel a 16-byte spill per lane and pair).
+	auto cand_of = [&](int k) -> int {	// the overlap of this lane's k-th candidate, 0: none
+		const int c = (k & 1) ? 64 * (k + 1) - 1 - lane : 64 * k + lane;
 		const int idx = all ? c : (int) list[c < total ? c : 0];
-		ov[k] = c < total ? idx + minov : 0;
-	}
-#pragma unroll
+		return c < total ? idx + minov : 0;
+	};
+	float *const bnd = reinterpret_cast<float *>(wb + BND);
+#pragma unroll 1
 	for (int k = 0; k < NC; k++) {
+		const int o = cand_of(k);
 		// (lanes finish together: the k-th candidates of all lanes are walked in lockstep, to the longest of them)
-		int steps = (ov[k] + 15) >> 4;
-		for (int o = 32; o > 0; o >>= 1) {
-			const int other = __shfl_xor(steps, o);
+		int steps = (o + 15) >> 4;
+		for (int off = 32; off > 0; off >>= 1) {
+			const int other = __shfl_xor(steps, off);
 			steps = other > steps ? other : steps;
 		}
 		steps = uni(steps);
 		unsigned acc = 0;
+#pragma unroll 1
 		for (int st = 0; st < steps; st++)
-			acc += word_counts<L, FNQ, RNQ>(wb, flen, rlen, ov[k], 16 * st, 16 * st < ov[k]);
+			acc += word_counts<L, FNQ, RNQ>(wb, flen, rlen, o, 16 * st, 16 * st < o);
 		const int unknowns = (int) (acc & 1023u), matches = (int) (acc >> 10);
-		bound[k] = ov[k] != 0 ? (double) unknowns * many_all + (double) matches * many_match + (double) (ov[k] - unknowns - matches) * many_strong : -__builtin_inf();
+		const double b = (double) unknowns * many_all + (double) matches * many_match + (double) (o - unknowns - matches) * many_strong;
+		float bf = (float) b;
+		if ((double) bf < b)	// towards +inf: a bound may be too large, never too small
+			bf = __uint_as_float(__float_as_uint(bf) + (bf > 0.0f ? 1u : (bf < 0.0f ? 0xFFFFFFFFu : 1u)));
+		bnd[64 * k + lane] = o != 0 ? bf : -__builtin_inff();
 	}
 	// best bound first
 	ManySums out;
@@ -967,33 +978,31 @@ __device__ __attribute__((noinline)) ManySums scan_many_sums(unsigned char *wb, 
 	out.examined = total;
 	out.ambiguous = 0;
 	for (;;) {
-		double b = bound[0];
+		float b = -__builtin_inff();
 		int which = 0;
-#pragma unroll
-		for (int k = 1; k < NC; k++) {
-			if (bound[k] > b) {
-				b = bound[k];
+#pragma unroll 1
+		for (int k = 0; k < NC; k++) {
+			const float v = bnd[64 * k + lane];
+			if (v > b) {
+				b = v;
 				which = k;
 			}
 		}
-		int o = ov[0];
-#pragma unroll
-		for (int k = 1; k < NC; k++)
-			o = which == k ? ov[k] : o;
+		const int o = cand_of(which);
 		// the wave's best: the largest bound (the smaller overlap among equal bounds, so that the order is fixed)
-		double wbnd = b;
-		int wov = b > -__builtin_inf() ? o : 0x7FFFFFFF;
+		float wbnd = b;
+		int wov = b > -__builtin_inff() ? o : 0x7FFFFFFF;
 		for (int off = 32; off > 0; off >>= 1) {
-			const double ob = __shfl_xor(wbnd, off);
+			const float ob = __shfl_xor(wbnd, off);
 			const int oo = __shfl_xor(wov, off);
 			if (ob > wbnd || (ob == wbnd && oo < wov)) {
 				wbnd = ob;
 				wov = oo;
 			}
 		}
-		wbnd = uni_f64(wbnd);
+		wbnd = __uint_as_float((unsigned) uni((int) __float_as_uint(wbnd)));
 		wov = uni(wov);
-		if (wov == 0x7FFFFFFF || wbnd < out.best - 1e-6)
+		if (wov == 0x7FFFFFFF || (double) wbnd < out.best - 1e-6)
 			break;	// nothing left, or nothing left that could reach the best score
 		const double pr = wave_sum_any_order(score_share<ALGO, L>(wb, ltab, flen, rlen, wov, nrb, nn, lane));
 		if (pr > out.best + 1e-6) {
@@ -1002,9 +1011,8 @@ __device__ __attribute__((noinline)) ManySums scan_many_sums(unsigned char *wb, 
 		} else if (!(pr < out.best - 1e-6)) {
 			out.ambiguous = 1;
 		}
-#pragma unroll
-		for (int k = 0; k < NC; k++)
-			bound[k] = ov[k] == wov ? -__builtin_inf() : bound[k];
+		if (o == wov)	// (the winner is its lane's current best: that lane strikes it)
+			bnd[64 * which + lane] = -__builtin_inff();
 	}
 	return out;
 }

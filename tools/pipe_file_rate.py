@@ -36,8 +36,8 @@ def main():
     reps = max(1, args.pairs // base_n)
     n = base_n * reps
     algo = ["simple_bayesian", "pear", "rdp_mle", "uparse", "flash", "ea_util", "stitch"].index(bench.CONFIGS[args.config]["algo"])
-    with tempfile.TemporaryDirectory(dir=args.dir) as tmp:
-        exe = os.path.join(tmp, "pamd_pipe")
+    with tempfile.TemporaryDirectory(dir=args.dir) as tmp, tempfile.TemporaryDirectory() as bindir:
+        exe = os.path.join(bindir, "pamd_pipe")    # (a memory-backed directory is often mounted noexec)
         subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
                                os.path.join(ROOT, "tests", "c", "pamd_pipe.c"), "-o", exe,
                                "-L", os.path.join(ROOT, "pandaseq_amd"), "-lpandaseq_amd", "-L/opt/rocm/lib", "-lamdhip64", "-lm",

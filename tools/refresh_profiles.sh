@@ -22,11 +22,13 @@ for c in 2 3 4; do python3 bench.py --steps 3 --warmup 1 --config $c --no-cpu --
 python3 profiles/summarize_rocprof.py --like '%pamd_%' $(find "$OUT/prof" -name '*_results.db' | head -1) > "$OUT/rocprof.txt"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof2" -o t -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --config 2 --no-cpu --no-e2e > "$OUT/prof2.log" 2>&1)
 python3 profiles/summarize_rocprof.py --like '%pamd_%' $(find "$OUT/prof2" -name '*_results.db' | head -1) > "$OUT/rocprof_config2.txt"
-traffic() {	# config sums pairs
+traffic() {	# config sums pairs [tag]
 	export PAMD_CONFIG=$1 PAMD_SUMS=$2 PAMD_PAIRS=$3
-	(cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/traffic_rd_$1_$2" -o t -- python3 "$ROOT/tools/traffic_probe.py" > "$OUT/traffic_rd_$1_$2.log" 2>&1)
-	(cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/traffic_wr_$1_$2" -o t -- python3 "$ROOT/tools/traffic_probe.py" > "$OUT/traffic_wr_$1_$2.log" 2>&1)
-	python3 profiles/summarize_traffic.py $(find "$OUT/traffic_rd_$1_$2" -name '*_results.db' | head -1) $(find "$OUT/traffic_wr_$1_$2" -name '*_results.db' | head -1) $3 > "$OUT/traffic_config$1_$2.json"
+	T=$1$4_$2
+	rm -rf "$OUT/traffic_rd_$T" "$OUT/traffic_wr_$T"
+	(cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/traffic_rd_$T" -o t -- python3 "$ROOT/tools/traffic_probe.py" > "$OUT/traffic_rd_$T.log" 2>&1)
+	(cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/traffic_wr_$T" -o t -- python3 "$ROOT/tools/traffic_probe.py" > "$OUT/traffic_wr_$T.log" 2>&1)
+	python3 profiles/summarize_traffic.py $(find "$OUT/traffic_rd_$T" -name '*_results.db' | head -1) $(find "$OUT/traffic_wr_$T" -name '*_results.db' | head -1) $3 > "$OUT/traffic_config$T.json"
 }
 traffic 1 fast 50000000
 traffic 1 exact 50000000
@@ -35,11 +37,9 @@ traffic 3 fast 20000000
 traffic 4 fast 40000000
 # `-a` on config 2 (its own kernel instantiation: its own traffic file, bench.py looks for the _after name)
 export PAMD_PRIMERS_AFTER=1
-traffic 2 fast 20000000
-mv "$OUT/traffic_config2_fast.json" "$OUT/traffic_config2_after_fast.json"
+traffic 2 fast 20000000 _after
 bash tools/pmc_fk.sh 8000000 2 > "$OUT/pmc_config2_after_fast.txt" 2>&1
 unset PAMD_PRIMERS_AFTER
-traffic 2 fast 20000000
 for c in 1 2 3 4; do bash tools/pmc_fk.sh 8000000 $c > "$OUT/pmc_config${c}_fast.txt" 2>&1; done
 # the per-phase ablation wants six more builds of the library: make them BEFORE going to the GPU box (bash tools/fk_phases.sh build);
 # built there only if they did not travel
