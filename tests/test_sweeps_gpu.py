@@ -1,6 +1,6 @@
 """Fixed-seed slices of the randomized campaigns, under the driver (pytest -m gpu).
 
-The campaigns (tests/parity_sweep.py, primer_sweep.py, length_sweep.py, textio_sweep.py, compat_sweep.py) compare the device
+The campaigns (tests/parity_sweep.py, primer_sweep.py, length_sweep.py, textio_sweep.py, compat_sweep.py, per_pair_sweep.py) compare the device
 path with the oracle on every record, row and counter -- diff.c:26-99's notion of "same result", applied wholesale.  Round 3's
 runs of them found two silent wrong answers in the lean kernel that the fixed suite had passed, and they only ever ran on the
 builder's lease.  Here every driver run sees a slice of each; the seeds rotate with ROUND (bump it every round), so successive
@@ -92,6 +92,19 @@ def test_compat_campaign(built, first, rounds, runs):
     lines = []
     bad, done = compat_sweep.run(rounds, first, log=_log(lines))
     _verdict("compat_sweep first%d rounds%d" % (first, rounds), bad, done, runs, lines)
+
+
+PERPAIR = (600 * ROUND, 25)
+
+
+@pytest.mark.parametrize("first,rounds", [PERPAIR], ids=["perpair-first%d-rounds%d" % PERPAIR])
+def test_per_pair_campaign(built, first, rounds):
+    """panda_assembler_assemble() on the host path == pamd_compat_assemble_many() on the kernels == per pair on the device, under
+    random options (primers before / after / with a penalty, a fused module, overlap bounds, a threshold), and == the oracle."""
+    import per_pair_sweep
+    lines = []
+    bad, done = per_pair_sweep.run(rounds, first, log=_log(lines))
+    _verdict("per_pair_sweep first%d rounds%d" % (first, rounds), bad, done, rounds, lines)
 
 
 # ---- lean + general kernel against the general kernel alone -----------------------------------------------------------
