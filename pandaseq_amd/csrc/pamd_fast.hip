@@ -1749,8 +1749,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		asm volatile("" : "+s"(k_stride), "+s"(k_capacity), "+s"(k_nt), "+s"(k_p));
 		// The staged bases of all rounds of the merge (below), requested before the register rotation and the row's allocation:
 		// sixty scalar instructions that need nothing from the LDS run while the reads are under way.
-		constexpr int NR = L::NR;
-		constexpr int NF = L::MAXLEN / 64;	// rounds that can hold a forward base (a read is at most MAXLEN bases long)
+		// (NARROW: reads of at most 192 bases: a row spans six rounds, a forward base lies in the first three)
+		constexpr int NR = NARROW ? 6 : L::NR;
+		constexpr int NF = NARROW ? 3 : L::MAXLEN / 64;	// rounds that can hold a forward base (a read is at most MAXLEN bases long)
 		unsigned ef[NF], er[NR];
 		{
 			const unsigned aF = lds_addr(wb + L::F) + 2u * (unsigned) (lane + fo);					// round r: F[fo + 64r + lane] ...
@@ -1930,8 +1931,12 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			}
 		} else {
 			trip(std::integral_constant<int, 0>(), four());
-			if (seqlen > 256)
-				trip(std::integral_constant<int, 4>(), four());
+			if (seqlen > 256) {
+				if constexpr (NARROW)
+					trip(std::integral_constant<int, 4>(), two());
+				else
+					trip(std::integral_constant<int, 4>(), four());
+			}
 		}
 		wave_sync();
 		STOP(4);
