@@ -84,7 +84,7 @@ static_assert(Lay<true>::T1 % 16 == 0 && Lay<true>::FLAGS % 16 == 0 && Lay<true>
 static_assert(Lay<true>::PIDX % 16 == 0 && Lay<true>::MC % 16 == 0 && Lay<true>::MK % 16 == 0 && Lay<true>::POST_END <= Geo<true, 9>::T3, "`-a` staging lies over the first two k-mer tables");
 template <int ALGO>
 __device__ __host__ constexpr int t1_bits() {
-	return ALGO == PAMD_ALGO_RDP_MLE ? 9 : 10;	// (512 slots for every scorer: measured 2 % slower on config 1)
+	return ALGO == PAMD_ALGO_RDP_MLE ? 9 : 10;	// (512 slots for every scorer: measured 2 % slower on config 1; for reads of at most 192 bases only, round 4: 1 % slower on config 4)
 }
 
 // k-mer -> slot of table 1..4: bit fields of one 24-bit multiplicative hash (a second one for the rarely used last table)
