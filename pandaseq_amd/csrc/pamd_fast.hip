@@ -1031,6 +1031,38 @@ __device__ __forceinline__ double min_f64(double a, double b) {
 	return r;
 }
 
+// ---- min_phred: the row's smallest phred (plugin_min_phred.c:8-22) without a chain of LDS round trips ------------------------
+// the wave's smallest value, for values <= 0 (lanes DPP does not reach read as 0.0): DPP moves, no ds_bpermute
+__device__ __forceinline__ double wave_min_nonpositive(double v) {
+	v = min_f64(v, dpp_f64<0xB1>(v));	// quad_perm:[1,0,3,2]
+	v = min_f64(v, dpp_f64<0x4E>(v));	// quad_perm:[2,3,0,1]
+	v = min_f64(v, dpp_f64<0x141>(v));	// row_half_mirror
+	v = min_f64(v, dpp_f64<0x140>(v));	// row_mirror
+	v = min_f64(v, dpp_f64_rows<0x142, 0xA>(v));	// row_bcast:15
+	v = min_f64(v, dpp_f64_rows<0x143, 0xC>(v));	// row_bcast:31
+	return lane_f64(v, 63);
+}
+// panda_result_phred (nt.c:126-150) answers from where p lies among the 47 values of qual_score -- on one of them, or
+// strictly between two (or beyond the last) -- and from nothing else: its walk only ever compares p with them.  The answers for
+// the 47 + 48 places are made once per workgroup BY the walk (fk_phred_places: `on[k]`, `between[k]` = p in (score[k-1],
+// score[k]), k = 47: beyond the last); a pair then finds its place with one table read per lane and two ballots instead of six
+// dependent reads.  (pamd_io.hip's formatter does the same per base.)
+__device__ __forceinline__ void fk_phred_places(const double *score, unsigned char *places, int tid) {
+	if (tid < 47)
+		places[tid] = (unsigned char) result_phred(score, score[tid]);
+	else if (tid < 47 + 48) {
+		const int k = tid - 47;
+		const double p = k == 0 ? score[0] * 2.0 : (k == 47 ? score[46] * 0.5 : 0.5 * (score[k - 1] + score[k]));
+		places[48 + k] = (unsigned char) result_phred(score, p);
+	}
+}
+__device__ __forceinline__ int fk_phred_of(const double *score, const unsigned char *places, double p, int lane) {
+	const double s = score[lane < 47 ? lane : 46];
+	const u64 on = ballot(lane < 47 && s == p), below = ballot(lane < 47 && s < p);
+	return on != 0 ? (int) places[__builtin_ctzll(on)] : (int) places[48 + __popcll(below)];
+}
+
+
 template <bool LONG>
 struct Carry;
 template <>
@@ -1180,7 +1212,7 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 // NARROW (short geometry only): reads of at most 192 bases seed three bases per lane, on windows of the code streams
 // POST (LONG only, any-order sums): `-a`, the primers are looked for in the merged sequence and cut off it
 template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW, bool POST>
-__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases) {
+__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, const unsigned char *places, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases) {
 	typedef Lay<LONG> L;
 	constexpr int BPL = NARROW ? 3 : L::BPL;
 	constexpr bool WINDOWS = BPL != 4;	// k-mers from unaligned words of the code streams (else from the neighbouring lanes' registers)
@@ -2047,11 +2079,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				}
 			}
 			if (PHRED) {	// the smallest phred of the KEPT bases (plugin_min_phred.c:8-22 sees the clipped sequence)
-				for (int o = 32; o > 0; o >>= 1) {
-					const double other = __shfl_xor(pmin, o);
-					pmin = other < pmin ? other : pmin;
-				}
-				phmin = result_phred(ltab + PAMD_LT_SCORE, uni_f64(pmin));
+				phmin = fk_phred_of(ltab + PAMD_LT_SCORE, places, wave_min_nonpositive(pmin), lane);
 				if (ballot(pall <= qs0) != 0 && phmin > 1)
 					phmin = 1;
 				if (out_len <= 0)
@@ -2065,13 +2093,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		if (store && lane * 16 < seqlen)
 			((gbl_u128 *) row_nt)[lane] = reinterpret_cast<const u32x4 *>(nts)[lane];
 		if (PHRED) {
-			// one bisection per pair instead of one per base (see above)
-			for (int o = 32; o > 0; o >>= 1) {
-				const double other = __shfl_xor(pmin, o);
-				pmin = other < pmin ? other : pmin;
-			}
-			const double lowest = uni_f64(pmin);
-			phmin = result_phred(ltab + PAMD_LT_SCORE, lowest);
+			// one lookup per pair instead of one walk per base (see above)
+			phmin = fk_phred_of(ltab + PAMD_LT_SCORE, places, wave_min_nonpositive(pmin), lane);
 			if (ballot(pall <= qs0) != 0 && phmin > 1)
 				phmin = 1;
 			if (seqlen <= 0)
@@ -2161,6 +2184,7 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 	for (unsigned i = tid; i < PAMD_NUM_COUNTERS; i += blockDim.x)
 		lctr[i] = 0;
 	unsigned char *wb = lds + P.lds_primer_off + (size_t) wave * Geo<LONG, t1_bits<ALGO>()>::WAVE_BYTES;	// (the per-wave regions start where the general kernel keeps its primers)
+	unsigned char *places = lds + P.lds_primer_off + (size_t) nwaves * Geo<LONG, t1_bits<ALGO>()>::WAVE_BYTES;	// PHRED: 96 bytes behind the last wave's region (fk_phred_places)
 	unsigned primer_bases = 0;	// PRIM: this lane's base of the forward primer | of the reverse primer << 8 (N past their ends) | << 16: lanes 0..31 the forward, lanes 32..63 the reverse primer's bases 0..31
 	// what lies before a read reads as N: the word before the forward N map (seed windows start eight bases early)
 	if (lane < 4)
@@ -2173,6 +2197,10 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 				       | ((lane < 32 ? (lane < P.fprimer_len ? (unsigned) P.primers[lane] : 15u) : (lane - 32 < P.rprimer_len ? (unsigned) P.primers[456 + lane - 32] : 15u)) << 16);
 	}
 	__syncthreads();
+	if (PHRED) {	// (after the tables are staged: the places are made from the staged score table)
+		fk_phred_places(ltab + PAMD_LT_SCORE, places, tid);
+		__syncthreads();
+	}
 
 	// (measured, round 4, and left out: the four waves of a SIMD at four static priorities (s_setprio by (wave >> 2) & 3): +-0.3 %;
 	// the compiler's max-ilp and max-memory-clause scheduling strategies: +0.6 % / -0.3 % on config 1, inside the noise on config 4)
@@ -2210,7 +2238,7 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 			// here, the lane number's derivatives are recomputed where they are used (an instruction or two each).
 			asm volatile("" : "+v"(lane_now));
 		}
-		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST>(P, ltab, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases);
+		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST>(P, ltab, places, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases);
 		MARK("loop");
 		npend++;
 		if (npend == 64) {
@@ -2279,7 +2307,7 @@ int pamd_fast_supports(const PamdKernelParams &p) {
 size_t pamd_fast_lds_bytes(const PamdKernelParams &p, int waves_per_wg) {
 	const bool rdp = p.algo == PAMD_ALGO_RDP_MLE;
 	const size_t wave = pamd_fast_supports(p) == PAMD_FAST_SHORT ? (rdp ? Geo<false, 9>::WAVE_BYTES : Geo<false, 10>::WAVE_BYTES) : (rdp ? Geo<true, 9>::WAVE_BYTES : Geo<true, 10>::WAVE_BYTES);
-	return (size_t) p.lds_primer_off + (size_t) waves_per_wg * wave;
+	return (size_t) p.lds_primer_off + (size_t) waves_per_wg * wave + 96u;	// (+ the 96 bytes of fk_phred_places)
 }
 
 int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg, size_t lds_bytes, void *stream) {
