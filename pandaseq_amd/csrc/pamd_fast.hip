@@ -305,6 +305,33 @@ __device__ __forceinline__ int stage8(const uint4 v, const int len, int lane, un
 // (4) the few that are left are summed exactly, in the reference's order, and compared as the reference compares them.
 // Returns -1 when it cannot settle the read that cheaply (no good alignment, a bound too loose to filter, too many left).
 
+// the wave's largest value by DPP moves (a lane a move does not reach keeps its own value): no ds_bpermute round trips
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_f64_or_self(double v) {
+	union {
+		double d;
+		int i[2];
+	} x, y;
+	x.d = v;
+	y.i[0] = __builtin_amdgcn_update_dpp(x.i[0], x.i[0], CTRL, ROWS, 0xF, false);
+	y.i[1] = __builtin_amdgcn_update_dpp(x.i[1], x.i[1], CTRL, ROWS, 0xF, false);
+	return y.d;
+}
+__device__ __forceinline__ double max_f64(double a, double b) {	// v_max_f64 itself (no NaNs where it is used)
+	double r;
+	asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+	v = max_f64(v, dpp_f64_or_self<0xB1, 0xF>(v));
+	v = max_f64(v, dpp_f64_or_self<0x4E, 0xF>(v));
+	v = max_f64(v, dpp_f64_or_self<0x141, 0xF>(v));
+	v = max_f64(v, dpp_f64_or_self<0x140, 0xF>(v));
+	v = max_f64(v, dpp_f64_or_self<0x142, 0xA>(v));
+	v = max_f64(v, dpp_f64_or_self<0x143, 0xC>(v));
+	return lane_f64(v, 63);
+}
+
 // the sum of one alignment's terms in primer order (offset.c:79-87): lanes look the terms up, lane 0 adds them
 __device__ __forceinline__ double primer_exact(const double *ltab, unsigned char *wb, unsigned row_off, int s, unsigned pbase, int plen, int lane) {
 	typedef Lay<true> L;
@@ -514,12 +541,7 @@ __device__ __forceinline__ int primer_settle(const double *ltab, unsigned char *
 		}
 	};
 	auto raise = [&]() {	// a better bound for what is still to be summed
-		double m = besti != 0 ? best : bound;
-		for (int off = 32; off > 0; off >>= 1) {
-			const double o = __shfl_xor(m, off);
-			m = o > m ? o : m;
-		}
-		m = uni_f64(m);
+		const double m = wave_max_f64(besti != 0 ? best : bound);
 		bound = m > bound ? m : bound;
 	};
 	// Alignment s may hold K(s) = floor((bound * (s + plen + 1) - 1e-6) / err_t) disagreements that count and still reach the
@@ -576,20 +598,22 @@ __device__ __forceinline__ int primer_settle(const double *ltab, unsigned char *
 			return -1;
 		return got != 0 ? __builtin_amdgcn_readlane(besti, __builtin_ctzll(got)) : 0;
 	}
-	for (int off = 32; off > 0; off >>= 1) {
-		const double ob = __shfl_xor(best, off);
-		const int oi = __shfl_xor(besti, off);
-		const bool greater = ob > best, equal = ob == best;
-		close |= oi != 0 && besti != 0 && ob != best && fabs(ob - best) <= 4.5e-16;
-		const bool take = (oi != 0) && (besti == 0 || greater || (equal && oi < besti));
-		if (take) {
-			best = ob;
-			besti = oi;
-		}
-	}
+	// (the wave's largest value by DPP; a lane whose value differs from it by less than exp() can tell apart sends the read to
+	// the careful path -- only comparisons with the winner matter: whatever else lies close together loses to it either way --;
+	// among the lanes that hold it the smallest index)
+	const double top = wave_max_f64(besti != 0 ? best : -__builtin_inf());
+	close |= besti != 0 && best != top && fabs(best - top) <= 4.5e-16;
 	if (ballot(close) != 0)
 		return -1;
-	return uni(besti);
+	u64 holders = ballot(besti != 0 && best == top);
+	int winner = 0x7FFFFFFF;
+	while (holders != 0) {
+		const int l = __builtin_ctzll(holders);
+		holders &= holders - 1;
+		const int bi = __builtin_amdgcn_readlane(besti, l);
+		winner = bi < winner ? bi : winner;
+	}
+	return winner;
 }
 
 // ---- `-a`: the primers are looked for in the MERGED sequence (assembler.c:300-333, offset.c:114-133) ----------------------
