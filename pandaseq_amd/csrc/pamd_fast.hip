@@ -331,6 +331,27 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 	v = max_f64(v, dpp_f64_or_self<0x143, 0xC>(v));
 	return lane_f64(v, 63);
 }
+__device__ __forceinline__ int wave_max_i32(int v) {	// likewise, integers
+#define FK_STEP(CTRL, ROWS)                                                                 \
+	{                                                                                   \
+		const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xF, false);    \
+		v = o > v ? o : v;                                                          \
+	}
+	FK_STEP(0xB1, 0xF) FK_STEP(0x4E, 0xF) FK_STEP(0x141, 0xF) FK_STEP(0x140, 0xF) FK_STEP(0x142, 0xA) FK_STEP(0x143, 0xC)
+#undef FK_STEP
+	return __builtin_amdgcn_readlane(v, 63);
+}
+// among the lanes in `holders`, the smallest of their values (usually one lane)
+__device__ __forceinline__ int smallest_of(u64 holders, int value) {
+	int w = 0x7FFFFFFF;
+	while (holders != 0) {
+		const int l = __builtin_ctzll(holders);
+		holders &= holders - 1;
+		const int x = __builtin_amdgcn_readlane(value, l);
+		w = x < w ? x : w;
+	}
+	return w;
+}
 
 // the sum of one alignment's terms in primer order (offset.c:79-87): lanes look the terms up, lane 0 adds them
 __device__ __forceinline__ double primer_exact(const double *ltab, unsigned char *wb, unsigned row_off, int s, unsigned pbase, int plen, int lane) {
@@ -794,6 +815,9 @@ __device__ __attribute__((noinline)) ManyResult scan_many(unsigned char *wb, int
 	for (int half = 0; half < 2; half++) {
 		const int ova = ov[2 * half], ovb = ov[2 * half + 1];
 		const int wa = (ova + 15) >> 4;
+		// (ds_bpermute butterflies here and below, not DPP moves: with those this function's register footprint went from 56 to
+		// 128 and the hot path, which has to keep its values across the call, spilled: config 1 -7 %.  It runs for three pairs
+		// in a hundred.)
 		int steps = wa + ((ovb + 15) >> 4);
 		for (int o = 32; o > 0; o >>= 1) {
 			const int other = __shfl_xor(steps, o);
@@ -978,12 +1002,7 @@ __device__ __attribute__((noinline)) ManySums scan_many_sums(unsigned char *wb, 
 	for (int k = 0; k < NC; k++) {
 		const int o = cand_of(k);
 		// (lanes finish together: the k-th candidates of all lanes are walked in lockstep, to the longest of them)
-		int steps = (o + 15) >> 4;
-		for (int off = 32; off > 0; off >>= 1) {
-			const int other = __shfl_xor(steps, off);
-			steps = other > steps ? other : steps;
-		}
-		steps = uni(steps);
+		const int steps = wave_max_i32((o + 15) >> 4);
 		unsigned acc = 0;
 #pragma unroll 1
 		for (int st = 0; st < steps; st++)
@@ -1014,19 +1033,9 @@ __device__ __attribute__((noinline)) ManySums scan_many_sums(unsigned char *wb, 
 		}
 		const int o = cand_of(which);
 		// the wave's best: the largest bound (the smaller overlap among equal bounds, so that the order is fixed)
-		float wbnd = b;
-		int wov = b > -__builtin_inff() ? o : 0x7FFFFFFF;
-		for (int off = 32; off > 0; off >>= 1) {
-			const float ob = __shfl_xor(wbnd, off);
-			const int oo = __shfl_xor(wov, off);
-			if (ob > wbnd || (ob == wbnd && oo < wov)) {
-				wbnd = ob;
-				wov = oo;
-			}
-		}
-		wbnd = __uint_as_float((unsigned) uni((int) __float_as_uint(wbnd)));
-		wov = uni(wov);
-		if (wov == 0x7FFFFFFF || (double) wbnd < out.best - 1e-6)
+		const double wbnd = wave_max_f64((double) b);
+		const int wov = smallest_of(ballot((double) b == wbnd), b > -__builtin_inff() ? o : 0x7FFFFFFF);
+		if (wov == 0x7FFFFFFF || wbnd < out.best - 1e-6)
 			break;	// nothing left, or nothing left that could reach the best score
 		const double pr = wave_sum_any_order(score_share<ALGO, L>(wb, ltab, flen, rlen, wov, nrb, nn, lane));
 		if (pr > out.best + 1e-6) {
