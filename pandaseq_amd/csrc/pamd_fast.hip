@@ -1050,9 +1050,9 @@ __device__ __attribute__((noinline)) ManySums scan_many_sums(unsigned char *wb, 
 	return out;
 }
 
-struct WaveArena {
-	u64 cur;
-	u64 end;
+struct WaveArena {	// this wave's share of the compact arena, in units of 16 bases (rows and chunks are whole multiples of them): two scalar
+	unsigned cur;	// registers instead of four -- the kernel has none to spare, and a spilled one costs vector instructions
+	unsigned end;
 };
 
 // the registers a wave carries from one pair to the next (software prefetch): the lengths and this lane's share of the two
@@ -1751,9 +1751,10 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		} else {
 			// ---- scan + argmax: one candidate per 16-lane row, 16 positions per lane ----
 			const int row = lane >> 4;
-			int myov = ov0;	// (nine pairs in ten have one candidate: no per-lane selects)
-			if (ncand != 1)
-				myov = row == 0 ? ov0 : (row == 1 ? ov1 : (row == 2 ? ov2 : ov3));
+			// (the row's candidate out of a scalar pair that packs the four: a shift and a mask per lane -- three selects on
+			// row masks cost the masks' scalar registers, which the kernel spills into vector lanes and reads back per pair)
+			const u64 ovpack = (u64) (unsigned) ov0 | ((u64) (unsigned) ov1 << 16) | ((u64) (unsigned) ov2 << 32) | ((u64) (unsigned) ov3 << 48);
+			const int myov = (int) ((unsigned) (ovpack >> (unsigned) (lane & 0x30)) & 0xFFFFu);
 			unsigned packed = word_counts<L>(wb, flen, rlen, myov, 16 * (lane & 15), row < ncand);
 			if (LONG && (ov0 > 256 || ov1 > 256 || ov2 > 256 || ov3 > 256))	// (a row of lanes covers 256 positions)
 				packed += word_counts<L>(wb, flen, rlen, myov, 256 + 16 * (lane & 15), row < ncand);
@@ -1836,27 +1837,21 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		rotated = true;
 
 		seqlen = A + novl + Bn;	// len - 1; len = seqlen + 1 is in 3 .. 511 (639)
-		const u64 need = ((u64) seqlen + 15ull) & ~15ull;
+		const unsigned need16 = ((unsigned) seqlen + 15u) >> 4;
 		if (k_stride != 0) {
 			off = pair * k_stride;
 		} else {
-			if (__builtin_expect(arena.cur + need > arena.end, 0)) {
+			if (__builtin_expect(arena.cur + need16 > arena.end, 0)) {
 				u64 got = 0;
 				if (lane == 0)
 					got = atomicAdd(P.seq_cursor, P.arena_chunk);
-				union {
-					u64 v;
-					int i[2];
-				} x;
-				x.v = got;
-				x.i[0] = uni(x.i[0]);
-				x.i[1] = uni(x.i[1]);
-				arena.cur = x.v;
-				arena.end = x.v + P.arena_chunk;
+				const unsigned chunk16 = (unsigned) (P.arena_chunk >> 4);
+				arena.cur = (unsigned) uni((int) (unsigned) (got >> 4));	// (the cursor only ever moves by whole chunks: a multiple of 16)
+				arena.end = arena.cur + chunk16;
 			}
-			off = arena.cur;
-			arena.cur += need;
-			if (off + need > k_capacity)
+			off = (u64) arena.cur << 4;
+			arena.cur += need16;
+			if (off + 16ull * need16 > k_capacity)
 				off = ~0ull;
 		}
 		const bool store = off != ~0ull;
