@@ -1179,17 +1179,17 @@ __device__ __forceinline__ void insert_all(const unsigned (&addr)[BPL], unsigned
 		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") "s_waitcnt lgkmcnt(0)"
 			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [sv] "=&s"(sv)
 			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2])
-			     : "vcc", "memory");
+			     : "vcc", "scc", "memory");
 	else if constexpr (BPL == 4)
 		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") FK_INS("%[w3]", "%[a3]", "%[c3]") "s_waitcnt lgkmcnt(0)"
 			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [w3] "+v"(was[3]), [sv] "=&s"(sv)
 			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [a3] "v"(addr[3]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [c3] "v"(carry[3])
-			     : "vcc", "memory");
+			     : "vcc", "scc", "memory");
 	else
 		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") FK_INS("%[w3]", "%[a3]", "%[c3]") FK_INS("%[w4]", "%[a4]", "%[c4]") "s_waitcnt lgkmcnt(0)"
 			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [w3] "+v"(was[3]), [w4] "+v"(was[4]), [sv] "=&s"(sv)
 			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [a3] "v"(addr[3]), [a4] "v"(addr[4]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [c3] "v"(carry[3]), [c4] "v"(carry[4])
-			     : "vcc", "memory");
+			     : "vcc", "scc", "memory");
 #pragma unroll
 	for (int j = 0; j < BPL; j++)
 		carry[j] = was[j] > carry[j] ? was[j] : carry[j];
