@@ -108,3 +108,19 @@ def test_every_class_object_is_complete(built):
     assert L.panda_algorithm_quality_compare(a, qa, qb) == T.mismatch_sb[30][12]
     qb[0] = 1
     assert L.panda_algorithm_quality_compare(a, qa, qb) == T.match_sb[30][12]
+
+
+def test_reference_constructor_still_needs_a_gpu(built):
+    """The per-pair host path is an entry point of an assembler that has its GPU: panda_assembler_new() itself refuses to build
+    one without (no CPU fallback for batches and streams); only the test hook used above builds a device-less assembler."""
+    import ctypes as C
+    import torch
+    from pandaseq_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = _lib.lib()
+    L.panda_assembler_new.restype = C.c_void_p
+    L.panda_assembler_new.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.panda_assembler_new(None, None, None, None) is None
+    L.pamd_last_error.restype = C.c_char_p
+    assert b"no CPU fallback" in L.pamd_last_error() or b"GPU" in L.pamd_last_error() or b"device" in L.pamd_last_error()
