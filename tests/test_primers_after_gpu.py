@@ -74,23 +74,50 @@ def test_primers_after_adversarial_with_modules(built, penalty):
         assert o_ctr["nofp"] + o_ctr["norp"] > 0 and o_ctr["ok"] > 0
 
 
-def test_primers_after_one_primer_and_trims(built):
+@pytest.mark.parametrize("exact", [True, False])
+def test_primers_after_one_primer_and_trims(built, exact):
     """Only one primer set (the other side trimmed by a fixed count), and no primer at all (both trims
-    applied to the merged sequence, assembler.c:311,322); trims that eat the whole sequence count as NOFP."""
+    applied to the merged sequence, assembler.c:311,322); trims that eat the whole sequence count as NOFP.
+    (exact: the general kernel's `-a`; any-order sums: the lean kernel's)"""
     from pandaseq_amd import synth
     spec = synth.config_spec(2)
     fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 3000)
-    _pair("simple_bayesian", fwd, rev, flen, rlen, fprimer=synth.nt_codes(spec.fprimer), rtrim=9)
-    _pair("simple_bayesian", fwd, rev, flen, rlen, rprimer=synth.nt_codes(spec.rprimer, complement=True), ftrim=5)
-    _pair("pear", fwd, rev, flen, rlen, ftrim=20, rtrim=31)
-    o_res, o_ctr = _pair("simple_bayesian", fwd, rev, flen, rlen, ftrim=300, rtrim=300)
+    _pair("simple_bayesian", fwd, rev, flen, rlen, exact=exact, fprimer=synth.nt_codes(spec.fprimer), rtrim=9)
+    _pair("simple_bayesian", fwd, rev, flen, rlen, exact=exact, rprimer=synth.nt_codes(spec.rprimer, complement=True), ftrim=5)
+    _pair("pear", fwd, rev, flen, rlen, exact=exact, ftrim=20, rtrim=31)
+    _pair("rdp_mle", fwd, rev, flen, rlen, exact=exact, fprimer=synth.nt_codes(spec.fprimer), rtrim=9, modules=[("min_phred", 3)])
+    o_res, o_ctr = _pair("simple_bayesian", fwd, rev, flen, rlen, exact=exact, ftrim=300, rtrim=300)
     assert o_ctr["nofp"] > 2500 and o_ctr["ok"] == 0
 
 
-def test_primers_after_short_reads_and_counting_scorers(built):
+@pytest.mark.parametrize("exact", [True, False])
+def test_primers_after_short_reads_and_counting_scorers(built, exact):
     from pandaseq_amd import synth
     spec = synth.config_spec(0)
     fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 2500)
     fp = synth.nt_codes("ACGTTGCA")
-    for algo, tol in (("flash", 0.0), ("ea_util", 0.0), ("stitch", 0.0)):
-        _pair(algo, fwd, rev, flen, rlen, fprimer=fp, rprimer=fp, est_rel_tol=tol)
+    for algo, tol in (("flash", 0.0), ("ea_util", 0.0), ("stitch", 0.0), ("uparse", 0.0)):
+        _pair(algo, fwd, rev, flen, rlen, exact=exact, fprimer=fp, rprimer=fp, est_rel_tol=tol)
+
+
+def test_primers_after_ambiguity_codes_in_the_primer_and_long_primers(built):
+    """A primer with IUPAC codes and an N (a primer N is skipped, offset.c:79; an ambiguity code agrees with any of its bases),
+    a 24-base primer (the lean scan's limit: its first sixteen bases filter, the rest are checked with the sum) and a 30-base one
+    (the general kernel's), planted at the start of the merged sequence; any-order sums."""
+    from pandaseq_amd import synth
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 2000)
+    rng = np.random.default_rng(5)
+    for plen in (12, 24, 30):
+        f2 = fwd.copy()
+        primer = rng.choice(np.array([1, 2, 4, 8], dtype=np.uint8), size=plen)
+        f2[:, :plen, 0] = primer      # the forward read (and so the merged sequence) starts with the primer
+        f2[::7, 3, 0] = 15            # ... sometimes with an N in it (agrees with everything)
+        f2[::11, 5, 0] = 1 if primer[5] != 1 else 2     # ... or a wrong base: the alignment's value is NaN, the primer is not found
+        f2[::13, 6, 0] = primer[6] | (1 if primer[6] != 1 else 2)     # ... or an ambiguity code that includes the right base (the general kernel's pair)
+        loose = primer.copy()
+        loose[2] = 15                 # the primer as configured: an N
+        loose[7] = primer[7] | (1 if primer[7] != 1 else 2)     # and an ambiguity code that includes the planted base
+        o_res, o_ctr = _pair("simple_bayesian", f2, rev, flen, rlen, exact=False, fprimer=loose, rtrim=4)
+        assert o_ctr["ok"] > 500 and o_ctr["nofp"] > 100
+        assert np.median(o_res["fwd_offset"][o_res["status"] == 0]) == plen
