@@ -275,6 +275,7 @@ def main():
             "sums": ("reference order (all outputs bit-identical)" if args.sums == "exact" else
                      "any order + exactness guards (decisions, bases, per-base log-p bit-identical; quality / est_overlap_prob within 1e-9)"),
             "launch": asm.last_launch_info(),
+            "lean_kernel": asm.last_lean_variant(),     # which instantiation of pamd_fast_kernel served the launches ("general": none)
         },
         "stat": {k: ctr[k] for k in ("count", "ok", "noalgn", "lowq", "badr", "nofp", "norp", "slow")},
         # the STAT lines a reference worker prints at the end of its input (pool.c:86-104), from the counters of one step summed

@@ -175,12 +175,19 @@ int pamd_clear_modules(pamd_assembler *a);
 int pamd_set_exact_sums(pamd_assembler *a, int exact);
 /* Two kernels serve a launch: a lean one for ordinary pairs (reads of at most 256 bases holding only
  * A C G T N with qualities 0..46, a handful of seeded overlaps) and the general one, which then assembles whatever the
- * lean kernel deferred -- and everything, when the configuration is outside the lean kernel's (primers, `-a`, a maximum
- * overlap, min_phred, exact sums).  Results do not depend on which kernel produced them.  enable = 0 sends every pair
+ * lean kernel deferred -- and everything, when the configuration is outside the lean kernel's (a maximum overlap, reads
+ * longer than 320 bases, a primer penalty, `-a` with sums in the reference's order: DESIGN.md section 3).  Results do not
+ * depend on which kernel produced them.  enable = 0 sends every pair
  * to the general kernel (tests use it to compare the two); default 1. */
 int pamd_set_fast_path(pamd_assembler *a, int enable);
 /* how many pairs of the most recent launch the lean kernel handed to the general one (synchronises); < 0 if none ran */
 long long pamd_last_deferred(pamd_assembler *a);
+/* which instantiation of the lean kernel served the most recent launch (a probe for tests and profiles):
+ * 0 = none (the general kernel took the launch whole); else PAMD_LEAN_SHORT (reads of at most 256 bases), PAMD_LEAN_LONG (at
+ * most 320), PAMD_LEAN_PRIMERS (the same with `-p` / `-q` primers or trims found inside it) or PAMD_LEAN_AFTER (`-a`), plus
+ * PAMD_LEAN_NARROW when reads of at most 192 bases were seeded three bases per lane */
+enum { PAMD_LEAN_SHORT = 1, PAMD_LEAN_LONG = 2, PAMD_LEAN_PRIMERS = 3, PAMD_LEAN_AFTER = 4, PAMD_LEAN_NARROW = 0x100 };
+int pamd_last_lean_variant(pamd_assembler *a);
 
 /* The probability tables this library computes (host side; works without a GPU).
  * Order: qual_nn, qual_score[47], qual_score_err[47], then eight 47x47 row-major matrices:

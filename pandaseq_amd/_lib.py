@@ -69,7 +69,7 @@ SYMBOLS = [
     "pamd_set_primer_penalty", "pamd_set_primers_after", "pamd_add_module_min_phred", "pamd_add_module_min_overlapbits",
     "pamd_clear_modules", "pamd_set_exact_sums", "pamd_tables_get", "pamd_assemble_device", "pamd_assemble_host",
     "pamd_last_kernel_ms", "pamd_last_launch_info", "pamd_synth_generate", "pamd_debug_phase_cycles",
-    "pamd_assemble_status", "pamd_set_log_threshold", "pamd_set_fast_path", "pamd_last_deferred", "pamd_assemble_device_range", "pamd_encode_rows_device", "pamd_table_image",
+    "pamd_assemble_status", "pamd_set_log_threshold", "pamd_set_fast_path", "pamd_last_deferred", "pamd_last_lean_variant", "pamd_assemble_device_range", "pamd_encode_rows_device", "pamd_table_image",
 ]
 
 
@@ -121,6 +121,8 @@ def lib():
     L.pamd_set_fast_path.argtypes = [C.c_void_p, C.c_int]
     L.pamd_last_deferred.restype = C.c_longlong
     L.pamd_last_deferred.argtypes = [C.c_void_p]
+    L.pamd_last_lean_variant.restype = C.c_int
+    L.pamd_last_lean_variant.argtypes = [C.c_void_p]
     L.pamd_last_kernel_ms.restype = C.c_float
     L.pamd_last_kernel_ms.argtypes = [C.c_void_p]
     L.pamd_debug_phase_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int]

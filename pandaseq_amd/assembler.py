@@ -183,6 +183,13 @@ class Assembler:
         """Pairs the lean kernel handed to the general one in the last launch (-1: it did not run)."""
         return int(lib().pamd_last_deferred(self._h))
 
+    LEAN_NAMES = {0: "general", 1: "short", 2: "long", 3: "primers", 4: "after"}
+
+    def last_lean_variant(self) -> str:
+        """Which instantiation of the lean kernel served the last launch: general (none), short, short+narrow, long, primers, after."""
+        v = int(lib().pamd_last_lean_variant(self._h))
+        return self.LEAN_NAMES[v & 0xFF] + ("+narrow" if v & 0x100 else "")
+
     def check_overflow(self):
         """After synchronising: raise if pairs of the last launch did not fit in the output arena
         (their records carry status NOSPACE)."""

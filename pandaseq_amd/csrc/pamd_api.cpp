@@ -73,6 +73,7 @@ struct pamd_assembler {
 	size_t defer_cap = 0;
 	unsigned *d_defer_count = nullptr;	// ... and how many; the word behind it: how many of them the general kernel's waves have taken
 	bool last_two_kernels = false;
+	int last_variant = 0;	// pamd_last_lean_variant()
 	double *d_notp = nullptr;
 	std::vector<double> h_image;	// host copy of the table image on the device (pamd_table_image)
 	uint16_t *d_slots = nullptr;	// log-p -> index of the image (pamd_encode.hip)
@@ -359,6 +360,10 @@ long long pamd_last_deferred(pamd_assembler *a) {
 	if (hipSetDevice(a->device) != hipSuccess || hipEventSynchronize(a->ev_stop) != hipSuccess || hipMemcpy(&n, a->d_defer_count, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
 		return -1;
 	return (long long) n;
+}
+
+int pamd_last_lean_variant(pamd_assembler *a) {
+	return a == nullptr ? 0 : a->last_variant;
 }
 
 int pamd_assemble_status(pamd_assembler *a, uint64_t *n_overflowed) {
@@ -779,6 +784,7 @@ static int assemble_device_impl(pamd_assembler *a, const pamd_batch *b, void *st
 		}
 	}
 	a->last_two_kernels = two;
+	a->last_variant = two ? (variant | ((variant == PAMD_FAST_SHORT && smax <= 192) ? PAMD_LEAN_NARROW : 0)) : 0;
 	rc = pamd_launch_assemble(p, wgs, waves, lds_bytes, stream);
 	if (rc != PAMD_OK)
 		return rc;
