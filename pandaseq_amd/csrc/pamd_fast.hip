@@ -2231,6 +2231,7 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 	}
 
 	// (measured, round 4, and left out: the four waves of a SIMD at four static priorities (s_setprio by (wave >> 2) & 3): +-0.3 %;
+	// the four started a quarter or half of a pair's time apart (s_sleep): +-0.3 % -- they drift apart by themselves;
 	// the compiler's max-ilp and max-memory-clause scheduling strategies: +0.6 % / -0.3 % on config 1, inside the noise on config 4)
 	WaveArena arena;
 	arena.cur = 0;
