@@ -284,8 +284,8 @@ void pamd_compat_set_exact_sums(int exact);
  * per call: for checking the two against each other).  PAMD_COMPAT_PER_PAIR=device makes 1 the default of a process.  Arrays
  * (pamd_compat_assemble_many) and streams (panda_assembler_next) of pairs always go to the device. */
 void pamd_compat_set_per_pair_device(int device);
-/* The array form of panda_assembler_assemble() (pandaseq-assembler.h:137-163): n pairs through one upload, one launch and
- * one download per 65536 of them instead of one of each per pair -- what a caller that already holds its pairs wants
+/* The array form of panda_assembler_assemble() (pandaseq-assembler.h:137-163): n pairs through the batches of
+ * panda_assembler_next() (up to 65536 pairs each, four in flight) instead of one at a time -- what a caller that already holds its pairs wants
  * (panda_diff's A/B loop, diff.c:26-99: INTEGRATION.md section 2).  `visit` is called for every pair, in order, with its record
  * (NULL when the pair did not assemble; valid during the call only, as panda_assembler_assemble's is until the next call);
  * counters, modules and the fail-alignment handler behave as if the pairs had been passed one by one.  Returns how many

@@ -1490,11 +1490,11 @@ int slot_run(PandaAssembler a, pamd_slot *s) {
 void slot_wait(pamd_slot *s);
 
 // Pull the next batch from the source into slot `s` (the caller's thread) and start it.
-void slot_fill_and_submit(PandaAssembler a, pamd_slot *s) {
+void slot_fill_and_submit(PandaAssembler a, pamd_slot *s, size_t batch_pairs = 0) {
 	s->n = s->n_dev = s->pos = 0;
 	if (a->eof)
 		return;
-	const size_t want = g_batch_pairs.load();
+	const size_t want = batch_pairs != 0 ? batch_pairs : g_batch_pairs.load();
 	if (!slot_reserve(a, s, want)) {
 		fprintf(stderr, "pandaseq_amd: cannot allocate the staging buffers of a %zu-pair batch\n", want);
 		abort();
@@ -2064,6 +2064,28 @@ const panda_result_seq *panda_assembler_assemble(PandaAssembler a, panda_seq_ide
 	return replay(a, 0, forward, reverse);
 }
 
+namespace {
+// the caller's arrays as a PandaNextSeq source (pamd_compat_assemble_many)
+struct array_source {
+	const panda_seq_identifier *ids;
+	const panda_qual *const *forward, *const *reverse;
+	const size_t *forward_length, *reverse_length;
+	size_t n, pos;
+};
+bool array_next(panda_seq_identifier *id, const panda_qual **forward, size_t *forward_length, const panda_qual **reverse, size_t *reverse_length, void *user_data) {
+	array_source *src = static_cast<array_source *>(user_data);
+	if (src->pos >= src->n)
+		return false;
+	const size_t i = src->pos++;
+	*id = src->ids[i];
+	*forward = src->forward[i];
+	*forward_length = src->forward_length[i];
+	*reverse = src->reverse[i];
+	*reverse_length = src->reverse_length[i];
+	return true;
+}
+}	// namespace
+
 size_t pamd_compat_assemble_many(PandaAssembler a, const panda_seq_identifier *ids, const panda_qual *const *forward, const size_t *forward_length, const panda_qual *const *reverse, const size_t *reverse_length, size_t n, PamdVisit visit, void *user_data) {
 	// a pending prefetched batch of panda_assembler_next() shares the staging area: refuse to mix (as panda_assembler_assemble)
 	for (pamd_slot *sl : a->slots)
@@ -2072,33 +2094,86 @@ size_t pamd_compat_assemble_many(PandaAssembler a, const panda_seq_identifier *i
 			return 0;
 		}
 	size_t assembled = 0;
-	const bool host = device_algo_of(a->algo) < 0;	// a class of the caller's: pair by pair through its own functions
-	constexpr size_t CHUNK = 65536;	// one upload, one launch and one download per chunk
-	for (size_t base = 0; base < n; base += CHUNK) {
-		const size_t m = n - base < CHUNK ? n - base : CHUNK;
-		for (size_t i = 0; i < m; i++)
-			if (forward_length[base + i] > PAMD_MAX_LEN || reverse_length[base + i] > PAMD_MAX_LEN) {	// the reference asserts (assembler.c:375-376)
+	if (device_algo_of(a->algo) < 0) {	// a class of the caller's: pair by pair through its own functions
+		for (size_t i = 0; i < n; i++) {
+			if (forward_length[i] > PAMD_MAX_LEN || reverse_length[i] > PAMD_MAX_LEN) {	// the reference asserts (assembler.c:375-376)
 				fprintf(stderr, "pandaseq_amd: read longer than PANDA_MAX_LEN\n");
 				abort();
 			}
-		if (!host) {
-			ensure_staging(a, m);
-			for (size_t i = 0; i < m; i++)
-				stage_pair(a, i, &ids[base + i], forward[base + i], forward_length[base + i], reverse[base + i], reverse_length[base + i]);
-			a->batch_n = m;
-			a->batch_pos = m;
-			if (run_batch(a) != PAMD_OK) {
-				fprintf(stderr, "pandaseq_amd: %s\n", pamd_last_error());
-				abort();	// a device failure is fatal, never silently wrong
-			}
-		}
-		for (size_t i = 0; i < m; i++) {
-			const panda_result_seq *r = host ? host_assemble(a, &ids[base + i], forward[base + i], forward_length[base + i], reverse[base + i], reverse_length[base + i]) : replay(a, i, forward[base + i], reverse[base + i]);
+			const panda_result_seq *r = host_assemble(a, &ids[i], forward[i], forward_length[i], reverse[i], reverse_length[i]);
 			assembled += r != nullptr;
 			if (visit != nullptr)
-				visit(base + i, r, user_data);
+				visit(i, r, user_data);
 		}
+		return assembled;
 	}
+	if (a->dev == nullptr) {
+		fprintf(stderr, "pandaseq_amd: this assembler has no device: only panda_assembler_assemble() runs on it\n");
+		abort();
+	}
+	// The arrays are a source like any other: they go through panda_assembler_next()'s machinery -- 65 536 pairs per batch,
+	// four batches in flight (upload, kernels, index-coded download and expansion of different batches overlap), records handed
+	// back in order -- with the one difference that `visit` sees every pair, the ones that did not assemble as NULL.
+	// (Round 3 ran one synchronous upload / launch / download of full strided rows per batch: 1.0 M pairs/s.)
+	for (int k = 1; k < panda_assembler::NSLOT; k++)
+		if (a->devs[k] == nullptr) {
+			a->devs[k] = pamd_assembler_create(a->device);
+			a->dev_dirty = true;
+			if (a->devs[k] == nullptr) {
+				fprintf(stderr, "pandaseq_amd: %s\n", pamd_last_error());
+				abort();
+			}
+		}
+	if (a->slots[0] == nullptr) {
+		for (int k = 0; k < panda_assembler::NSLOT; k++) {
+			a->slots[k] = new pamd_slot;
+			a->slots[k]->dev = a->devs[k];
+		}
+		g_streaming.fetch_add(1);
+	}
+	for (int k = 0; k < panda_assembler::NSLOT; k++)
+		a->slots[k]->dev = a->devs[k];
+	array_source src = { ids, forward, reverse, forward_length, reverse_length, n, 0 };
+	const PandaNextSeq saved_next = a->next;
+	void *const saved_data = a->next_data;
+	const bool saved_eof = a->eof, saved_primed = a->primed;
+	const int saved_cur = a->cur;
+	a->next = array_next;
+	a->next_data = &src;
+	a->eof = false;
+	// an array no longer than a batch is cut in NSLOT pieces, so that its upload, kernels, download and expansion overlap as well
+	size_t batch = g_batch_pairs.load();
+	const size_t piece = (n + panda_assembler::NSLOT - 1) / panda_assembler::NSLOT;
+	if (piece < batch)
+		batch = piece < 4096 ? 4096 : piece;
+	for (int k = 0; k < panda_assembler::NSLOT; k++)
+		slot_fill_and_submit(a, a->slots[k], batch);
+	size_t index = 0;
+	for (int cur = 0;; cur = (cur + 1) % panda_assembler::NSLOT) {
+		pamd_slot *s = a->slots[cur];
+		slot_wait(s);
+		if (s->n == 0)
+			break;	// the arrays are exhausted (slots are filled in order: an empty one is the end)
+		a->n_batches++;
+		for (size_t i = 0; i < s->n; i++) {
+			const panda_result_seq *r = slot_replay(a, s, i);
+			assembled += r != nullptr;
+			if (visit != nullptr)
+				visit(index, r, user_data);
+			index++;
+		}
+		s->pos = s->n;
+		slot_fill_and_submit(a, s, batch);
+	}
+	for (int k = 0; k < panda_assembler::NSLOT; k++) {	// nothing may be left in flight or half consumed
+		slot_wait(a->slots[k]);
+		a->slots[k]->n = a->slots[k]->pos = 0;
+	}
+	a->next = saved_next;
+	a->next_data = saved_data;
+	a->eof = saved_eof;
+	a->primed = saved_primed;
+	a->cur = saved_cur;
 	return assembled;
 }
 

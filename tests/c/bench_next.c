@@ -7,7 +7,7 @@
  * included: the source callback, the copies into pinned memory, PCIe both ways, the kernels, the expansion into
  * panda_result[] and a consumer that reads every merged base.  Plain C, written as an embedder writes it.
  *
- * usage: bench_next <pairs.bin> <total pairs> <algo> <exact sums 0|1> [batch pairs] [consume] [api]
+ * usage: bench_next <pairs.bin> <total pairs> <algo> <exact sums 0|1> [batch pairs] [consume] [api] [chunk]
  *   api: 0 = the panda_assembler_next loop; 1 = panda_assembler_assemble per pair (diff.c:26-99); 2 = pamd_compat_assemble_many
  *   consume: 0 = the record's scalars only (length, overlap, quality); 1 = + every merged nt; 2 = + every log-p
  *            (default 2: what a FASTQ writer reads, output.c:100-126.  At 16 bytes per base, pandaseq-common.h:221-230,
@@ -147,8 +147,8 @@ int main(int argc, char **argv) {
 		while (next_pair(&id, &f, &fl, &r, &rl, &src))
 			if ((res = panda_assembler_assemble(a, &id, f, fl, r, rl)) != NULL)
 				CONSUME(res);
-	} else {	/* the same pairs handed over as arrays, 65536 at a time */
-		enum { CHUNK = 65536 };
+	} else {	/* the same pairs handed over as arrays, 65536 at a time (or [chunk] at a time) */
+		const size_t CHUNK = argc > 8 ? (size_t) atol(argv[8]) : 65536;
 		panda_seq_identifier *ids = malloc(CHUNK * sizeof *ids);
 		const panda_qual **fs = malloc(CHUNK * sizeof *fs), **rs = malloc(CHUNK * sizeof *rs);
 		size_t *fls = malloc(CHUNK * sizeof *fls), *rls = malloc(CHUNK * sizeof *rls);

@@ -48,7 +48,7 @@ def synth_pairs(spec, n):
     return synth.generate_numpy(spec, 0, n)
 
 
-def run(config=1, pairs=4_000_000, sums="exact", batch=65536, distinct=8192, algo=None, consume=2, api=0, rows="eager"):
+def run(config=1, pairs=4_000_000, sums="exact", batch=65536, distinct=8192, algo=None, consume=2, api=0, rows="eager", chunk=65536):
     from pandaseq_amd import synth
     import bench
     spec = synth.config_spec(config)
@@ -60,10 +60,13 @@ def run(config=1, pairs=4_000_000, sums="exact", batch=65536, distinct=8192, alg
         del fwd, rev
         env = dict(os.environ)
         env["PAMD_COMPAT_ROWS"] = rows
-        out = subprocess.check_output([exe, pin, str(pairs), algo or bench.CONFIGS[config]["algo"].replace("simple_bayesian", "sb"), "1" if sums == "exact" else "0", str(batch), str(consume), str(api)], timeout=1200, env=env)
+        out = subprocess.check_output([exe, pin, str(pairs), algo or bench.CONFIGS[config]["algo"].replace("simple_bayesian", "sb"), "1" if sums == "exact" else "0", str(batch), str(consume), str(api), str(chunk)], timeout=1200, env=env)
     d = json.loads(out.decode().strip().splitlines()[-1])
     d.update(config=config, sums=sums, batch_pairs=batch, distinct_pairs=min(distinct, pairs), api=("panda_assembler_next", "panda_assembler_assemble", "pamd_compat_assemble_many")[api], rows=rows,
-             path="in-memory PandaNextSeq source -> panda_assembler_next (pinned staging, two batches in flight, index-coded download) -> consumer reading every merged base")
+             path=("in-memory PandaNextSeq source -> panda_assembler_next (pinned staging, four batches in flight, index-coded download)",
+                   "the caller's pair -> panda_assembler_assemble on the caller's thread",
+                   "the caller's arrays, %d pairs a call -> pamd_compat_assemble_many (the machinery of panda_assembler_next)" % chunk)[api]
+             + " -> consumer reading " + ("the records' scalars", "every merged nt", "every merged base")[consume])
     return d
 
 
@@ -94,6 +97,7 @@ if __name__ == "__main__":
     ap.add_argument("--sums", default="exact")
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--consume", type=int, default=2)
+    ap.add_argument("--chunk", type=int, default=65536, help="pairs per pamd_compat_assemble_many call (--api 2)")
     ap.add_argument("--api", type=int, default=0, help="0 panda_assembler_next, 1 panda_assembler_assemble per pair, 2 pamd_compat_assemble_many")
     ap.add_argument("--rows", default="eager", help="eager | lazy (PAMD_COMPAT_ROWS)")
     ap.add_argument("--threads", type=int, default=0, help="> 0: bench_pool.c, that many threads with an assembler each")
@@ -101,4 +105,4 @@ if __name__ == "__main__":
     if args.threads > 0:
         print(json.dumps(run_pool(args.config, args.pairs, args.sums, args.threads)))
         sys.exit(0)
-    print(json.dumps(run(args.config, args.pairs, args.sums, args.batch, consume=args.consume, api=args.api, rows=args.rows)))
+    print(json.dumps(run(args.config, args.pairs, args.sums, args.batch, consume=args.consume, api=args.api, rows=args.rows, chunk=args.chunk)))
