@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <utility>
 #include "pamd_internal.h"
 #include "pamd_device.h"
 
@@ -148,6 +149,25 @@ __device__ __forceinline__ unsigned lds_read_u16(unsigned addr) {
 // under way BEFORE a stretch of scalar work the compiler would otherwise leave them behind)
 __device__ __forceinline__ unsigned lds_read_u16_early(unsigned addr) {
 	return *reinterpret_cast<volatile lds_cu16 *>(addr);
+}
+// The same as the bare instruction (a volatile 16-bit load is followed by an `and 0xffff` the zero-extending read does not need).
+// The compiler does not count this read: whoever uses the value issues lds_wait_all() on it first.
+template <int OFF>
+__device__ __forceinline__ unsigned lds_read_u16_bare(unsigned addr) {
+	unsigned v;
+	asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+	return v;
+}
+template <int... I, class F>
+__device__ __forceinline__ void for_each_int(std::integer_sequence<int, I...>, F &&f) {	// f(0_c), f(1_c), ...: a loop whose index is a constant expression
+	(f(std::integral_constant<int, I>()), ...);
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_all(unsigned (&a)[N]) {
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+	for (int i = 0; i < N; i++)
+		asm volatile("" : "+v"(a[i]));	// (volatile statements keep their order: no use of a[i] moves above the wait)
 }
 __device__ __forceinline__ double lds_read_f64(unsigned addr) {
 	return *reinterpret_cast<lds_cf64 *>(addr);
@@ -1822,12 +1842,13 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		{
 			const unsigned aF = lds_addr(wb + L::F) + 2u * (unsigned) (lane + fo);					// round r: F[fo + 64r + lane] ...
 			const unsigned aR = lds_addr(wb + L::R) + 2u * (unsigned) (rlen - 1 + A - lane) - 128u * (NR - 1);	// ... and R[rlen - 1 - (64r + lane - A)]
-#pragma unroll
-			for (int r = 0; r < NR; r++) {
-				if (r < NF)
-					ef[r] = lds_read_u16_early(aF + 128u * r);
-				er[r] = lds_read_u16_early(aR + 128u * (NR - 1 - r));
-			}
+			auto read_round = [&](auto rc) __attribute__((always_inline)) {
+				constexpr int r = decltype(rc)::value;
+				if constexpr (r < NF)
+					ef[r] = lds_read_u16_bare<128 * r>(aF);
+				er[r] = lds_read_u16_bare<128 * (NR - 1 - r)>(aR);
+			};
+			for_each_int(std::make_integer_sequence<int, NR>(), read_round);
 		}
 		MARK("rotate+alloc");
 		// Rotate the prefetched registers in BEFORE this pair's stores are issued (vmcnt is one in-order queue for
@@ -1889,6 +1910,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		const unsigned nN = lN + (unsigned) lane;
 		// (explicitly global: through a generic pointer these would be flat_store, which every later LDS wait waits for as well)
 		gbl_f64 *const gP = (gbl_f64 *) (row_p + lane);
+		lds_wait_all(ef);
+		lds_wait_all(er);
 		MARK("merge");
 		// one round: table index and base of output base 64 R + lane
 		auto round = [&](auto rc, unsigned &qi_out, unsigned &nt_out) __attribute__((always_inline)) {
