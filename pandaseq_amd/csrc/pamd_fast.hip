@@ -1524,6 +1524,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			unsigned m1[BPL], m2[BPL], xk[BPL];
 			bool ok[BPL];
 			const unsigned l1 = lds_addr(t1), l2 = lds_addr(t2);
+			// (the compiler issues these 2 BPL reads k-mer by k-mer, three LDS round trips; all eight under way before the first
+			// use -- bare reads, one wait -- measured: nothing on configs 1, 2 and 4, -1.5 % on config 3.  The other waves cover it.)
 #pragma unroll
 			for (int j = 0; j < BPL; j++) {
 				xk[j] = br << (2 * j);	// this k-mer in the top half
