@@ -643,7 +643,12 @@ __device__ __forceinline__ int finish_read(const TextRef &T, const ReadSpan &R, 
 			const unsigned keep = first_bytes((int) pos - (int) idx);
 			const unsigned n4 = nts[it] & keep, q4 = quals[it] & keep;
 			// interleave: nt0 q0 nt1 q1 | nt2 q2 nt3 q3
-			*reinterpret_cast<uint2 *>(row + 2u * idx) = make_uint2(__builtin_amdgcn_perm(q4, n4, 0x05010400u), __builtin_amdgcn_perm(q4, n4, 0x07030602u));
+			// (nontemporal, as every bulk output of this file: written once, read by a later kernel or copied out; +1..3 % on ingest and formatting)
+			typedef unsigned v2u __attribute__((ext_vector_type(2)));
+			v2u o;
+			o.x = __builtin_amdgcn_perm(q4, n4, 0x05010400u);
+			o.y = __builtin_amdgcn_perm(q4, n4, 0x07030602u);
+			__builtin_nontemporal_store(o, reinterpret_cast<v2u *>(row + 2u * idx));
 		}
 	}
 	return 0;
@@ -1096,12 +1101,13 @@ struct __attribute__((packed, aligned(1))) Text16 {
 	unsigned x, y, z, w;
 };
 __device__ __forceinline__ void store16(uint8_t *dst, unsigned x, unsigned y, unsigned z, unsigned w) {
-	Text16 t;
+	typedef unsigned v4u_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+	v4u_unaligned t;
 	t.x = x;
 	t.y = y;
 	t.z = z;
 	t.w = w;
-	*reinterpret_cast<Text16 *>(dst) = t;
+	__builtin_nontemporal_store(t, reinterpret_cast<v4u_unaligned *>(dst));
 }
 
 // panda_nt_to_ascii, nt.c:167-173 ("NACMGRSVTWYHKDBN"; anything outside 0..15 prints N): one nt / four nts of a word
