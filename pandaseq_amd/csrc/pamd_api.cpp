@@ -553,6 +553,7 @@ static int assemble_device_impl(pamd_assembler *a, const pamd_batch *b, void *st
 	// Every wave that merges a pair reserves a chunk of the compact arena (one global atomic per chunk), so a launch
 	// can leave up to waves x chunk bases unused: 16384 per wave for large batches, less for small ones and for
 	// the general kernel's pass over the lean kernel's deferred pairs (a few per wave).
+	// (Measured at 50 M pairs, config 1: 8192, 16384 and 32768 give the same rate; 4096 and 65536 lose 3-5 %.)
 	p.arena_chunk = b->n_pairs >= 262144 ? 16384 : 2048;
 	p.seq_stride = b->seq_stride;
 	p.seq_capacity = b->seq_capacity;
