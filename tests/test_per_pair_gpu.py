@@ -79,3 +79,34 @@ def test_per_pair_equals_batches_with_a_fused_module(client, tmp_path, algo, mod
     from pandaseq_amd import synth
     fwd, rev, flen, rlen = synth.generate_numpy(synth.config_spec(1), 9000, 1200)
     _three_ways(client, tmp_path, algo, fwd, rev, flen, rlen, ["-m", "%s:%d" % (module, value)], modules=[(module, value)])
+
+
+def test_array_form_across_more_batches_than_slots(client, tmp_path):
+    """pamd_compat_assemble_many() runs on the four pipelined slots of panda_assembler_next(): 300 000 pairs are more than the
+    four batches of 65 536 that can be in flight, so every slot is refilled while others are being consumed; the output is the
+    per-pair host path's, byte for byte (short reads keep the two files at 150 MB)."""
+    import filecmp
+    from pandaseq_amd import synth
+    spec = synth.SynthSpec(0x5EED7700, 40, 46, 70, qhi=36)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 300_000)
+    pairs = tmp_path / "pairs.bin"
+    pp.write_pairs(pairs, fwd, rev, flen, rlen)
+    env = dict(os.environ, PAMD_COMPAT_SUMS="exact")
+    records = pp.run_client(client, pairs, tmp_path / "many.bin", "simple_bayesian", "many", env=env)
+    pp.run_client(client, pairs, tmp_path / "host.bin", "simple_bayesian", "pair", env=env)
+    assert filecmp.cmp(tmp_path / "many.bin", tmp_path / "host.bin", shallow=False)
+    assert len(records[0]) == 300_000 and sum(r is not None for r in records[0]) > 250_000
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 4097])
+def test_array_form_on_few_pairs(client, tmp_path, n):
+    """... and arrays shorter than one piece of a batch (one slot filled, three idle), or empty"""
+    from pandaseq_amd import synth
+    fwd, rev, flen, rlen = synth.generate_numpy(synth.config_spec(4), 500, max(n, 1))
+    fwd, rev, flen, rlen = fwd[:n], rev[:n], flen[:n], rlen[:n]
+    pairs = tmp_path / "pairs.bin"
+    pp.write_pairs(pairs, fwd, rev, flen, rlen)
+    env = dict(os.environ, PAMD_COMPAT_SUMS="exact")
+    pp.run_client(client, pairs, tmp_path / "many.bin", "simple_bayesian", "many", env=env)
+    pp.run_client(client, pairs, tmp_path / "host.bin", "simple_bayesian", "pair", env=env)
+    assert (tmp_path / "many.bin").read_bytes() == (tmp_path / "host.bin").read_bytes()
