@@ -1938,6 +1938,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				nt_out = e_f;
 				return;
 			}
+			// (the round kinds of the first trip decided once per row -- fifteen classes by A0 / 64 and ceil(AF / 64), a switch and four
+			// straight-line rounds each, round 3's verdict 2b -- measured: a compare tree of four branches instead of eight compares,
+			// 400 instructions more, ten more scalar registers spilled: -2 % on configs 1, 3 and 4)
 			// (a fourth kind -- every base of the round in the overlap, nine pairs in ten have one: no border selects, eight vector
 			// instructions fewer -- measured: -0.8 % on config 1, -1.7 % on config 4; the branch costs more than the selects)
 			const int j = 64 * R + lane;
