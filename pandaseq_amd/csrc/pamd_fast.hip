@@ -1342,6 +1342,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			{
 				int fpl = P.fprimer_len, rpl = P.rprimer_len;
 				asm volatile("" : "+s"(fpl), "+s"(rpl));	// (what follows is two multiplications per pair; hoisted out of the loop it is two spilled doubles)
+				// (measured: the primer geometry's kernel re-reads a dozen kernel arguments per pair -- trivially rematerialisable, the
+				// allocator loads them again rather than park them in a vector lane; handed over as opaque values from outside the pair
+				// loop, nine of 27 scalar loads go: no change in the rate)
 				const double thr_f = (double) fpl * P.threshold, thr_r = (double) rpl * P.threshold, inv_err_t = P.primer_inv_err_t;
 				// per read: -3 no primer configured, -2 not looked at yet, -1 not settled yet, >= 0 what the scan returns
 				// (a primer as long as the read, or longer, is not found: offset.c:55-57, :70)
