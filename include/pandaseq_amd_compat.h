@@ -14,9 +14,13 @@
  * struct panda_assembler / panda_algorithm / panda_module are private in the reference
  * (assembler.h:28, algo.h:28, module.c:84) and are private here too.
  *
- * When this library is linked INTO libpandaseq (INTEGRATION.md), build it with
- * -DPAMD_WITH_REFERENCE_OBJECTS: the panda_algorithm_* and panda_module_* definitions below are
- * then left to the reference's algo.c / algo_*.c / module.c.
+ * When this library is linked INTO libpandaseq (INTEGRATION.md section 2), build it with
+ * -DPAMD_WITH_REFERENCE_OBJECTS: it then defines exactly what the three files it replaces define --
+ * assembler.c, assembler_support.c and module.c (module.c works on struct panda_assembler's private
+ * fields, module.c:99-220, so it goes with them) -- and leaves every other panda_* name below
+ * (algorithm objects, nt / offset / seqid / misc / log-proxy helpers, the FASTQ reader constructors of
+ * fastq.c and fileio.c) to the reference's own objects.  tests/test_link_modes_cpu.py holds both sides
+ * of that to the reference's sources.
  */
 #ifndef PANDASEQ_AMD_COMPAT_H
 #define PANDASEQ_AMD_COMPAT_H
@@ -124,6 +128,9 @@ PandaAssembler panda_assembler_open(const char *forward, const char *reverse, Pa
 /* which GPU the readers created from now on parse on (default 0), and the PAMD_FQ_* code (pandaseq_amd_io.h) the
  * last reader on this thread stopped with -- the PandaCode the reference's reader would have logged */
 void pamd_compat_set_fastq_device(int device);
+/* The device reader under its own name, same signature as panda_create_fastq_reader (fastq.c:200-237): what that name IS in
+ * the standalone build, and what a program linked with the reference's fastq.c calls to have its text parsed on the GPU. */
+PandaNextSeq pamd_compat_create_fastq_reader(PandaBufferRead forward, void *forward_data, PandaDestroy forward_destroy, PandaBufferRead reverse, void *reverse_data, PandaDestroy reverse_destroy, PandaLogProxy logger, unsigned char qualmin, PandaTagging policy, PandaBufferRead index, void *index_data, PandaDestroy index_destroy, void **user_data, PandaDestroy *destroy);
 int pamd_compat_last_fastq_stop(void);
 /* misc.c:38-41: what PANDA_MAX_LEN expands to (pandaseq-common.h:44); plugins call it */
 size_t panda_max_len(void);

@@ -4,6 +4,7 @@
 // assembler_support.c.  All assembly arithmetic happens in the HIP kernel; nothing here scores,
 // merges or sums anything.
 #include <hip/hip_runtime_api.h>
+#include <dirent.h>
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <sched.h>
@@ -355,8 +356,12 @@ __attribute__((constructor)) static void register_builtin_algorithms(void) {	// 
 	panda_algorithm_register(&panda_algorithm_uparse_class);
 }
 }	// extern "C"
+#endif	// PAMD_WITH_REFERENCE_OBJECTS (the algorithm objects)
 
 // ---------------------------------------------------------------- modules (module.c)
+// Ours in every build: the reference's module.c includes the private assembler.h and works on `struct panda_assembler`'s
+// fields (module.c:99-220: `assembler->modules`, `->rejected`, `->logger`, `->mutex`), so it leaves the link together with
+// assembler.c and assembler_support.c, and there is no public accessor for a module's callbacks.
 struct panda_module {
 	size_t refcnt;
 	PandaCheck check;
@@ -579,8 +584,46 @@ const char *panda_module_get_version(PandaModule m) {	// module.c:379-382
 		return "1.0";	// VER_INFO of plugin_min_phred.c:6 / plugin_min_overlapbits.c:15
 	return m->version == nullptr ? nullptr : *m->version;
 }
+
+#ifdef PAMD_WITH_REFERENCE_OBJECTS
+// module.c:393-451, the one internal name of module.c a file that STAYS in the link calls (args.c:273, the front end's help):
+// the modules this library knows -- the two that run inside the kernel, then the plugin files of $PANDASEQ_PLUGIN_DIR.
+void module_show_all(void) {
+	fprintf(stderr, "\nKnown modules:\n");
+	fprintf(stderr, "min_phred(1.0): %s\n\tUsage: %s\n", "Require every base of the assembled sequence to reach a minimum PHRED score", "min_phred:value");
+	fprintf(stderr, "min_overlapbits(1.0): %s\n\tUsage: %s\n", "Require a minimum amount of information in the overlap", "min_overlapbits:15");
+	const char *dir = getenv("PANDASEQ_PLUGIN_DIR");
+	DIR *d = dir != nullptr ? opendir(dir) : nullptr;
+	if (d == nullptr)
+		return;
+	while (struct dirent *e = readdir(d)) {
+		const std::string file = e->d_name;
+		if (file.size() < 4 || file.compare(file.size() - 3, 3, ".so") != 0)
+			continue;
+		void *handle = dlopen((std::string(dir) + "/" + file).c_str(), RTLD_LAZY | RTLD_LOCAL);
+		if (handle == nullptr)
+			continue;
+		const std::string module = plugin_module_name(file);
+		const int *api = static_cast<const int *>(plugin_symbol(handle, module, "api"));
+		if (api == nullptr || *api != PANDA_API) {
+			fprintf(stderr, "Invalid API in %s (%d != %d).\n", file.c_str(), api == nullptr ? -1 : *api, PANDA_API);
+		} else {
+			const char **version = static_cast<const char **>(plugin_symbol(handle, module, "version"));
+			const char **desc = static_cast<const char **>(plugin_symbol(handle, module, "desc"));
+			const char **usage = static_cast<const char **>(plugin_symbol(handle, module, "usage"));
+			fprintf(stderr, "%s", module.c_str());
+			if (version != nullptr && *version != nullptr)
+				fprintf(stderr, "(%s)", *version);
+			fprintf(stderr, desc != nullptr && *desc != nullptr ? ": %s\n" : "%s\n", desc != nullptr && *desc != nullptr ? *desc : "");
+			if (usage != nullptr && *usage != nullptr)
+				fprintf(stderr, "\tUsage: %s\n", *usage);
+		}
+		dlclose(handle);
+	}
+	closedir(d);
+}
+#endif
 }	// extern "C"
-#endif	// PAMD_WITH_REFERENCE_OBJECTS
 
 // ---------------------------------------------------------------- the assembler
 struct panda_assembler {
@@ -817,9 +860,11 @@ inline int host_clampq(int q) {	// PHREDCLAMP, prob.h:23
 
 // algo.c:27-32: the log probability one overlap position contributes to the merged base, for any algorithm object: asked of
 // the class's own function (the seven built-in classes': pamd_host_scorers.cpp).
+#ifndef PAMD_WITH_REFERENCE_OBJECTS
 double panda_algorithm_quality_compare(PandaAlgorithm algorithm, const panda_qual *a, const panda_qual *b) {
 	return panda_algorithm_class(algorithm)->match_probability(panda_algorithm_data(algorithm), (a->nt & b->nt) != 0, a->qual, b->qual);
 }
+#endif
 
 namespace {
 
@@ -1723,6 +1768,7 @@ void ensure_staging(PandaAssembler a, size_t pairs) {
 
 extern "C" {
 
+#ifndef PAMD_WITH_REFERENCE_OBJECTS	// (nt.c, offset.c, seqid.c, misc.c, proxy.c stay in a link with the reference's objects)
 // ---- per-base helpers (nt.c:120-150) ----
 // Plugins compiled against the reference headers call these on the panda_result rows they are
 // handed (plugin_min_phred.c:16).  The bisection keeps the reference's quirks: 1 at or below
@@ -1758,7 +1804,6 @@ char panda_result_phred(const panda_result *r) {
 
 // ---- the rest of what callers and plugins reach for around the assembler (standalone build only: in a build that links the
 // reference's objects, nt.c, offset.c and misc.c bring their own) ----
-#ifndef PAMD_WITH_REFERENCE_OBJECTS
 double panda_quality_probability(const panda_qual *q) {	// nt.c:116-119
 	return exp(panda_quality_log_probability(q));
 }
@@ -1931,9 +1976,11 @@ void pamd_compat_set_exact_sums(int exact) {
 	g_exact_sums.store(exact ? 1 : 0);
 }
 
+#ifndef PAMD_WITH_REFERENCE_OBJECTS
 size_t panda_max_len(void) {	// misc.c:38-41
 	return PAMD_MAX_LEN;
 }
+#endif
 
 PandaAssembler panda_assembler_new(PandaNextSeq next, void *next_data, PandaDestroy next_destroy, PandaLogProxy logger) {
 	return panda_assembler_new_kmer(next, next_data, next_destroy, logger, PANDA_DEFAULT_NUM_KMERS);
@@ -2072,7 +2119,7 @@ struct array_source {
 	const size_t *forward_length, *reverse_length;
 	size_t n, pos;
 };
-bool array_next(panda_seq_identifier *id, const panda_qual **forward, size_t *forward_length, const panda_qual **reverse, size_t *reverse_length, void *user_data) {
+static bool array_next(panda_seq_identifier *id, const panda_qual **forward, size_t *forward_length, const panda_qual **reverse, size_t *reverse_length, void *user_data) {
 	array_source *src = static_cast<array_source *>(user_data);
 	if (src->pos >= src->n)
 		return false;

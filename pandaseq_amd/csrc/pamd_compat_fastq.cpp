@@ -218,7 +218,10 @@ int pamd_compat_last_fastq_stop(void) {
 	return g_last_stop;
 }
 
-PandaNextSeq panda_create_fastq_reader(PandaBufferRead forward, void *forward_data, PandaDestroy forward_destroy, PandaBufferRead reverse, void *reverse_data, PandaDestroy reverse_destroy, PandaLogProxy logger, unsigned char qualmin, PandaTagging policy, PandaBufferRead index, void *index_data, PandaDestroy index_destroy, void **user_data, PandaDestroy *destroy) {
+// The device reader under a name of its own: what panda_create_fastq_reader() is in the standalone build, and what a program
+// that links the reference's fastq.c / fileio.c (-DPAMD_WITH_REFERENCE_OBJECTS: those files stay)
+// calls when it wants its text parsed on the GPU instead.
+PandaNextSeq pamd_compat_create_fastq_reader(PandaBufferRead forward, void *forward_data, PandaDestroy forward_destroy, PandaBufferRead reverse, void *reverse_data, PandaDestroy reverse_destroy, PandaLogProxy logger, unsigned char qualmin, PandaTagging policy, PandaBufferRead index, void *index_data, PandaDestroy index_destroy, void **user_data, PandaDestroy *destroy) {
 	(void) logger;
 	*user_data = nullptr;
 	*destroy = nullptr;
@@ -270,6 +273,11 @@ PandaNextSeq panda_create_fastq_reader(PandaBufferRead forward, void *forward_da
 	return reader_next;
 }
 
+#ifndef PAMD_WITH_REFERENCE_OBJECTS	// fastq.c:200-237, fileio.c:86-153: the reference's own in a link with its objects
+PandaNextSeq panda_create_fastq_reader(PandaBufferRead forward, void *forward_data, PandaDestroy forward_destroy, PandaBufferRead reverse, void *reverse_data, PandaDestroy reverse_destroy, PandaLogProxy logger, unsigned char qualmin, PandaTagging policy, PandaBufferRead index, void *index_data, PandaDestroy index_destroy, void **user_data, PandaDestroy *destroy) {
+	return pamd_compat_create_fastq_reader(forward, forward_data, forward_destroy, reverse, reverse_data, reverse_destroy, logger, qualmin, policy, index, index_data, index_destroy, user_data, destroy);
+}
+
 PandaBufferRead panda_open_buffer(const char *file_name, PandaLogProxy logger, void **user_data, PandaDestroy *destroy) {
 	(void) logger;
 	*user_data = nullptr;
@@ -310,6 +318,9 @@ PandaNextSeq panda_open_fastq(const char *forward, const char *reverse, PandaLog
 	return panda_create_fastq_reader(fr, fd, fdes, rr, rdd, rdes, logger, qualmin, policy, nullptr, nullptr, nullptr, user_data, destroy);
 }
 
+#endif	// PAMD_WITH_REFERENCE_OBJECTS
+
+// assembler_support.c:102-117 (a file this library replaces in every build): on whichever panda_create_fastq_reader() the link has
 PandaAssembler panda_assembler_new_fastq_reader(PandaBufferRead forward, void *forward_data, PandaDestroy forward_destroy, PandaBufferRead reverse, void *reverse_data, PandaDestroy reverse_destroy, PandaLogProxy logger, unsigned char qualmin, PandaTagging policy) {
 	void *user_data;
 	PandaDestroy destroy;
@@ -319,6 +330,7 @@ PandaAssembler panda_assembler_new_fastq_reader(PandaBufferRead forward, void *f
 	return panda_assembler_new(next, user_data, destroy, logger);
 }
 
+#ifndef PAMD_WITH_REFERENCE_OBJECTS	// fileio.c:139-153
 PandaAssembler panda_assembler_open_fastq(const char *forward, const char *reverse, PandaLogProxy logger, unsigned char qualmin, PandaTagging policy) {
 	void *user_data;
 	PandaDestroy destroy;
@@ -328,6 +340,9 @@ PandaAssembler panda_assembler_open_fastq(const char *forward, const char *rever
 	return panda_assembler_new(next, user_data, destroy, logger);
 }
 
+#endif
+
+// pandaseq-assembler.h:93-101 declares this name; the reference defines only panda_assembler_open_fastq (fileio.c:139)
 PandaAssembler panda_assembler_open(const char *forward, const char *reverse, PandaLogProxy logger, unsigned char qualmin, PandaTagging policy) {
 	return panda_assembler_open_fastq(forward, reverse, logger, qualmin, policy);
 }
