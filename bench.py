@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--io", action="store_true", help="N=1 only: also time the data-format rows either side of the path (FASTQ ingest, FASTA / "
                                                       "FASTQ formatting, tools/bench_io.py) with their own CPU baseline; reported under \"io\"")
     ap.add_argument("--io-pairs", type=int, default=4_000_000)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` leg (N=1, default configuration only: three timed steps of each other "
+                                                                    "BASELINE.json configuration's single-GPU shard after the headline line is measured)")
+    ap.add_argument("--other-pairs", type=int, default=0, help="pairs per GPU of the `other_configs` entries (0 = each configuration's own size; tests shrink it)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (the reference's own panda_assembler_next loop "
                                                           "through the drop-in C API, tests/c/bench_next.c)")
     ap.add_argument("--e2e-pairs", type=int, default=24_000_000)
@@ -90,41 +93,16 @@ def oracle_config(po, synth, cfg_index, algo=None, primers_after=False, min_phre
     return po.make_config(algo or CONFIGS[cfg_index]["algo"], primers_after=primers_after, **kw)
 
 
-def main():
-    args = parse()
-    import numpy as np
+def run_config(env, args, cfg_index, n, steps, warmup, headline=True):
+    """One configuration's shard on this rank's GPU: generate it in HBM, calibrate the arena, `warmup` untimed and `steps` timed
+    passes of the hot path between barrier + synchronize fences.  Returns everything the JSON line (or an `other_configs`
+    entry) is made from; the batch stays resident for the legs that follow."""
     import torch
-
-    import pandaseq_amd as pa
-    from pandaseq_amd import _lib, synth
-    from pandaseq_amd.stats import allreduce_counters, format_stat_block
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with that many ranks (WORLD_SIZE={world})")
-    dist = None
-    # test hook (tests/test_bench_gpu.py): run a 2-rank job on a 1-GPU box -- every rank on cuda:0,
-    # counters reduced over gloo instead of RCCL.  Never set by the driver.
-    single_device = os.environ.get("PAMD_BENCH_SINGLE_DEVICE") == "1"
-    if single_device:
-        local = 0
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        if single_device:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
-
-    cfg_index = args.config
-    n = args.pairs or CONFIGS[cfg_index]["pairs"]
-    asm, spec = setup_assembler(pa, synth, cfg_index, local, exact_sums=args.sums == "exact", algo=args.algo, primers_after=args.primers_after, min_phred=args.min_phred)
-    L = spec.read_len
+    pa, synth, dist, dev, rank, world, local = env["pa"], env["synth"], env["dist"], env["dev"], env["rank"], env["world"], env["local"]
+    from pandaseq_amd.stats import allreduce_counters
+    # (the scorer / `-a` / min_phred overrides and --chunk-pairs belong to the headline configuration; an `other_configs` entry runs as BASELINE.json names it)
+    asm, spec = setup_assembler(pa, synth, cfg_index, local, exact_sums=args.sums == "exact", algo=args.algo if headline else None,
+                                primers_after=args.primers_after and headline, min_phred=args.min_phred if headline else 2)
 
     # ---- calibrate the arena on the first pairs, then build the full shard in HBM ----
     ncal = min(n, 1 << 20)
@@ -156,7 +134,7 @@ def main():
         return 9 * (int(pairs * per_pair * 1.03) + slack)
 
     budget = int(free_b * 0.94)
-    if args.chunk_pairs:
+    if args.chunk_pairs and headline:
         chunk = min(n, args.chunk_pairs)
     elif fixed + arena_bytes(n) <= budget:
         chunk = n
@@ -192,12 +170,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one_step()
     fence()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         one_step(*evs[k])
     fence()
     t1 = time.perf_counter()
@@ -224,6 +202,49 @@ def main():
     lens = int((batch.flen.to(torch.int64) & 0xFFFF).sum().item() + (batch.rlen.to(torch.int64) & 0xFFFF).sum().item())
     algo_bytes = 2 * lens + 9 * merged_bases + 64 * n
     achieved = algo_bytes / avg_kernel_s / 1e9
+
+    return dict(cfg_index=cfg_index, n=n, steps=steps, warmup=warmup, elapsed=elapsed, kernel_ms_avg=avg_kernel_s * 1e3, algo_bytes=algo_bytes, achieved=achieved,
+                ctr=ctr, asm=asm, spec=spec, batch=batch, arenas=arenas, n_chunks=n_chunks, chunk=chunk, value=n * world * steps / elapsed,
+                launch=asm.last_launch_info(), lean_kernel=asm.last_lean_variant(), deferred=asm.last_deferred())
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    import pandaseq_amd as pa
+    from pandaseq_amd import _lib, synth
+    from pandaseq_amd.stats import allreduce_counters, format_stat_block
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with that many ranks (WORLD_SIZE={world})")
+    dist = None
+    # test hook (tests/test_bench_gpu.py): run a 2-rank job on a 1-GPU box -- every rank on cuda:0,
+    # counters reduced over gloo instead of RCCL.  Never set by the driver.
+    single_device = os.environ.get("PAMD_BENCH_SINGLE_DEVICE") == "1"
+    if single_device:
+        local = 0
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        if single_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    env = dict(pa=pa, synth=synth, dist=dist, dev=dev, rank=rank, world=world, local=local)
+    cfg_index = args.config
+    n = args.pairs or CONFIGS[cfg_index]["pairs"]
+    meas = run_config(env, args, cfg_index, n, args.steps, args.warmup)
+    batch, asm, ctr, spec, n_chunks, chunk, elapsed = meas["batch"], meas["asm"], meas["ctr"], meas["spec"], meas["n_chunks"], meas["chunk"], meas["elapsed"]
+    algo_bytes, achieved, avg_kernel_s, L = meas["algo_bytes"], meas["achieved"], meas["kernel_ms_avg"] / 1e3, spec.read_len
 
     # HBM bytes per launch from the PMC passes (tools/traffic_probe.py -> profiles/r03_traffic_config*.json):
     # FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, units calibrated on a 1 GiB copy in the same
@@ -341,14 +362,26 @@ def main():
                 best = scaling[-1]
             if m > sample:
                 o_res, sample = res_t, m
-        # the largest sample doubles as an at-scale parity check of statuses and overlaps
+        # The largest sample doubles as an at-scale parity check -- of ROWS, not only of records: for every pair of the sample the
+        # device's status, overlap, merged length, mismatches and two position-weighted checksums of its merged row in the
+        # 50 M-pair arena (sum (j+1) nt_j and sum (j+1) bits(p_j), wrapping 64-bit integers: exact in any order; SURVEY Appendix B's
+        # checksum made bit-exact) against the oracle's (po_row_checksums_mt: a second, untimed pass that keeps the rows).
         dres = batch.results[:sample].cpu().numpy().view(_lib.RESULT_DTYPE).reshape(-1)
-        same = bool((dres["status"] == o_res["status"]).all() and (dres["overlap"][o_res["status"] == 0] == o_res["overlap"][o_res["status"] == 0]).all())
+        ok_o = o_res["status"] == 0
+        same_records = bool((dres["status"] == o_res["status"]).all() and all((dres[k][ok_o] == o_res[k][ok_o]).all() for k in ("overlap", "seq_len", "mismatches", "degenerates", "examined")))
+        c0 = time.perf_counter()
+        o_res2, o_cs_nt, o_cs_p = po.row_checksums(ocfg, hf[:sample], hr[:sample], hfl[:sample], hrl[:sample], threads=int(max(1, min(affinity, 2 * effective))))
+        d_cs_nt, d_cs_p = pa.row_checksums(batch.results, batch.seq_nt, batch.seq_p, first=0, count=sample)
+        same_rows = bool(np.array_equal(d_cs_nt.cpu().numpy().view(np.uint64), o_cs_nt) and np.array_equal(d_cs_p.cpu().numpy().view(np.uint64), o_cs_p)
+                         and (o_res2["status"] == o_res["status"]).all()) if n_chunks == 1 else None   # (a shard streamed through two arenas no longer holds the first rows)
+        rows_seconds = time.perf_counter() - c0
+        same = same_records and same_rows is not False
         eff_at_cores = best["pairs_per_s"] / (rate1 * min(best["threads"], effective))
         out["cpu_baseline"] = {
             "value": best["pairs_per_s"],
             "unit": "pairs/s",
-            "cores": best["threads"],
+            "cores": int(min(best["threads"], effective)),   # CPUs the process may use (cgroup quota / affinity) ...
+            "threads": best["threads"],                     # ... and the pthreads that reached the best rate on them
             "kind": "port",
             "sample": (f"first {best['pairs']} pairs of the same batch, oracle C port, {best['threads']} pinned pthreads, one assembler each over a private, "
                        "self-touched copy of its contiguous slice (pool.c:140-167), in memory (no FASTQ parsing), merged sequence discarded; "
@@ -360,10 +393,38 @@ def main():
             "note": ("efficiency = rate / (single-thread rate x min(threads, effective cores)); SMT siblings share a core's pipelines, so "
                      "the upper half of the ladder (threads > physical cores) adds well under 1x per thread"),
             "matches_gpu_on_sample": same,
+            "sample_check": {"pairs": sample, "records": same_records, "rows": same_rows, "accepted_rows": int(ok_o.sum()),
+                             "what": "status of every pair; overlap, merged length, mismatches, degenerates, examined of every accepted pair; per accepted row "
+                                     "sum (j+1) nt_j and sum (j+1) bits(log-p_j) in wrapping 64-bit arithmetic, device rows in the arena against the oracle's",
+                             "seconds": rows_seconds},
         }
+    # ---- the other BASELINE.json configurations' single-GPU shards, in the same record (N=1, default configuration only) ----
+    if world == 1 and cfg_index == 1 and (not args.pairs or args.other_pairs) and not args.algo and not args.primers_after and not args.no_other_configs:
+        batch = asm = None
+        meas.clear()
+        torch.cuda.empty_cache()
+        others = {}
+        for oc in (2, 3, 4):
+            try:
+                r = run_config(env, args, oc, args.other_pairs or CONFIGS[oc]["pairs"], 3, 1, headline=False)
+                octr = r["ctr"]
+                others[f"config{oc}"] = {
+                    "workload": CONFIGS[oc]["name"], "pairs_per_gpu": r["n"], "steps": 3, "warmup": 1, "pairs_per_s": r["value"], "ms_per_step": r["elapsed"] / 3 * 1e3,
+                    "kernel_ms": r["kernel_ms_avg"], "frac": r["achieved"] / HBM_PEAK_GBPS, "achieved_GBps": r["achieved"], "bytes_per_pair": r["algo_bytes"] / r["n"],
+                    "lean_kernel": r["lean_kernel"], "launch": r["launch"], "launches_per_step": r["n_chunks"], "deferred_pairs": r["deferred"],
+                    "stat": {k: octr[k] for k in ("count", "ok", "noalgn", "lowq", "badr", "nofp", "norp", "slow")}, "rejected": octr["rejected"][:2],
+                }
+                r.clear()
+            except BaseException as exc:   # (SystemExit of a shard that does not fit included: the headline line does not depend on this leg)
+                others[f"config{oc}"] = {"error": str(exc)[:300]}
+            torch.cuda.empty_cache()
+        others["note"] = ("each: the configuration's single-GPU shard resident in HBM, 1 warmup + 3 timed steps by the same code as the headline line "
+                          "(run_config), any-order sums; frac = algorithmic bytes / HIP-event kernel time / 8 TB/s")
+        out["other_configs"] = others
     # ---- end to end through the drop-in API (never `value`): the reference's loop, PCIe both ways, plain C ----
     if rank == 0 and world == 1 and not args.no_e2e and cfg_index in (1, 3, 4):
-        del batch, arenas, results, f, r, fl, rl
+        batch = asm = None
+        meas.clear()
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_next
@@ -380,7 +441,7 @@ def main():
             e2e["every_base_read_one_assembler_per_thread"] = {k: d[k] for k in keys + ("threads",)}
             # the per-pair entry point (what panda_diff calls, diff.c:26-99) and its array form
             d = bench_next.run(config=cfg_index, pairs=min(400_000, args.e2e_pairs), sums=args.sums, consume=2, api=1, distinct=1 << 16)
-            e2e["panda_assembler_assemble_per_pair"] = {k: d[k] for k in keys}
+            e2e["panda_assembler_assemble_per_pair_host"] = dict({k: d[k] for k in keys}, device=False)   # (a CPU thread: the per-pair entry point runs on the host path)
             d = bench_next.run(config=cfg_index, pairs=args.e2e_pairs // 4, sums=args.sums, consume=2, api=2)
             e2e["pamd_compat_assemble_many"] = {k: d[k] for k in keys}
             e2e["unit"] = "pairs/s"

@@ -873,6 +873,81 @@ static void *bench_worker(void *arg) {
 	return NULL;
 }
 
+/* ---- per-row checksums of a batch (bench.py's at-scale parity check; tests): the batch is assembled in blocks of 256 pairs with
+ * their merged rows, and of every accepted pair's row two position-weighted sums are kept, both in wrapping 64-bit integer
+ * arithmetic -- so that they are exact whatever order a checker on another machine adds in --:
+ *   cs_nt[i] = sum (j+1) * nt_j        cs_p[i] = sum (j+1) * (the 64 bits of p_j)        (0, 0 for a pair without a row) */
+struct cs_job {
+	struct mt_job j;
+	uint64_t *cs_nt, *cs_p;
+};
+
+static void *cs_worker(void *arg) {
+	struct cs_job *b = arg;
+	struct mt_job *j = &b->j;
+	enum { BLOCK = 256 };
+	const size_t ostride = 2 * PO_MAX_LEN;
+	uint8_t *nt = malloc((size_t) BLOCK * ostride);
+	double *p = malloc((size_t) BLOCK * ostride * sizeof(double));
+	memset(&j->ctr, 0, sizeof j->ctr);
+	if (!nt || !p)
+		abort();
+	for (size_t lo = j->lo; lo < j->hi; lo += BLOCK) {
+		const size_t n = j->hi - lo < BLOCK ? j->hi - lo : BLOCK;
+		po_counters ctr;
+		memset(&ctr, 0, sizeof ctr);
+		po_assemble_batch(j->c, j->t, n, j->fwd + lo * j->fstride, j->fstride, j->rev + lo * j->rstride, j->rstride, j->flen + lo, j->rlen + lo, j->res + lo, nt, p, ostride, &ctr);
+		for (size_t i = 0; i < n; i++) {
+			uint64_t a = 0, q = 0;
+			if (j->res[lo + i].status == 0) {
+				const size_t m = j->res[lo + i].seq_len;
+				for (size_t k = 0; k < m; k++) {
+					uint64_t bits;
+					memcpy(&bits, &p[i * ostride + k], 8);
+					a += (uint64_t) (k + 1) * nt[i * ostride + k];
+					q += (uint64_t) (k + 1) * bits;
+				}
+			}
+			b->cs_nt[lo + i] = a;
+			b->cs_p[lo + i] = q;
+		}
+	}
+	free(nt);
+	free(p);
+	return NULL;
+}
+
+void po_row_checksums_mt(const po_config *c, const po_tables *t, size_t n, const po_qual *fwd, size_t fstride, const po_qual *rev, size_t rstride, const uint16_t *flen, const uint16_t *rlen, po_result *res, uint64_t *cs_nt, uint64_t *cs_p, int threads) {
+	if (threads < 1)
+		threads = 1;
+	struct cs_job *jobs = calloc((size_t) threads, sizeof *jobs);
+	pthread_t *tid = calloc((size_t) threads, sizeof *tid);
+	if (!jobs || !tid)
+		abort();
+	for (int k = 0; k < threads; k++) {
+		struct mt_job *j = &jobs[k].j;
+		j->c = c;
+		j->t = t;
+		j->lo = n * (size_t) k / (size_t) threads;
+		j->hi = n * (size_t) (k + 1) / (size_t) threads;
+		j->fwd = fwd;
+		j->rev = rev;
+		j->fstride = fstride;
+		j->rstride = rstride;
+		j->flen = flen;
+		j->rlen = rlen;
+		j->res = res;
+		jobs[k].cs_nt = cs_nt;
+		jobs[k].cs_p = cs_p;
+		if (pthread_create(&tid[k], NULL, cs_worker, &jobs[k]) != 0)
+			abort();
+	}
+	for (int k = 0; k < threads; k++)
+		pthread_join(tid[k], NULL);
+	free(jobs);
+	free(tid);
+}
+
 double po_bench_mt(const po_config *c, const po_tables *t, size_t n, const po_qual *fwd, size_t fstride, const po_qual *rev, size_t rstride, const uint16_t *flen, const uint16_t *rlen, po_result *res, po_counters *ctr, int threads, int pin) {
 	if (threads < 1)
 		threads = 1;

@@ -172,6 +172,8 @@ void po_assemble_batch_mt(const po_config *c, const po_tables *t, size_t n, cons
 #endif
 /* bench.py's cpu_baseline leg: `threads` pinned workers, each over a private, self-touched copy of its slice; returns the
  * seconds from "all ready" to "all done" (< 0 on failure).  res may be NULL. */
+/* per-row checksums in wrapping 64-bit arithmetic: cs_nt[i] = sum (j+1) nt_j, cs_p[i] = sum (j+1) bits(p_j); 0 for a pair without a row */
+void po_row_checksums_mt(const po_config *c, const po_tables *t, size_t n, const po_qual *fwd, size_t fstride, const po_qual *rev, size_t rstride, const uint16_t *flen, const uint16_t *rlen, po_result *res, uint64_t *cs_nt, uint64_t *cs_p, int threads);
 double po_bench_mt(const po_config *c, const po_tables *t, size_t n, const po_qual *fwd, size_t fstride, const po_qual *rev, size_t rstride, const uint16_t *flen, const uint16_t *rlen, po_result *res, po_counters *ctr, int threads, int pin);
 
 #endif

@@ -236,6 +236,26 @@ def bench_mt(cfg, fwd, rev, flen, rlen, threads, pin=True):
     return secs, res, ctr[0]
 
 
+def row_checksums(cfg, fwd, rev, flen, rlen, threads=1):
+    """(results, cs_nt, cs_p): per accepted pair, sum (j+1) nt_j and sum (j+1) bits(p_j) over its merged row, both in wrapping
+    64-bit integer arithmetic (exact in any order of addition); 0 where a pair has no row.  po_row_checksums_mt."""
+    fwd = np.ascontiguousarray(fwd, dtype=np.uint8)
+    rev = np.ascontiguousarray(rev, dtype=np.uint8)
+    flen = np.ascontiguousarray(flen, dtype=np.uint16)
+    rlen = np.ascontiguousarray(rlen, dtype=np.uint16)
+    n = fwd.shape[0]
+    res = np.zeros(n, dtype=RESULT_DTYPE)
+    cs_nt = np.zeros(n, dtype=np.uint64)
+    cs_p = np.zeros(n, dtype=np.uint64)
+    L = lib()
+    L.po_row_checksums_mt.restype = None
+    L.po_row_checksums_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.po_row_checksums_mt(C.byref(cfg), C.byref(tables()), n, fwd.ctypes.data, fwd.shape[1], rev.ctypes.data, rev.shape[1],
+                          flen.ctypes.data, rlen.ctypes.data, res.ctypes.data, cs_nt.ctypes.data, cs_p.ctypes.data, int(threads))
+    return res, cs_nt, cs_p
+
+
 def ref_tables_np():
     """Tables emitted by the REFERENCE's own mktable (oracle/_ref/libreftable.so), or None when
     that build is absent (it can only be produced where /root/reference exists)."""

@@ -5,4 +5,4 @@ mirror of the reference's assembler interface, the synthetic-pair generator and 
 counter all-reduce.
 """
 from ._lib import ALGO, STATUS, NUM_COUNTERS, RESULT_DTYPE, PamdError, LibraryMissing  # noqa: F401
-from .assembler import Assembler, DeviceBatch, upload_batch, alloc_outputs, counters_to_dict  # noqa: F401
+from .assembler import Assembler, DeviceBatch, upload_batch, alloc_outputs, counters_to_dict, row_checksums  # noqa: F401

@@ -73,6 +73,42 @@ def alloc_outputs(n, capacity, device, seq_stride=0):
     )
 
 
+def row_checksums(results, seq_nt, seq_p, first=0, count=None, seq_stride=0, block=262144):
+    """Two position-weighted checksums of every merged row of pairs [first, first + count), computed where the rows lie (in HBM):
+    cs_nt[i] = sum (j+1) nt_j and cs_p[i] = sum (j+1) * (the 64 bits of p_j), both in wrapping 64-bit integer arithmetic, so
+    that the result does not depend on the order of addition and can be held, bit for bit, against a checker's on another
+    machine (bench.py's at-scale parity check; "a checksum of checksums" over a whole run).  0 for a pair without a row.
+    `results`: uint8 [n, 48] records; rows at results.seq_offset in the compact arena, or at i * seq_stride.  Returns two int64
+    tensors (the bit patterns of the uint64 sums)."""
+    torch = _torch()
+    n = results.shape[0]
+    count = n - first if count is None else count
+    dev = results.device
+    cs_nt = torch.zeros(count, dtype=torch.int64, device=dev)
+    cs_p = torch.zeros(count, dtype=torch.int64, device=dev)
+    p_bits = seq_p.view(torch.int64)
+    for lo in range(first, first + count, block):
+        hi = min(first + count, lo + block)
+        rec = results[lo:hi]
+        m = rec[:, 24:26].contiguous().view(torch.int16).to(torch.int64).flatten() & 0xFFFF
+        m = m * (rec[:, 38] == 0)      # accepted pairs only
+        off = rec[:, 16:24].contiguous().view(torch.int64).flatten()
+        if seq_stride:
+            off = torch.arange(lo, hi, device=dev, dtype=torch.int64) * seq_stride
+        off = torch.where(m > 0, off, torch.zeros_like(off))
+        total = int(m.sum().item())
+        if total == 0:
+            continue
+        seg = torch.repeat_interleave(torch.arange(hi - lo, device=dev, dtype=torch.int64), m, output_size=total)
+        start = torch.cumsum(m, 0) - m
+        j = torch.arange(total, device=dev, dtype=torch.int64) - start[seg]
+        idx = off[seg] + j
+        w = j + 1
+        cs_nt[lo - first:hi - first].index_add_(0, seg, seq_nt[idx].to(torch.int64) * w)
+        cs_p[lo - first:hi - first].index_add_(0, seg, p_bits[idx] * w)
+    return cs_nt, cs_p
+
+
 def upload_batch(fwd, rev, flen, rlen, device="cuda:0", seq_stride=None, capacity=None):
     """numpy panda_qual rows -> DeviceBatch.  seq_stride=None picks strided output rows wide enough
     for any merge; seq_stride=0 selects the compact arena (capacity bases)."""

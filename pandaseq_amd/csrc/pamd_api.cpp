@@ -85,6 +85,7 @@ struct pamd_assembler {
 	bool primers_dirty = true;
 	unsigned long long *d_error = nullptr;
 	bool notp_never_finite = false;	// of the table image on the device (upload_tables)
+	bool tables_symmetric = false;	// matrices A and B of that image, bit for bit
 	unsigned long long *d_phase = nullptr;
 	void *hb_ptr[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };	// pamd_assemble_host staging
 	size_t hb_cap[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -431,6 +432,11 @@ static int upload_tables(pamd_assembler *a, hipStream_t st) {
 		for (size_t i = 0; i < img.size(); i++)
 			notp[i] = (img[i] > M_LN2) ? std::log1p(-std::exp(-img[i])) : std::log(-std::expm1(-img[i]));
 		HIP_TRY(hipMemcpy(a->d_notp, notp.data(), sizeof(double) * notp.size(), hipMemcpyHostToDevice));
+		a->tables_symmetric = true;
+		for (int qa = 0; qa < PAMD_NQ; qa++)
+			for (int qb = 0; qb < qa; qb++)
+				if (memcmp(&A[qa * PAMD_NQ + qb], &A[qb * PAMD_NQ + qa], 8) != 0 || memcmp(&B[qa * PAMD_NQ + qb], &B[qb * PAMD_NQ + qa], 8) != 0)
+					a->tables_symmetric = false;
 		a->notp_never_finite = true;
 		for (size_t i = 0; i < (a->algo == PAMD_ALGO_RDP_MLE ? img.size() : (size_t) PAMD_LT_C); i++)
 			if (i != (size_t) PAMD_LT_ZERO && std::isfinite(notp[i]))	// (the spare slot holds 0.0 and is no base's log-p)
@@ -617,6 +623,7 @@ static int assemble_device_impl(pamd_assembler *a, const pamd_batch *b, void *st
 		}
 	}
 	p.notp_never_finite = a->notp_never_finite ? 1 : 0;
+	p.tables_symmetric = a->tables_symmetric ? 1 : 0;
 	p.primer_qthr = 22;
 	p.primer_err_t = a->tabs.score_err[22];
 	p.primer_inv_err_t = 1.0 / p.primer_err_t;
@@ -760,21 +767,18 @@ static int assemble_device_impl(pamd_assembler *a, const pamd_batch *b, void *st
 		PamdKernelParams pf = p;
 		pf.defer_list = a->d_defer;
 		pf.defer_count = a->d_defer_count;
-		int fwaves = MAX_WAVES_PER_WG;
-		while (fwaves > 1 && pamd_fast_lds_bytes(pf, fwaves) > LDS_LIMIT)
-			fwaves--;
-		if (fwaves > waves && getenv("PAMD_MAX_WAVES"))
-			fwaves = waves;
-		size_t fwant = (b->n_pairs + (size_t) fwaves - 1) / (size_t) fwaves;
-		int fwgs = a->cu_count > 0 ? a->cu_count : 256;
-		if ((size_t) fwgs > fwant)
-			fwgs = (int) fwant;
-		rc = pamd_launch_fast(pf, fwgs, fwaves, pamd_fast_lds_bytes(pf, fwaves), stream);
+		int fwaves = 0, fwgs = 0;
+		size_t flds = 0;
+		int cap = MAX_WAVES_PER_WG;
+		if (getenv("PAMD_MAX_WAVES") && waves < cap)	// occupancy experiments only
+			cap = waves;
+		pamd_fast_geometry(pf, a->cu_count, LDS_LIMIT, cap, &fwgs, &fwaves, &flds);
+		rc = pamd_launch_fast(pf, fwgs, fwaves, flds, stream);
 		if (rc != PAMD_OK)
 			return rc;
 		a->last_wgs = fwgs;
 		a->last_waves = fwaves;
-		a->last_lds = (int) pamd_fast_lds_bytes(pf, fwaves);
+		a->last_lds = (int) flds;
 		p.pair_list = a->d_defer;
 		p.pair_count = a->d_defer_count;
 		p.arena_chunk = b->n_pairs >= 262144 ? 4096 : 1024;

@@ -83,17 +83,53 @@ struct Geo {
 static_assert(FK_NT % 16 == 0 && FK_T1 % 16 == 0 && FK_FLAGS % 16 == 0, "16-byte LDS accesses");
 static_assert(Lay<true>::T1 % 16 == 0 && Lay<true>::FLAGS % 16 == 0 && Lay<true>::R % 16 == 0, "16-byte LDS accesses");
 static_assert(Lay<true>::PIDX % 16 == 0 && Lay<true>::MC % 16 == 0 && Lay<true>::MK % 16 == 0 && Lay<true>::POST_END <= Geo<true, 9>::T3, "`-a` staging lies over the first two k-mer tables");
-template <int ALGO>
+__device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) {
+	return (unsigned) __umul24(a, b);	// (this ROCm's __umul24 yields a SIGNED value: a plain >> on it is an arithmetic shift)
+}
+// DENSE (round 5): five waves per SIMD instead of four.  One 16-wave workgroup per CU is what 36 KB of tables + 7.6 KB per
+// wave allow; the short geometry's kernels of the scorers whose matrices are symmetric (every one but uparse's; rdp_mle has
+// three of them and stays as it was) instead run TWO workgroups of ten waves per CU: the two matrices staged as lower
+// triangles (2 x 9 KB instead of 2 x 17.7 KB: tri_index()), a 512-slot first k-mer table (5.6 KB per wave), and a kernel
+// compiled for 96 vector registers -- 2 x (18.4 + 3.6 + 54.8) KB = 153.5 of 160 KB.  -DFK_DENSE=0 builds the round-4 geometry (A/B).
+#ifndef FK_DENSE
+#define FK_DENSE 0
+#endif
+template <int ALGO, bool LONG>
+__device__ __host__ constexpr bool dense_geo() {
+	return FK_DENSE != 0 && !LONG && ALGO != PAMD_ALGO_UPARSE && ALGO != PAMD_ALGO_RDP_MLE;
+}
+#ifndef FK_OPAQUE_NARROW
+#define FK_OPAQUE_NARROW 0
+#endif
+#ifndef FK_DENSE_WPE
+#define FK_DENSE_WPE 6
+#endif
+#ifndef FK_DENSE_NW
+#define FK_DENSE_NW 10
+#endif
+constexpr int FK_DENSE_WAVES = FK_DENSE_NW;	// per workgroup, two workgroups per CU
+constexpr unsigned FK_TRI = PAMD_NQ * (PAMD_NQ + 1) / 2;	// entries of a lower triangle
+constexpr unsigned FK_DLT_A = PAMD_LT_A, FK_DLT_B = PAMD_LT_A + FK_TRI, FK_DLT_END = FK_DLT_B + FK_TRI;	// the dense table image (doubles): score, err, A, B
+template <int ALGO, bool LONG = false>
 __device__ __host__ constexpr int t1_bits() {
-	return ALGO == PAMD_ALGO_RDP_MLE ? 9 : 10;	// (512 slots for every scorer: measured 2 % slower on config 1; for reads of at most 192 bases only, round 4: 1 % slower on config 4)
+	return (ALGO == PAMD_ALGO_RDP_MLE || dense_geo<ALGO, LONG>()) ? 9 : 10;	// (512 slots for every scorer in the 16-wave geometry: measured 2 % slower on config 1; for reads of at most 192 bases only, round 4: 1 % slower on config 4)
+}
+// entry (a, b) of a symmetric 47 x 47 matrix stored as its lower triangle: row max(a, b), column min(a, b)
+__device__ __forceinline__ unsigned tri_index(unsigned a, unsigned b) {
+	const unsigned hi = a > b ? a : b, lo = a > b ? b : a;
+	return (mul24(hi, hi + 1u) >> 1) + lo;
+}
+// the index, in the staged table image, of entry (a, b) of the "match" (A) or "mismatch" (B) matrix
+template <bool DENSE>
+__device__ __forceinline__ unsigned mat_index(bool match, unsigned a, unsigned b) {
+	if (DENSE)
+		return (match ? FK_DLT_A : FK_DLT_B) + tri_index(a, b);
+	return (match ? (unsigned) PAMD_LT_A : (unsigned) PAMD_LT_B) + a * PAMD_NQ + b;
 }
 
 // k-mer -> slot of table 1..4: bit fields of one 24-bit multiplicative hash (a second one for the rarely used last table)
 constexpr unsigned HASH_C = 0x9E3779u, HASH_C4 = 0x85EBCBu;
 
-__device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) {
-	return (unsigned) __umul24(a, b);	// (this ROCm's __umul24 yields a SIGNED value: a plain >> on it is an arithmetic shift)
-}
 template <int T1B>
 __device__ __forceinline__ unsigned slot1(unsigned k) {
 	return mul24(k, HASH_C) >> (32 - T1B);
@@ -906,14 +942,15 @@ __device__ __forceinline__ double score_share(const unsigned char *wb, const dou
 			const int fi = flen - ov + i, ri = rlen - 1 - i;
 			const unsigned ef = lds_read_u16(lF + 2u * (unsigned) fi), er = lds_read_u16(lR + 2u * (unsigned) ri);
 			const unsigned a = ef & 0xFFu, b = er & 0xFFu, qa = ef >> 8;
-			const unsigned base = (a & b) != 0 ? PAMD_LT_A : PAMD_LT_B;
+			const bool agree = (a & b) != 0;
+			constexpr bool DENSE = dense_geo<ALGO, std::is_same<L, Lay<true>>::value>();
 			if (ALGO == PAMD_ALGO_PEAR) {
 				// the second index is the FORWARD read's quality at the reverse index (algo_pear.c:52,54, sic); past the forward
 				// read the reference reads beyond the array: defined as quality 0 here
 				const unsigned qb = ri < flen ? lds_read_u16(lF + 2u * (unsigned) ri) >> 8 : 0u;
-				part += (a == 15u || b == 15u) ? nrb : lds_read_f64(lT + 8u * (base + qa * PAMD_NQ + qb));
+				part += (a == 15u || b == 15u) ? nrb : lds_read_f64(lT + 8u * mat_index<DENSE>(agree, qa, qb));
 			} else {
-				part += lds_read_f64(lT + 8u * (base + qa * PAMD_NQ + (er >> 8))) - nn;
+				part += lds_read_f64(lT + 8u * mat_index<DENSE>(agree, qa, er >> 8)) - nn;
 			}
 		}
 	}
@@ -1290,7 +1327,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	int seqlen = 0, bo = -1, examined = 0, mism = 0, degen = 0, phmin = 127;
 	bool slow = false;
 	const int minov = P.minoverlap;
-	constexpr int T1B = t1_bits<ALGO>();
+	constexpr int T1B = t1_bits<ALGO, LONG>();
+	constexpr bool DENSE = dense_geo<ALGO, LONG>();
 	typedef Geo<LONG, T1B> G;
 	unsigned *const t1 = reinterpret_cast<unsigned *>(wb + L::T1), *const t2 = reinterpret_cast<unsigned *>(wb + G::T2);
 	unsigned *const t3 = reinterpret_cast<unsigned *>(wb + G::T3), *const t4 = reinterpret_cast<unsigned *>(wb + G::T4);
@@ -1421,13 +1459,19 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			// when the previous pair used them)
 			static_assert((G::T3 - L::T1) % 1024u == 0 && (G::WAVE_BYTES - G::T3) / 16u <= 64u, "whole rounds of 64 lanes x 16 bytes");
 			uint4 *h = reinterpret_cast<uint4 *>(wb + L::T1) + lane;
+			unsigned e = EMPTY;
+			asm volatile("" : "+v"(e));	// (made here: hoisted out of the pair loop the four registers of the constant are spilled and reloaded per pair)
+			const uint4 e4 = make_uint4(e, e, e, e);
 #pragma unroll
 			for (unsigned i = 0; i < (G::T3 - L::T1) / 1024u; i++)
-				h[64u * i] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+				h[64u * i] = e4;
 			if (deep_dirty && lane < (int) ((G::WAVE_BYTES - G::T3) / 16u))
-				reinterpret_cast<uint4 *>(wb + G::T3)[lane] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
-			if (lane < (LONG ? 24 : 16))
-				reinterpret_cast<uint4 *>(flags)[lane] = make_uint4(0u, 0u, 0u, 0u);
+				reinterpret_cast<uint4 *>(wb + G::T3)[lane] = e4;
+			if (lane < (LONG ? 24 : 16)) {
+				unsigned z = 0u;
+				asm volatile("" : "+v"(z));	// (likewise)
+				reinterpret_cast<uint4 *>(flags)[lane] = make_uint4(z, z, z, z);
+			}
 			deep_dirty = false;
 		}
 		wave_sync();
@@ -1518,7 +1562,10 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		{
 			unsigned w, nw;	// base BPL*l + b at bits 2b..2b+1 of w, its N flag at bit 2b+1 of nw
 			if constexpr (WINDOWS) {
-				const int rb = 2 * BPL * lane;
+				int ln = lane;
+				if constexpr (DENSE)
+					asm volatile("" : "+v"(ln));	// (the window's address is the same for every pair: hoisted out of the pair loop it is spilled at 80 registers, and its reload waits for the next pair's rows)
+				const int rb = 2 * BPL * ln;
 				const unsigned *cw = reinterpret_cast<const unsigned *>(wb + L::RC) + (rb >> 5), *nwp = reinterpret_cast<const unsigned *>(wb + L::RN) + (rb >> 5);
 				const unsigned c0 = cw[0], c1 = cw[1], n0 = nwp[0], n1 = nwp[1];
 				w = __builtin_amdgcn_alignbit(c1, c0, (unsigned) rb & 31u);
@@ -1705,15 +1752,15 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 						const int fi = flen - ov + i, ri = rlen - 1 - i;
 						const unsigned ef = lds_read_u16(lF + 2u * (unsigned) fi), er = lds_read_u16(lR + 2u * (unsigned) ri);
 						const unsigned a = ef & 0xFFu, b = er & 0xFFu, qa = ef >> 8;
-						const unsigned base = (a & b) != 0 ? PAMD_LT_A : PAMD_LT_B;
+						const bool agree = (a & b) != 0;
 						double term;
 						if (ALGO == PAMD_ALGO_PEAR) {
 							// the second index is the FORWARD read's quality at the reverse index (algo_pear.c:52,54, sic);
 							// past the forward read the reference reads beyond the array: defined as quality 0 here
 							const unsigned qb = ri < flen ? lds_read_u16(lF + 2u * (unsigned) ri) >> 8 : 0u;
-							term = (a == 15u || b == 15u) ? nrb : lds_read_f64(lT + 8u * (base + qa * PAMD_NQ + qb));
+							term = (a == 15u || b == 15u) ? nrb : lds_read_f64(lT + 8u * mat_index<DENSE>(agree, qa, qb));
 						} else {
-							term = lds_read_f64(lT + 8u * (base + qa * PAMD_NQ + (er >> 8))) - nn;
+							term = lds_read_f64(lT + 8u * mat_index<DENSE>(agree, qa, er >> 8)) - nn;
 						}
 						if (EXACT)
 							ps[i] = term;
@@ -1959,9 +2006,10 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				const unsigned d = fq > rq ? fq - rq : rq - fq;
 				qi = PAMD_LT_SCORE + (match ? (fq > rq ? fq : rq) : (d < 2 ? 2 : d));
 			} else if (ALGO == PAMD_ALGO_RDP_MLE) {	// algo_rdp_mle.c:29-41
+				static_assert(ALGO != PAMD_ALGO_RDP_MLE || !DENSE, "rdp_mle's third matrix has no place in the dense image");
 				qi = match ? PAMD_LT_SCORE + (fq > rq ? fq : rq) : PAMD_LT_C + fq * PAMD_NQ + rq;
 			} else {	// algo_simple_bayes.c:68-75, algo_pear.c:61-68, algo_uparse.c:68-75, algo_stitch.c:59-67
-				qi = (match ? PAMD_LT_A : PAMD_LT_B) + fq * PAMD_NQ + rq;
+				qi = mat_index<DENSE>(match, fq, rq);
 			}
 			if (cliff) {
 				asm volatile("; B-cliff");	// (keeps this a branch: as selects it would cost every pair six instructions a round)
@@ -2229,16 +2277,12 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 }
 
 // PHRED: a min_phred module is loaded, the merge tracks the row's smallest log-p (plugin_min_phred.c:8-22)
-#ifdef FK_NO_W4	/* A/B builds only */
-#define FK_WAVES_ATTR
-#else
-#define FK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
-#endif
 // (one 16-wave workgroup fills a CU's LDS: four waves per SIMD whatever the registers allow, so the compiler is told to
 // spend all 128 vector registers on scheduling instead of saving them for waves that cannot come -- 1 % on a 16 M-pair
-// launch, nothing measurable at 50 M)
+// launch, nothing measurable at 50 M.  DENSE: two workgroups of ten waves, five waves per SIMD, 96 registers.)
 template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW, bool POST = false>
-__global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const PamdKernelParams P) {
+__global__ __launch_bounds__((dense_geo<ALGO, LONG>() ? 64 * FK_DENSE_WAVES : 1024)) __attribute__((amdgpu_waves_per_eu((dense_geo<ALGO, LONG>() ? FK_DENSE_WPE : 4), (dense_geo<ALGO, LONG>() ? FK_DENSE_WPE : 4))))
+void pamd_fast_kernel(const PamdKernelParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	double *ltab = reinterpret_cast<double *>(lds);
 	unsigned *lctr = reinterpret_cast<unsigned *>(lds + P.lds_ctr_off);
@@ -2247,12 +2291,23 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 	const int wave = uni(tid >> 6);
 	const int nwaves = blockDim.x >> 6;
 
-	for (unsigned i = tid; i < P.lds_table_doubles; i += blockDim.x)
-		ltab[i] = P.tables[i];
+	if constexpr (dense_geo<ALGO, LONG>()) {
+		// the two matrices as lower triangles (the host has checked that they are symmetric: pamd_launch_fast)
+		for (unsigned i = tid; i < PAMD_LT_A; i += blockDim.x)
+			ltab[i] = P.tables[i];
+		for (unsigned i = tid; i < 2u * PAMD_TAB; i += blockDim.x) {
+			const unsigned m = i >= PAMD_TAB ? 1u : 0u, e = i - m * PAMD_TAB, a = e / PAMD_NQ, b = e - a * PAMD_NQ;
+			if (a >= b)
+				ltab[(m ? FK_DLT_B : FK_DLT_A) + ((a * (a + 1u)) >> 1) + b] = P.tables[PAMD_LT_A + i];
+		}
+	} else {
+		for (unsigned i = tid; i < P.lds_table_doubles; i += blockDim.x)
+			ltab[i] = P.tables[i];
+	}
 	for (unsigned i = tid; i < PAMD_NUM_COUNTERS; i += blockDim.x)
 		lctr[i] = 0;
-	unsigned char *wb = lds + P.lds_primer_off + (size_t) wave * Geo<LONG, t1_bits<ALGO>()>::WAVE_BYTES;	// (the per-wave regions start where the general kernel keeps its primers)
-	unsigned char *places = lds + P.lds_primer_off + (size_t) nwaves * Geo<LONG, t1_bits<ALGO>()>::WAVE_BYTES;	// PHRED: 96 bytes behind the last wave's region (fk_phred_places)
+	unsigned char *wb = lds + P.lds_primer_off + (size_t) wave * Geo<LONG, t1_bits<ALGO, LONG>()>::WAVE_BYTES;	// (the per-wave regions start where the general kernel keeps its primers)
+	unsigned char *places = lds + P.lds_primer_off + (size_t) nwaves * Geo<LONG, t1_bits<ALGO, LONG>()>::WAVE_BYTES;	// PHRED: 96 bytes behind the last wave's region (fk_phred_places)
 	unsigned primer_bases = 0;	// PRIM: this lane's base of the forward primer | of the reverse primer << 8 (N past their ends) | << 16: lanes 0..31 the forward, lanes 32..63 the reverse primer's bases 0..31
 	// what lies before a read reads as N: the word before the forward N map (seed windows start eight bases early)
 	if (lane < 4)
@@ -2300,7 +2355,7 @@ __global__ __launch_bounds__(1024) FK_WAVES_ATTR void pamd_fast_kernel(const Pam
 		load_pair<LONG>(nxt, P, q, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
 		int lane_now = lane;
-		if constexpr (LONG || ALGO == PAMD_ALGO_EA_UTIL || ALGO == PAMD_ALGO_STITCH || !counting_algo<ALGO>()) {	// (the two table-scored counting scorers spill in the short geometry too; so do pear and rdp_mle, whose many-candidate scan is a call the hot path's registers have to survive)
+		if constexpr (LONG || ALGO == PAMD_ALGO_EA_UTIL || ALGO == PAMD_ALGO_STITCH || !counting_algo<ALGO>() || (dense_geo<ALGO, LONG>() && NARROW && FK_OPAQUE_NARROW)) {	// (the two table-scored counting scorers spill in the short geometry too; so do pear and rdp_mle, whose many-candidate scan is a call the hot path's registers have to survive)
 			// The compiler hoists everything that depends on the lane number alone out of this loop -- multiples, shifts,
 			// LDS addresses -- and, out of registers, spills it: a reload from scratch memory then waits, vmcnt being one
 			// in-order queue, for whatever went before it, the rows just requested for the next pair among them.  Made opaque
@@ -2373,10 +2428,35 @@ int pamd_fast_supports(const PamdKernelParams &p) {
 	return 0;
 }
 
-size_t pamd_fast_lds_bytes(const PamdKernelParams &p, int waves_per_wg) {
-	const bool rdp = p.algo == PAMD_ALGO_RDP_MLE;
-	const size_t wave = pamd_fast_supports(p) == PAMD_FAST_SHORT ? (rdp ? Geo<false, 9>::WAVE_BYTES : Geo<false, 10>::WAVE_BYTES) : (rdp ? Geo<true, 9>::WAVE_BYTES : Geo<true, 10>::WAVE_BYTES);
-	return (size_t) p.lds_primer_off + (size_t) waves_per_wg * wave + 96u;	// (+ the 96 bytes of fk_phred_places)
+// does this launch run the DENSE geometry (dense_geo<ALGO, LONG>(), decided per instantiation above)?
+static bool fast_dense(const PamdKernelParams &p) {
+	return FK_DENSE != 0 && pamd_fast_supports(p) == PAMD_FAST_SHORT && p.algo != PAMD_ALGO_UPARSE && p.algo != PAMD_ALGO_RDP_MLE;
+}
+
+// The launch geometry of the lean kernel for this configuration on a device of `cu_count` CUs: workgroups, waves per workgroup,
+// LDS bytes per workgroup -- and the LDS offsets of `p` set to what its kernel expects (the dense geometry's table image is
+// smaller than the one the general kernel's offsets are made for).
+void pamd_fast_geometry(PamdKernelParams &p, int cu_count, size_t lds_limit, int max_waves, int *workgroups, int *waves_per_wg, size_t *lds_bytes) {
+	const bool rdp = p.algo == PAMD_ALGO_RDP_MLE, dense = fast_dense(p);
+	const int cus = cu_count > 0 ? cu_count : 256;
+	if (dense) {
+		p.lds_table_doubles = FK_DLT_END;
+		p.lds_ctr_off = (FK_DLT_END * 8u + 15u) & ~15u;
+		p.lds_primer_off = (p.lds_ctr_off + PAMD_NUM_COUNTERS * 4u + 15u) & ~15u;
+	}
+	const size_t wave = pamd_fast_supports(p) == PAMD_FAST_SHORT ? ((rdp || dense) ? Geo<false, 9>::WAVE_BYTES : Geo<false, 10>::WAVE_BYTES) : (rdp ? Geo<true, 9>::WAVE_BYTES : Geo<true, 10>::WAVE_BYTES);
+	int waves = dense ? FK_DENSE_WAVES : max_waves;
+	while (waves > 1 && (size_t) p.lds_primer_off + (size_t) waves * wave + 96u > lds_limit / (dense ? 2 : 1))	// (+ the 96 bytes of fk_phred_places)
+		waves--;
+	if (waves > max_waves)
+		waves = max_waves;
+	size_t wgs = (size_t) cus * (dense ? 2 : 1);
+	const size_t want = ((size_t) p.n_pairs + (size_t) waves - 1) / (size_t) waves;
+	if (wgs > want)
+		wgs = want;
+	*workgroups = (int) wgs;
+	*waves_per_wg = waves;
+	*lds_bytes = (size_t) p.lds_primer_off + (size_t) waves * wave + 96u;
 }
 
 int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg, size_t lds_bytes, void *stream) {
@@ -2391,6 +2471,9 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 						   : variant == PAMD_FAST_SHORT ? (p.exact_sums ? FK_PICK3(A, PH, true) : FK_PICK3(A, PH, false)) \
 										: (p.exact_sums ? FK_PICK4(A, PH, true) : FK_PICK4(A, PH, false)))
 #define FK_PICK(A) (p.has_min_phred ? FK_PICK2(A, true) : FK_PICK2(A, false))
+#ifdef FK_DEV_ONE	/* development: one instantiation family, for quick compiles */
+	kern = narrow ? pamd_fast_kernel<PAMD_ALGO_SIMPLE_BAYES, false, false, false, false, true> : pamd_fast_kernel<PAMD_ALGO_SIMPLE_BAYES, false, false, false, false, false>;
+#else
 	switch (variant == 0 ? -1 : p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
 		kern = FK_PICK(PAMD_ALGO_SIMPLE_BAYES);
@@ -2417,10 +2500,15 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 		pamd_set_error("the lean kernel does not serve algorithm %d in this configuration", p.algo);
 		return PAMD_EINVAL;
 	}
+#endif	// FK_DEV_ONE
 #undef FK_PICK
 #undef FK_PICK2
 #undef FK_PICK3
 #undef FK_PICK4
+	if (fast_dense(p) && !p.tables_symmetric) {	// (every scorer's matrices but uparse's are: tests/test_oracle_cpu.py holds the generator to it)
+		pamd_set_error("the lean kernel's dense geometry needs symmetric matrices (algorithm %d)", p.algo);
+		return PAMD_EINVAL;
+	}
 	hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 	if (e0 != hipSuccess) {
 		pamd_set_error("hipFuncSetAttribute(%zu bytes LDS, lean kernel): %s", lds_bytes, hipGetErrorString(e0));

@@ -29,15 +29,26 @@ def _check(line, n_gpus, steps, warmup):
 
 
 def test_bench_single_gpu(built):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "300000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2", "--e2e-pairs", "400000"],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "300000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2", "--e2e-pairs", "400000", "--other-pairs", "200000"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _check(out.stdout.strip().splitlines()[-1], 1, 2, 1)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["cores"] >= 1 and c["matches_gpu_on_sample"] is True
+    # `cores` = CPUs the process may use, `threads` = pthreads run on them; the sample check looks at rows, not only at records
+    assert c["threads"] >= c["cores"] and c["cores"] <= c["effective_cores"]["used_for_efficiency"] + 0.5
+    assert c["sample_check"]["records"] is True and c["sample_check"]["rows"] is True and c["sample_check"]["accepted_rows"] > 0
+    # the other BASELINE.json configurations, timed by the same code, in the same record
+    o = d["other_configs"]
+    for k, lean in (("config2", "primers"), ("config3", "short"), ("config4", "short+narrow")):
+        assert "error" not in o[k], o[k]
+        assert o[k]["pairs_per_gpu"] == 200000 and o[k]["stat"]["count"] == 200000 and o[k]["pairs_per_s"] > 0 and 0 < o[k]["frac"] < 1 and o[k]["kernel_ms"] > 0
+        assert lean in o[k]["lean_kernel"].lower(), o[k]["lean_kernel"]
+    assert o["config3"]["rejected"][1] > 0 and o["config2"]["stat"]["nofp"] + o["config2"]["stat"]["norp"] >= 0
     e = d["end_to_end"]
     assert "error" not in e, e
     assert e["record_only"]["pairs"] == 400000 and e["record_only"]["pairs_per_s"] > 0 and e["every_base_read"]["ok"] > 0
+    assert e["panda_assembler_assemble_per_pair_host"]["device"] is False
 
 
 def test_bench_two_ranks_sharded(built):

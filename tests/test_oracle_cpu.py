@@ -447,3 +447,45 @@ def test_the_bench_kernels_do_not_spill(built, tmp_path):
         assert set(per_phase) <= {"prologue", "loop"}, (inst, per_phase)   # ("loop": the loop's end and, laid out behind it, the cold blocks)
     cold = re.findall(r"\.set \.L(\S*scan_manyILi0E\S*)\.num_vgpr, (\d+)", (tmp_path / "fast.s").read_text())
     assert len(cold) == 1 and int(cold[0][1]) <= 80, cold     # (56 when this was written, 65 since the uniform regions are no longer structurized)
+
+
+def test_row_checksums_two_ways(built):
+    """bench.py's at-scale row parity rests on two implementations of the same per-row checksums -- the oracle's
+    (po_row_checksums_mt, C, on the host) and the product's (pandaseq_amd.row_checksums, torch, where the rows lie) --: here both
+    run on the same rows on the CPU, rows in a compact arena in shuffled order, and must agree bit for bit with each other and
+    with the definition."""
+    import torch
+    import pandaseq_amd as pa
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    from pandaseq_amd._lib import RESULT_DTYPE
+    spec = synth.config_spec(1)
+    n = 1500
+    f, r, fl, rl = synth.generate_numpy(spec, 77, n)
+    cfg = po.make_config("simple_bayesian")
+    res, nt, p, _ = po.assemble_batch(cfg, f, r, fl, rl)
+    res2, o_nt, o_p = po.row_checksums(cfg, f, r, fl, rl, threads=3)
+    assert (res == res2).all()
+    # the rows into an arena, in an order that is not the pairs'
+    order = np.random.default_rng(5).permutation(n)
+    rec = np.zeros(n, dtype=RESULT_DTYPE)
+    for k in rec.dtype.names:
+        if k in res.dtype.names and k != "seq_offset":
+            rec[k] = res[k]
+    arena_nt = np.zeros(n * 512 + 64, dtype=np.uint8)
+    arena_p = np.zeros(n * 512 + 64, dtype=np.float64)
+    cur = 16
+    for i in order:
+        m = int(res["seq_len"][i]) if res["status"][i] == 0 else 0
+        rec["seq_offset"][i] = cur if m else 0xFFFFFFFFFFFFFFFF
+        arena_nt[cur:cur + m] = nt[i, :m]
+        arena_p[cur:cur + m] = p[i, :m]
+        cur += (m + 15) // 16 * 16
+    t_res = torch.from_numpy(rec.view(np.uint8).reshape(n, 48).copy())
+    a, q = pa.row_checksums(t_res, torch.from_numpy(arena_nt), torch.from_numpy(arena_p), first=100, count=1300, block=256)
+    assert np.array_equal(a.numpy().view(np.uint64), o_nt[100:1400]) and np.array_equal(q.numpy().view(np.uint64), o_p[100:1400])
+    i = int(np.nonzero(res["status"] == 0)[0][3])
+    m = int(res["seq_len"][i])
+    w = np.arange(1, m + 1, dtype=np.uint64)
+    assert int(o_nt[i]) == int((nt[i, :m].astype(np.uint64) * w).sum()) and int(o_p[i]) == int((p[i, :m].view(np.uint64) * w).sum(dtype=np.uint64))
+    assert int(o_nt[res["status"] != 0].sum()) == 0
