@@ -283,7 +283,11 @@ void pamd_compat_set_batch_pairs(size_t pairs);
  * with every decision guarded: statuses, overlaps, merged bases and per-base log-p bit-identical to the reference, `quality`
  * and `estimated_overlap_probability` within 1e-9 (diff.c:26-99 compares bases and log-p, never these two); 1 = in the
  * reference's own order, every output bit bit-identical, about a fifth slower.  PAMD_COMPAT_SUMS=exact in the environment
- * makes 1 the default of a process. */
+ * makes 1 the default of a process.  An assembler with a `check` module that runs on the host (a caller's callback, a plugin
+ * file) sums in the reference's order by itself -- such a callback may compare `quality` or the score with a threshold of its
+ * own -- unless any-order sums were asked for in so many words: this function called with 0, or PAMD_COMPAT_SUMS=fast; with
+ * min_phred / min_overlapbits BEHIND a host module (their verdict is then made on the host from those sums) always.  The
+ * library says so once on stderr when it applies. */
 void pamd_compat_set_exact_sums(int exact);
 /* Where panda_assembler_assemble() (pandaseq-assembler.h:137-163, assembler.c:368-383) assembles its ONE pair: 0 (default) = on
  * the caller's thread, through the algorithm class's overlap_probability / match_probability as the reference does (sums in the
@@ -294,9 +298,12 @@ void pamd_compat_set_per_pair_device(int device);
 /* The array form of panda_assembler_assemble() (pandaseq-assembler.h:137-163): n pairs through the batches of
  * panda_assembler_next() (up to 65536 pairs each, four in flight) instead of one at a time -- what a caller that already holds its pairs wants
  * (panda_diff's A/B loop, diff.c:26-99: INTEGRATION.md section 2).  `visit` is called for every pair, in order, with its record
- * (NULL when the pair did not assemble; valid during the call only, as panda_assembler_assemble's is until the next call);
+ * (NULL when the pair did not assemble; valid during the call only, as panda_assembler_assemble's is until the next call;
+ * since round 4 its `forward` / `reverse` point at the library's staged copies of the reads, not at the caller's arrays -- same
+ * bytes, same lifetime as the record);
  * counters, modules and the fail-alignment handler behave as if the pairs had been passed one by one.  Returns how many
- * pairs assembled. */
+ * pairs assembled.  An array of at most a few thousand pairs is one piece in one slot; longer ones use up to four slots, each
+ * with a device assembler of its own, made the first time they are needed. */
 typedef void (*PamdVisit) (size_t index, const panda_result_seq *result, void *user_data);
 size_t pamd_compat_assemble_many(PandaAssembler assembler, const panda_seq_identifier *ids, const panda_qual *const *forward, const size_t *forward_length, const panda_qual *const *reverse, const size_t *reverse_length, size_t n, PamdVisit visit, void *user_data);
 /* where panda_assembler_next() builds a record's panda_result[] rows: 0 (default) = helper threads, batch by batch, ahead of

@@ -128,6 +128,36 @@ void pamd_formatter_destroy(pamd_formatter *f);
 int pamd_format_device(pamd_formatter *f, int format, size_t n_pairs, const pamd_pair_result *results, const uint8_t *seq_nt, const double *seq_p, const pamd_seqid *ids, const char *hdr_text, char *out, size_t out_capacity, size_t *out_bytes, uint64_t *fixups, size_t max_fixups, size_t *n_fixups, void *stream);
 int pamd_format_last_kernel_ms(pamd_formatter *f, float *ms);
 
+/* ---- files in, file out ------------------------------------------------------------------------------
+ * The loop a PANDAseq front end runs around the three device stages, as one call: two FASTQ files -> parse -> assemble ->
+ * format -> one FASTA / FASTQ file.  It stands where main.c's chain stands -- a reader thread per input behind a queue
+ * (async.c:103-149), workers pulling pairs (pool.c:71-108, mux.c:132-161), a writer thread (writer.c) -- with the workers
+ * replaced by the device and the host reduced to keeping both directions of the PCIe link busy: reader threads pread() blocks
+ * of either file into pinned memory, a copier thread per file sends them up on a stream of its own, the calling thread gathers
+ * each chunk's text on the device (records straddle blocks; the unconsumed tail of a chunk is carried into the next), runs the
+ * stages and sends the text back in pieces, writer threads pwrite() the pieces.  Plain (uncompressed) files; the bytes written
+ * are those the reference's reader -> assembler -> output.c chain writes for the same input, in input order.
+ *   a        a configured assembler (algorithm, primers, modules ... as set by the caller); its counters are not touched:
+ *            the run's own are returned in stats->counters (PAMD_CTR_* of pandaseq_amd.h; as with pamd_fastq_parse_device,
+ *            subtract stats->dropped from COUNT and BADR for the reference's numbers)
+ *   options  pairs_per_chunk 0 = 1 000 000 (at most 3 000 000); qualmin 0 = 33; reader_threads / writer_threads 0 = 3 per file / 1 (writers of ONE file take turns on its lock)
+ *   stats    pairs = records handed to the assembler; stop_code = PAMD_FQ_* (PAMD_FQ_END: the input was read to its end) and
+ *            stop_record = the record the reader gave up at; seconds_setup = allocations and thread start, seconds_pump = the rest */
+typedef struct {
+	const char *forward_path, *reverse_path, *out_path;
+	int format;		/* PAMD_OUT_FASTA / PAMD_OUT_FASTQ */
+	int qualmin, policy;	/* as pamd_fastq_parser_create */
+	size_t pairs_per_chunk;
+	int reader_threads, writer_threads;
+} pamd_pipe_options;
+typedef struct {
+	uint64_t pairs, dropped, chunks, in_bytes, out_bytes, stop_record;
+	int32_t stop_code, reserved;
+	double seconds_setup, seconds_pump;
+	int64_t counters[PAMD_NUM_COUNTERS];
+} pamd_pipe_stats;
+int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_options *options, pamd_pipe_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,11 +94,15 @@ int compat_per_pair_device() {
 	return v;
 }
 std::atomic<int> g_exact_sums{-1};
+std::atomic<bool> g_fast_sums_asked{false};	// any-order sums asked for in so many words (push_config: a host `check` then does not force the reference's order)
+std::atomic<bool> g_forced_said{false};
 int compat_exact_sums() {
 	int v = g_exact_sums.load();
 	if (v < 0) {
 		const char *e = getenv("PAMD_COMPAT_SUMS");
 		v = (e != nullptr && strcmp(e, "exact") == 0) ? 1 : 0;
+		if (e != nullptr && strcmp(e, "fast") == 0)
+			g_fast_sums_asked.store(true);
 		g_exact_sums.store(v);
 	}
 	return v;
@@ -737,10 +741,20 @@ int push_config(PandaAssembler a) {
 	// of its own -- min_overlapbits behind a host module does, a caller's callback may --: the kernel's guard (a fused verdict
 	// within 1e-6 of its threshold is re-made from sums in the reference's order) does not reach it, so such an assembler sums
 	// in the reference's order throughout.
-	bool host_check = false;
-	for (size_t m = a->fused_prefix; m < a->modules.size(); m++)
-		host_check |= a->modules[m]->fused_kind != 0 || a->modules[m]->check != nullptr;
-	const int exact = (compat_exact_sums() || host_check) ? 1 : 0;
+	// Two cases.  min_phred / min_overlapbits behind a host module: the verdict is THIS library's, made on the host from the
+	// record's sums -- reference order always.  A caller's own `check`: reference order unless the caller has asked for any-order
+	// sums in so many words (pamd_compat_set_exact_sums(0) called, or PAMD_COMPAT_SUMS=fast): a callback that never looks at
+	// `quality` or the score pays a fifth of the device's rate for nothing otherwise.  Said once on stderr when it applies.
+	bool fused_behind_host = false, host_check = false;
+	for (size_t m = a->fused_prefix; m < a->modules.size(); m++) {
+		fused_behind_host |= a->modules[m]->fused_kind != 0;
+		host_check |= a->modules[m]->check != nullptr;
+	}
+	const bool forced = !compat_exact_sums() && (fused_behind_host || (host_check && !g_fast_sums_asked.load()));
+	if (forced && !g_forced_said.exchange(true))
+		fprintf(stderr, "pandaseq_amd: a check module runs on the host behind the device: sums in the reference's order for this assembler (%s)\n",
+			fused_behind_host ? "min_phred / min_overlapbits follows a host module" : "pamd_compat_set_exact_sums(0) or PAMD_COMPAT_SUMS=fast keeps any-order sums");
+	const int exact = (compat_exact_sums() || forced) ? 1 : 0;
 	for (pamd_assembler *d : a->devs) {
 		if (d == nullptr)
 			continue;
@@ -1974,6 +1988,7 @@ void pamd_compat_set_per_pair_device(int device) {
 
 void pamd_compat_set_exact_sums(int exact) {
 	g_exact_sums.store(exact ? 1 : 0);
+	g_fast_sums_asked.store(!exact);
 }
 
 #ifndef PAMD_WITH_REFERENCE_OBJECTS
@@ -2133,6 +2148,27 @@ static bool array_next(panda_seq_identifier *id, const panda_qual **forward, siz
 }
 }	// namespace
 
+// slots 0 .. count-1 exist, each with a device assembler of its own (a launch owns its assembler's deferred list); the ones
+// beyond stay unmade until a longer array or panda_assembler_next() wants them
+static void ensure_slots(PandaAssembler a, int count) {
+	for (int k = 0; k < count; k++) {
+		if (a->devs[k] == nullptr) {
+			a->devs[k] = pamd_assembler_create(a->device);
+			a->dev_dirty = true;
+			if (a->devs[k] == nullptr) {
+				fprintf(stderr, "pandaseq_amd: %s\n", pamd_last_error());
+				abort();
+			}
+		}
+		if (a->slots[k] == nullptr) {
+			if (k == 0)
+				g_streaming.fetch_add(1);
+			a->slots[k] = new pamd_slot;
+		}
+		a->slots[k]->dev = a->devs[k];
+	}
+}
+
 size_t pamd_compat_assemble_many(PandaAssembler a, const panda_seq_identifier *ids, const panda_qual *const *forward, const size_t *forward_length, const panda_qual *const *reverse, const size_t *reverse_length, size_t n, PamdVisit visit, void *user_data) {
 	// a pending prefetched batch of panda_assembler_next() shares the staging area: refuse to mix (as panda_assembler_assemble)
 	for (pamd_slot *sl : a->slots)
@@ -2162,24 +2198,14 @@ size_t pamd_compat_assemble_many(PandaAssembler a, const panda_seq_identifier *i
 	// four batches in flight (upload, kernels, index-coded download and expansion of different batches overlap), records handed
 	// back in order -- with the one difference that `visit` sees every pair, the ones that did not assemble as NULL.
 	// (Round 3 ran one synchronous upload / launch / download of full strided rows per batch: 1.0 M pairs/s.)
-	for (int k = 1; k < panda_assembler::NSLOT; k++)
-		if (a->devs[k] == nullptr) {
-			a->devs[k] = pamd_assembler_create(a->device);
-			a->dev_dirty = true;
-			if (a->devs[k] == nullptr) {
-				fprintf(stderr, "pandaseq_amd: %s\n", pamd_last_error());
-				abort();
-			}
-		}
-	if (a->slots[0] == nullptr) {
-		for (int k = 0; k < panda_assembler::NSLOT; k++) {
-			a->slots[k] = new pamd_slot;
-			a->slots[k]->dev = a->devs[k];
-		}
-		g_streaming.fetch_add(1);
-	}
-	for (int k = 0; k < panda_assembler::NSLOT; k++)
-		a->slots[k]->dev = a->devs[k];
+	// an array no longer than a batch is cut in NSLOT pieces, so that its upload, kernels, download and expansion overlap as well;
+	// a handful of pairs is one piece in one slot (round 4 made four slots and three more device assemblers for any n)
+	size_t batch = g_batch_pairs.load();
+	const size_t piece = (n + panda_assembler::NSLOT - 1) / panda_assembler::NSLOT;
+	if (piece < batch)
+		batch = piece < 4096 ? 4096 : piece;
+	const int ns = (int) std::min<size_t>(panda_assembler::NSLOT, std::max<size_t>(1, (n + batch - 1) / batch));
+	ensure_slots(a, ns);
 	array_source src = { ids, forward, reverse, forward_length, reverse_length, n, 0 };
 	const PandaNextSeq saved_next = a->next;
 	void *const saved_data = a->next_data;
@@ -2188,15 +2214,10 @@ size_t pamd_compat_assemble_many(PandaAssembler a, const panda_seq_identifier *i
 	a->next = array_next;
 	a->next_data = &src;
 	a->eof = false;
-	// an array no longer than a batch is cut in NSLOT pieces, so that its upload, kernels, download and expansion overlap as well
-	size_t batch = g_batch_pairs.load();
-	const size_t piece = (n + panda_assembler::NSLOT - 1) / panda_assembler::NSLOT;
-	if (piece < batch)
-		batch = piece < 4096 ? 4096 : piece;
-	for (int k = 0; k < panda_assembler::NSLOT; k++)
+	for (int k = 0; k < ns; k++)
 		slot_fill_and_submit(a, a->slots[k], batch);
 	size_t index = 0;
-	for (int cur = 0;; cur = (cur + 1) % panda_assembler::NSLOT) {
+	for (int cur = 0;; cur = (cur + 1) % ns) {
 		pamd_slot *s = a->slots[cur];
 		slot_wait(s);
 		if (s->n == 0)
@@ -2212,7 +2233,7 @@ size_t pamd_compat_assemble_many(PandaAssembler a, const panda_seq_identifier *i
 		s->pos = s->n;
 		slot_fill_and_submit(a, s, batch);
 	}
-	for (int k = 0; k < panda_assembler::NSLOT; k++) {	// nothing may be left in flight or half consumed
+	for (int k = 0; k < ns; k++) {	// nothing may be left in flight or half consumed
 		slot_wait(a->slots[k]);
 		a->slots[k]->n = a->slots[k]->pos = 0;
 	}
@@ -2242,13 +2263,8 @@ const panda_result_seq *panda_assembler_next(PandaAssembler a) {
 				return res;
 		}
 	}
-	if (a->slots[0] == nullptr) {
-		for (int k = 0; k < panda_assembler::NSLOT; k++) {
-			a->slots[k] = new pamd_slot;
-			a->slots[k]->dev = a->devs[k];
-		}
-		g_streaming.fetch_add(1);
-	}
+	if (a->slots[panda_assembler::NSLOT - 1] == nullptr)
+		ensure_slots(a, panda_assembler::NSLOT);
 	while (true) {
 		pamd_slot *s = a->slots[a->cur];
 		if (s->pos == s->n) {

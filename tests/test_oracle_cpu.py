@@ -4,6 +4,7 @@ import ctypes as C
 import glob
 import math
 import os
+import sys
 import re
 
 import numpy as np
@@ -445,6 +446,14 @@ def test_the_bench_kernels_do_not_spill(built, tmp_path):
             elif t.startswith("scratch_"):
                 per_phase[phase] = per_phase.get(phase, 0) + 1
         assert set(per_phase) <= {"prologue", "loop"}, (inst, per_phase)   # ("loop": the loop's end and, laid out behind it, the cold blocks)
+    # ... and, over EVERY instantiation of the file (tools/isa_hazards.py): nothing touches the destination of a bare LDS read
+    # (lds_read_u16_bare: a load the compiler's waitcnt insertion does not see) before its wait on any path of the kernel's
+    # control-flow graph, and nothing the compiler emits uses M0, which the parking code writes behind its back
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_hazards
+    assert isa_hazards.count_bare_reads(listing) > 1000
+    assert isa_hazards.scan_bare_reads(listing) == []
+    assert isa_hazards.scan_m0(listing) == []
     cold = re.findall(r"\.set \.L(\S*scan_manyILi0E\S*)\.num_vgpr, (\d+)", (tmp_path / "fast.s").read_text())
     assert len(cold) == 1 and int(cold[0][1]) <= 80, cold     # (56 when this was written, 65 since the uniform regions are no longer structurized)
 

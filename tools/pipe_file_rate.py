@@ -20,11 +20,13 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--pairs", type=int, default=2_000_000)
+    ap.add_argument("--pairs", type=int, default=32_000_000)
     ap.add_argument("--config", type=int, default=1)
     ap.add_argument("--chunk", type=int, default=1_000_000)
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--sink", default=None, help="write the output here instead of a file in --dir (e.g. /dev/null: the pump without the output file system)")
     args = ap.parse_args()
     import bench
     import bench_next
@@ -43,6 +45,8 @@ def main():
                                "-L", os.path.join(ROOT, "pandaseq_amd"), "-lpandaseq_amd", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
                                "-Wl,-rpath," + os.path.join(ROOT, "pandaseq_amd"), "-Wl,-rpath,/opt/rocm/lib"])
         pf, pr, po = (os.path.join(tmp, x) for x in ("f.fastq", "r.fastq", "out.fasta"))
+        if args.sink:
+            po = args.sink
         with open(pf, "wb") as fh:
             for _ in range(reps):
                 fh.write(ft)
@@ -51,15 +55,24 @@ def main():
                 fh.write(rt)
         in_bytes = os.path.getsize(pf) + os.path.getsize(pr)
         best = None
-        for _ in range(3):
+        runs = []
+        for _ in range(args.reps):
             t0 = time.perf_counter()
-            subprocess.check_call([exe, pf, pr, po, str(algo), "fasta", str(args.chunk)], timeout=1200)
+            text = subprocess.check_output([exe, pf, pr, po, str(algo), "fasta", str(args.chunk)], timeout=1800).decode()
             dt = time.perf_counter() - t0
-            best = dt if best is None or dt < best else best
-        out_bytes = os.path.getsize(po)
-    d = {"what": "tests/c/pamd_pipe.c, file -> file (FASTQ x 2 -> FASTA) on %s: process start to exit, library and device start-up included" % args.dir,
-         "config": args.config, "pairs": n, "pairs_per_chunk": args.chunk, "seconds": best, "pairs_per_s": n / best,
-         "input_bytes": in_bytes, "output_bytes": out_bytes, "input_GBps": in_bytes / best / 1e9}
+            f = [ln.split("\t") for ln in text.splitlines() if ln.startswith("PIPE")][0]
+            info = dict(zip(f[1::2], f[2::2]))
+            assert int(info["pairs"]) == n, (info, n)
+            runs.append({"process_seconds": dt, "setup_seconds": float(info["setup_s"]), "pump_seconds": float(info["pump_s"]), "chunks": int(info["chunks"])})
+            if best is None or dt < best["process_seconds"]:
+                best = runs[-1]
+        out_bytes = os.path.getsize(po) if not args.sink else None
+    d = {"what": "tests/c/pamd_pipe.c = pamd_pipe_run(), file -> file (FASTQ x 2 -> FASTA) on %s; `pairs_per_s`: process start to exit (library load, device start-up, "
+                 "allocation of the pinned blocks and thread start included); `pump_pairs_per_s`: first block read to last byte written" % args.dir,
+         "config": args.config, "pairs": n, "pairs_per_chunk": args.chunk, "seconds": best["process_seconds"], "pairs_per_s": n / best["process_seconds"],
+         "pump_seconds": best["pump_seconds"], "pump_pairs_per_s": n / best["pump_seconds"], "setup_seconds": best["setup_seconds"],
+         "input_bytes": in_bytes, "output_bytes": out_bytes, "input_GBps": in_bytes / best["process_seconds"] / 1e9, "pump_input_GBps": in_bytes / best["pump_seconds"] / 1e9,
+         "pump_output_GBps": out_bytes / best["pump_seconds"] / 1e9 if out_bytes else None, "sink": args.sink, "reader_threads_per_file": int(os.environ.get("PAMD_PIPE_READERS", 3)), "writer_threads": int(os.environ.get("PAMD_PIPE_WRITERS", 1)), "runs": runs}
     print(json.dumps(d))
     if args.out:
         with open(args.out, "w") as fh:

@@ -1,10 +1,5 @@
 mkdir -p gpurun_out/r05a
-
-T0=$(date +%s); python bench.py > gpurun_out/r05a/bench_default.json 2> gpurun_out/r05a/bench_default.err; echo "bench wall $(( $(date +%s) - T0 )) s"; tail -5 gpurun_out/r05a/bench_default.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r05a/bench_default.json').read().strip().splitlines()[-1])
-print(d['value']/1e6, d['roofline']['frac'], d['roofline']['kernel_ms_avg'])
-print(json.dumps(d.get('other_configs'), indent=0)[:3000])
-c=d['cpu_baseline']; print(c['value'], c['cores'], c['threads'], c['matches_gpu_on_sample'], c['sample_check'])
-PY
+python -m pytest tests/test_pipe_gpu.py -x -q -m gpu 2>&1 | tail -2
+timeout 1200 python tools/pipe_file_rate.py --pairs 64000000 --reps 2 --out gpurun_out/r05a/pipe_file_64m.json 2>&1 | tail -1 | cut -c1-1500
+timeout 1200 python tools/pipe_file_rate.py --pairs 64000000 --reps 2 --sink /dev/null --out gpurun_out/r05a/pipe_null_64m.json 2>&1 | tail -1 | cut -c1-1500
+PAMD_PIPE_READERS=5 timeout 1200 python tools/pipe_file_rate.py --pairs 64000000 --reps 2 --sink /dev/null --out gpurun_out/r05a/pipe_null_64m_r5.json 2>&1 | tail -1 | cut -c1-1500
