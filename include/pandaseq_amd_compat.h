@@ -25,6 +25,7 @@
 #ifndef PANDASEQ_AMD_COMPAT_H
 #define PANDASEQ_AMD_COMPAT_H
 
+#include <stdarg.h>
 #include <stdbool.h>
 #include <stddef.h>
 #include <stdio.h>
@@ -265,6 +266,41 @@ void panda_seqid_copy(const panda_seq_identifier *src, panda_seq_identifier *des
 void panda_seqid_xprint(const panda_seq_identifier *id, PandaPrintf xprintf, void *x);
 void panda_seqid_print(const panda_seq_identifier *id, FILE *file);
 const char *panda_seqid_str(const panda_seq_identifier *id);
+/* seqid.c:127-285: one header line (without its '@') -> the identifier; the mate number it carries (1; 2 or 3), 0 when it does not
+ * parse.  The host form of what the device parser does per record (pamd_io.hip parse_header): for a caller that holds single
+ * header strings.  `end_ptr` (may be NULL) receives where parsing stopped.  One difference, where the reference's behaviour is
+ * undefined: an instrument, run or flowcell field of 100 characters or more fails here; the reference writes past its 100-byte
+ * field for up to 101. */
+typedef enum { PANDA_IDFMT_UNKNOWN, PANDA_IDFMT_SRA, PANDA_IDFMT_CASAVA_1_4, PANDA_IDFMT_CASAVA_1_7, PANDA_IDFMT_EBI_SRA, PANDA_IDFMT_CASAVA_CONVERTED } PandaIdFmt;	/* pandaseq-common.h:188-195 */
+int panda_seqid_parse(panda_seq_identifier *id, const char *input, PandaTagging policy);
+int panda_seqid_parse_fail(panda_seq_identifier *id, const char *input, PandaTagging policy, PandaIdFmt *detected_format, const char **end_ptr);
+
+/* ---- the writer object and the two formatters of a result (pandaseq-writer.h:36-141, writer.c; pandaseq.h:293-304, output.c:85-126):
+ * what a caller of panda_assembler_next() does with a record, under the reference's names and signatures.  A writer gathers
+ * what a thread appends and hands it to its `write` callback, whole, when that thread commits (records of different threads
+ * never interleave, as with the reference's per-thread buffers).  panda_writer_open_file() writes plain files (bzip: NULL, no
+ * libbz2 here).  The batched formatter -- text made on the device for a whole batch -- is pamd_format_device()
+ * (pandaseq_amd_io.h); these are the per-record forms. ---- */
+typedef struct panda_writer *PandaWriter;	/* pandaseq-common.h:117 */
+typedef void (*PandaBufferWrite) (const char *buffer, size_t buffer_length, void *data);	/* pandaseq-common.h:449-453 */
+PandaWriter panda_writer_new(PandaBufferWrite write, void *write_data, PandaDestroy write_destroy);
+PandaWriter panda_writer_new_file(FILE *file);
+PandaWriter panda_writer_new_null(void);
+PandaWriter panda_writer_new_stderr(void);
+PandaWriter panda_writer_new_stdout(void);
+PandaWriter panda_writer_open_file(const char *filename, bool bzip);
+void panda_writer_append(PandaWriter writer, const char *format, ...);
+void panda_writer_append_c(PandaWriter writer, char c);
+void panda_writer_append_id(PandaWriter writer, const panda_seq_identifier *id);
+void panda_writer_append_v(PandaWriter writer, const char *format, va_list va);
+void panda_writer_commit(PandaWriter writer);
+void panda_writer_set_slave(PandaWriter writer, PandaWriter slave);
+PandaWriter panda_writer_get_slave(PandaWriter writer);
+void panda_writer_flush(PandaWriter writer);
+PandaWriter panda_writer_ref(PandaWriter writer);
+void panda_writer_unref(PandaWriter writer);
+bool panda_output_fasta(const panda_result_seq *sequence, PandaWriter writer);	/* ">id;%f\n<bases>\n", %f of exp(quality); nothing for an empty sequence */
+bool panda_output_fastq(const panda_result_seq *sequence, PandaWriter writer);	/* "@id;%f\n<bases>\n+\n<33 + panda_result_phred>\n" */
 int panda_api_version(void);		/* misc.c:33-36 */
 char const *panda_version(void);	/* misc.c:28-31 */
 

@@ -1953,6 +1953,323 @@ const char *panda_seqid_str(const panda_seq_identifier *id) {	// a buffer per th
 	return text;
 }
 
+// ---- seqid.c:127-285: one header string -> the identifier (the device parser's program, pamd_io.hip parse_header, for a
+// caller's single strings).  A field is a run of characters up to '\0' ':' '#' '/' ' ' (PARSE_CHUNK_MAYBE, seqid.c:136).
+extern "C++" {
+namespace {
+struct IdCursor {
+	const char **at;
+	bool at_end() const { return **at == '\0'; }
+	static bool ends(char c) { return c == '\0' || c == ':' || c == '#' || c == '/' || c == ' '; }
+	bool push() {	// PARSE_PUSH
+		if (at_end())
+			return false;
+		(*at)++;
+		return true;
+	}
+	bool integer(int &value) {	// PARSE_INT: digits only, the value wraps as a 32-bit integer
+		unsigned v = 0;
+		if (at_end())
+			return false;
+		for (; !ends(**at); (*at)++) {
+			if (**at < '0' || **at > '9')
+				return false;
+			v = 10u * v + (unsigned) (**at - '0');
+		}
+		value = (int) v;
+		return true;
+	}
+	bool text(char *target, size_t room) {	// PARSE_STR: a field that must not start at the terminator, shorter than its array
+		size_t n = 0;
+		if (at_end())
+			return false;
+		for (; !ends(**at); (*at)++) {
+			if (n + 1 >= room)
+				return false;
+			target[n++] = **at;
+		}
+		target[n] = '\0';
+		return true;
+	}
+	bool tag(panda_seq_identifier *id) {	// the tag chunk: may be empty, at most PANDA_TAG_LEN characters (seqid.c:221-226,269-274)
+		size_t n = 0;
+		id->tag[0] = '\0';
+		for (; !ends(**at); (*at)++) {
+			if (n >= PANDA_TAG_LEN)
+				return false;
+			id->tag[n++] = **at;
+			// (a tag of exactly PANDA_TAG_LEN characters ends in the structure's padding byte, as the reference's does: seqid.c:224)
+			static_assert(offsetof(panda_seq_identifier, tag) + PANDA_TAG_LEN < sizeof(panda_seq_identifier), "room for the terminator");
+			reinterpret_cast<char *>(id)[offsetof(panda_seq_identifier, tag) + n] = '\0';
+		}
+		return true;
+	}
+};
+}	// namespace
+}	// extern "C++"
+
+int panda_seqid_parse_fail(panda_seq_identifier *id, const char *input, PandaTagging policy, PandaIdFmt *detected_format, const char **end_ptr) {
+	const char *temp;
+	int value = 0;
+	if (end_ptr == nullptr)
+		end_ptr = &temp;
+	*end_ptr = input;
+	IdCursor c = { end_ptr };
+	auto policy_ok = [&]() { return policy == PANDA_TAG_OPTIONAL || policy == (id->tag[0] == '\0' ? PANDA_TAG_ABSENT : PANDA_TAG_PRESENT); };
+	auto four_ints = [&]() {	// lane, tile, x, y, each followed by its separator
+		int *field[4] = { &id->lane, &id->tile, &id->x, &id->y };
+		for (int *f : field) {
+			if (!c.integer(value) || !c.push())
+				return false;
+			*f = value;
+		}
+		return true;
+	};
+	if (strlen(input) > 3 && (input[0] == 'E' || input[0] == 'S') && input[1] == 'R' && input[2] == 'R') {	// Short Read Archive, seqid.c:157-172
+		if (detected_format != nullptr)
+			*detected_format = input[0] == 'S' ? PANDA_IDFMT_SRA : PANDA_IDFMT_EBI_SRA;
+		*end_ptr += 3;
+		panda_seqid_clear(id);
+		for (int field = 0; field < 2; field++) {	// PARSE_SRA_INT + PARSE_PUSH: <number>.<number>
+			unsigned v = 0;
+			for (; **end_ptr != '\0' && **end_ptr != '.' && **end_ptr != ' '; (*end_ptr)++) {
+				if (**end_ptr < '0' || **end_ptr > '9')
+					return 0;
+				v = 10u * v + (unsigned) (**end_ptr - '0');
+			}
+			if (!c.push())
+				return 0;
+			if (field == 0)
+				snprintf(id->instrument, sizeof id->instrument, "%cRR%d", (int) input[0], (int) v);
+			else
+				id->lane = (int) v;
+		}
+		return c.push() ? 1 : 0;
+	}
+	if (strchr(input, '/') != nullptr) {	// CASAVA 1.4-1.6, or 1.7 converted to it (six colons before any '#'), seqid.c:173-235
+		size_t colons = 0;
+		for (const char *p = input; *p != '\0' && *p != '#'; p++)
+			colons += *p == ':';
+		if (detected_format != nullptr)
+			*detected_format = colons == 6 ? PANDA_IDFMT_CASAVA_CONVERTED : PANDA_IDFMT_CASAVA_1_4;
+		if (colons != 6)
+			id->run[0] = id->flowcell[0] = '\0';
+		if (!c.text(id->instrument, sizeof id->instrument) || !c.push())
+			return 0;
+		if (colons == 6 && (!c.text(id->run, sizeof id->run) || !c.push() || !c.text(id->flowcell, sizeof id->flowcell) || !c.push()))
+			return 0;
+		if (!four_ints())
+			return 0;
+		id->tag[0] = '\0';
+		if (*(*end_ptr - 1) == '#' && (!c.tag(id) || !c.push()))
+			return 0;
+		if (!policy_ok())
+			return 0;
+		return c.integer(value) ? value : 0;
+	}
+	// CASAVA 1.7+, seqid.c:236-284: instrument:run:flowcell:lane:tile:x:y mate:filtered:control:tag
+	if (detected_format != nullptr)
+		*detected_format = PANDA_IDFMT_CASAVA_1_7;
+	if (!c.text(id->instrument, sizeof id->instrument) || !c.push() || !c.text(id->run, sizeof id->run) || !c.push() || !c.text(id->flowcell, sizeof id->flowcell) || !c.push())
+		return 0;
+	if (!four_ints())
+		return 0;
+	int mate = 0;
+	if (!c.integer(mate) || !c.push())
+		return 0;
+	if (c.at_end())	// "filtered": any chunk
+		return 0;
+	while (!IdCursor::ends(**end_ptr))
+		(*end_ptr)++;
+	if (!c.push() || !c.integer(value) || !c.push())	// control bits
+		return 0;
+	if (!c.tag(id) || !policy_ok())
+		return 0;
+	return mate;
+}
+
+int panda_seqid_parse(panda_seq_identifier *id, const char *input, PandaTagging policy) {
+	return panda_seqid_parse_fail(id, input, policy, nullptr, nullptr);
+}
+
+// ---- writer.c: the writer object.  What a thread appends is its own until it commits; a commit hands it to `write` whole ----
+struct panda_writer {
+	size_t refcnt = 1;
+	PandaBufferWrite write = nullptr;
+	void *write_data = nullptr;
+	PandaDestroy write_destroy = nullptr;
+	PandaWriter commit_slave = nullptr;
+	std::mutex lock;
+	unsigned long serial = 0;	// (a thread's pending text is kept under this, not under the address: a new writer at an old one's address starts empty)
+};
+extern "C++" {
+namespace {
+std::atomic<unsigned long> g_writer_serial{1};
+std::string &pending_of(PandaWriter w) {
+	static thread_local std::vector<std::pair<unsigned long, std::string>> mine;
+	for (auto &e : mine)
+		if (e.first == w->serial)
+			return e.second;
+	if (mine.size() >= 64)	// (writers come and go: the oldest entry makes room)
+		mine.erase(mine.begin());
+	mine.emplace_back(w->serial, std::string());
+	return mine.back().second;
+}
+void file_write(const char *buffer, size_t buffer_length, void *file) {
+	if (fwrite(buffer, 1, buffer_length, static_cast<FILE *>(file)) != buffer_length)
+		perror("writer");
+}
+void null_write(const char *, size_t, void *) {
+}
+void close_file(void *file) {
+	fclose(static_cast<FILE *>(file));
+}
+}	// namespace
+}	// extern "C++"
+
+PandaWriter panda_writer_new(PandaBufferWrite write, void *write_data, PandaDestroy write_destroy) {
+	PandaWriter w = new panda_writer;
+	w->write = write;
+	w->write_data = write_data;
+	w->write_destroy = write_destroy;
+	w->serial = g_writer_serial.fetch_add(1);
+	return w;
+}
+
+PandaWriter panda_writer_new_file(FILE *file) {
+	return panda_writer_new(file_write, file, close_file);
+}
+
+PandaWriter panda_writer_new_null(void) {
+	return panda_writer_new(null_write, nullptr, nullptr);
+}
+
+PandaWriter panda_writer_new_stderr(void) {
+	return panda_writer_new(file_write, stderr, nullptr);
+}
+
+PandaWriter panda_writer_new_stdout(void) {
+	return panda_writer_new(file_write, stdout, nullptr);
+}
+
+PandaWriter panda_writer_open_file(const char *filename, bool bzip) {
+	if (bzip) {
+		pamd_set_error("%s: bzip2 output is not supported here (no libbz2 in this build)", filename);
+		return nullptr;
+	}
+	FILE *file = fopen(filename, "w");
+	return file == nullptr ? nullptr : panda_writer_new_file(file);
+}
+
+void panda_writer_append_v(PandaWriter writer, const char *format, va_list va) {
+	char text[2048];	// (the reference's uncommitted buffer holds 2048 bytes: longer output is cut there too)
+	const int n = vsnprintf(text, sizeof text, format, va);
+	if (n > 0)
+		pending_of(writer).append(text, (size_t) n < sizeof text ? (size_t) n : sizeof text - 1);
+}
+
+void panda_writer_append(PandaWriter writer, const char *format, ...) {
+	va_list va;
+	va_start(va, format);
+	panda_writer_append_v(writer, format, va);
+	va_end(va);
+}
+
+void panda_writer_append_c(PandaWriter writer, char c) {
+	pending_of(writer).push_back(c);
+}
+
+void panda_writer_append_id(PandaWriter writer, const panda_seq_identifier *id) {
+	panda_seqid_xprint(id, reinterpret_cast<PandaPrintf>(panda_writer_append), writer);
+}
+
+void panda_writer_commit(PandaWriter writer) {
+	std::string &text = pending_of(writer);
+	if (!text.empty()) {
+		std::lock_guard<std::mutex> g(writer->lock);
+		writer->write(text.data(), text.size(), writer->write_data);
+	}
+	text.clear();
+	if (writer->commit_slave != nullptr)
+		panda_writer_commit(writer->commit_slave);
+}
+
+void panda_writer_flush(PandaWriter writer) {	// (nothing is held back past a commit here)
+	(void) writer;
+}
+
+PandaWriter panda_writer_get_slave(PandaWriter writer) {
+	return writer->commit_slave;
+}
+
+void panda_writer_set_slave(PandaWriter writer, PandaWriter slave) {	// writer.c:288-306: no cycles
+	for (PandaWriter check = slave; check != nullptr; check = check->commit_slave)
+		if (check == writer || check->commit_slave == writer)
+			return;
+	if (writer->commit_slave != nullptr)
+		panda_writer_unref(writer->commit_slave);
+	writer->commit_slave = panda_writer_ref(slave);
+}
+
+PandaWriter panda_writer_ref(PandaWriter writer) {
+	if (writer == nullptr)
+		return nullptr;
+	std::lock_guard<std::mutex> g(writer->lock);
+	writer->refcnt++;
+	return writer;
+}
+
+void panda_writer_unref(PandaWriter writer) {
+	if (writer == nullptr)
+		return;
+	size_t left;
+	{
+		std::lock_guard<std::mutex> g(writer->lock);
+		left = --writer->refcnt;
+	}
+	if (left == 0) {
+		if (writer->commit_slave != nullptr)
+			panda_writer_unref(writer->commit_slave);
+		if (writer->write_destroy != nullptr && writer->write_data != nullptr)
+			writer->write_destroy(writer->write_data);
+		delete writer;
+	}
+}
+
+// ---- output.c:85-126: one record as FASTA / FASTQ text ----
+bool panda_output_fasta(const panda_result_seq *sequence, PandaWriter writer) {
+	if (sequence->sequence_length == 0)
+		return true;
+	panda_writer_append_c(writer, '>');
+	panda_writer_append_id(writer, &sequence->name);
+	panda_writer_append(writer, ";%f", exp(sequence->quality));
+	panda_writer_append_c(writer, '\n');
+	std::string &text = pending_of(writer);
+	for (size_t it = 0; it < sequence->sequence_length; it++)
+		text.push_back(panda_nt_to_ascii(sequence->sequence[it].nt));
+	text.push_back('\n');
+	panda_writer_commit(writer);
+	return true;
+}
+
+bool panda_output_fastq(const panda_result_seq *sequence, PandaWriter writer) {
+	if (sequence->sequence_length == 0)
+		return true;
+	panda_writer_append_c(writer, '@');
+	panda_writer_append_id(writer, &sequence->name);
+	panda_writer_append(writer, ";%f", exp(sequence->quality));
+	panda_writer_append_c(writer, '\n');
+	std::string &text = pending_of(writer);
+	for (size_t it = 0; it < sequence->sequence_length; it++)
+		text.push_back(panda_nt_to_ascii(sequence->sequence[it].nt));
+	text.append("\n+\n");
+	for (size_t it = 0; it < sequence->sequence_length; it++)
+		text.push_back((char) (33 + panda_result_phred(&sequence->sequence[it])));
+	text.push_back('\n');
+	panda_writer_commit(writer);
+	return true;
+}
+
 int panda_api_version(void) {	// misc.c:33-36
 	return PANDA_API;
 }

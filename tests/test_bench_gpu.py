@@ -88,3 +88,27 @@ def test_bench_chunked_launches(built, cfg):
     assert runs[0]["config"]["launches_per_step"] == 1 and runs[1]["config"]["launches_per_step"] == 3
     assert runs[0]["stat"] == runs[1]["stat"] and runs[0]["stat_block_sha1"] == runs[1]["stat_block_sha1"]
     assert runs[0]["roofline"]["algorithmic_bytes_per_launch"] == runs[1]["roofline"]["algorithmic_bytes_per_launch"]
+
+
+def test_bench_two_ranks_over_rccl(built):
+    """The N>1 path as the driver launches it -- one rank per GPU, the STAT counters all-reduced over RCCL (backend "nccl") -- whenever
+    this machine has two devices; the gloo variant above covers the sharding and the reduction on one.  Skips, loudly, on a 1-GPU box."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip(f"RCCL over two ranks needs two GPUs; this box has {n_dev} (the gloo test above covers the N>1 path on one device)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PAMD_BENCH_SINGLE_DEVICE", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29578",
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--pairs", "400000", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = _check(lines[0], 2, 2, 1)
+    assert "RCCL" in d["config"]["sharding"]
+    single = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "800000", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e"],
+                            capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert single.returncode == 0, single.stderr[-2000:]
+    s = json.loads(single.stdout.strip().splitlines()[-1])
+    assert d["stat"] == s["stat"] and d["stat_block_sha1"] == s["stat_block_sha1"]

@@ -2,6 +2,8 @@
 Reference behaviour: module.c:227-298 (loading), :360-391 (getters), algo.c:96-133 (registry)."""
 import ctypes
 import os
+
+import numpy as np
 import subprocess
 
 import pytest
@@ -282,3 +284,159 @@ def test_device_selection_is_per_thread(built):
         [t.start() for t in ts]
         [t.join() for t in ts]
         assert out == [None] * 8
+
+
+# ---- the data-format rows under the reference's names: seqid.c:127-285, writer.c, output.c:85-126 ----
+def _lib_and_types():
+    import ctypes as C
+    from oracle import pyoracle as po
+    from pandaseq_amd import _lib
+    L = _lib.lib()
+    L.panda_seqid_parse_fail.restype = C.c_int
+    L.panda_seqid_parse_fail.argtypes = [C.POINTER(po.SeqId), C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
+    L.panda_seqid_parse.restype = C.c_int
+    L.panda_seqid_parse.argtypes = [C.POINTER(po.SeqId), C.c_char_p, C.c_int]
+    return L
+
+
+def _host_parse(L, header, policy):
+    import ctypes as C
+    from oracle import pyoracle as po
+    raw = header if isinstance(header, bytes) else header.encode("latin1")
+    buf = C.create_string_buffer(raw)
+    sid, fmt = po.SeqId(), C.c_int(-1)
+    end = C.c_char_p()
+    d = L.panda_seqid_parse_fail(C.byref(sid), C.cast(buf, C.c_char_p), policy, C.byref(fmt), C.byref(end))
+    end_off = C.cast(end, C.c_void_p).value - C.addressof(buf)
+    return d, fmt.value, sid, end_off
+
+
+def test_host_seqid_parse_on_the_reference_vectors(built):
+    """panda_seqid_parse_fail as a host function against the six cases of the reference's own parser test (check_parser.c:29-36)."""
+    import json
+    from oracle import pyoracle as po
+    L = _lib_and_types()
+    with open(os.path.join(ROOT, "tests", "golden", "seqid_check_parser.json")) as fh:
+        g = json.load(fh)
+    assert len(g["cases"]) == 6
+    for c in g["cases"]:
+        d, fmt, sid, end = _host_parse(L, c["header"], po.TAG_OPTIONAL)
+        assert d == c["dir"] and po.IDFMT[fmt] == c["format"] and list(sid.fields()) == c["id"], c["header"]
+        assert end == len(c["header"]) or c["format"] != "CASAVA_1_7"      # (a header parsed to its end stops at its end)
+        sid2 = po.SeqId()
+        assert L.panda_seqid_parse(sid2, c["header"].encode(), po.TAG_OPTIONAL) == c["dir"] and list(sid2.fields()) == c["id"]
+
+
+def test_host_seqid_parse_against_the_oracle(built):
+    """... and against the oracle's restatement on headers of every format, truncated at every length, with odd characters, over-long
+    fields and each tagging policy: the direction, the detected format, where parsing stopped, and -- where it parsed -- every field."""
+    from oracle import pyoracle as po
+    L = _lib_and_types()
+    rng = np.random.default_rng(3)
+    base = ["M01271:10:000000000-A3WGH:1:1101:18786:6175 1:N:0:1", "ILLUMINA-BE9C3F:29:FC:3:1:2462:1120 2:Y:18:GCTATA", "M00958:47:A3GH7:1:1101:15028:1512 3:N:0:",
+            "1468:1:1:12675:1118#ATCACGA/1", "HWUSI-EAS100R:6:73:941:1973#0/2", "HWUSI:6:73:941:1973/1", "MISEQ03:18:000000000-A1REG:1:1101:14774:1712#GATAGTGCCAC/1",
+            "SRR001666.1 071112_SLXA-EAS1_s_7:5:1:817:345 length=36", "ERR12.7 x/1", "SRR5", "SRRx.1 a", "ERR1.2", "", ":", "a:b:c:1:2:3:4 1:N:0:" + "ACGT" * 12 + "AC",
+            "a:b:c:1:2:3:4 1:N:0:" + "ACGT" * 13, "x" * 99 + ":r:f:1:2:3:4 1:N:0:T", "i:" + "y" * 99 + ":f:1:2:3:4 1:N:0:T", "i:r:f:99999999999:2:3:4 1:N:0:T",
+            "i:r:f:1:2:3:4 1:N:0", "i:r:f:1:2:3:4 1", "i:r:f:1:2:3:4 1:N:x:T", "i:1:2:3:4#" + "G" * 50 + "/1", "i:1:2:3:4#" + "G" * 51 + "/1", "i:1:2:3:4#/1", "i:1:2:3:4/"]
+    cases = []
+    for h in base:
+        cases.append(h)
+        for cut in range(0, len(h), 3):
+            cases.append(h[:cut])
+        for _ in range(6):
+            b = bytearray(h.encode())
+            if b:
+                b[int(rng.integers(0, len(b)))] = int(rng.choice(list(b":/# .0a-")))
+            cases.append(bytes(b).decode("latin1"))
+    checked = parsed = 0
+    for h in cases:
+        if any(len(f) >= 100 for f in h.split(" ")[0].split("#")[0].split("/")[0].split(":")[:3]):
+            # (fields of 100 characters or more: the reference writes past its 100-byte array; refused here, include/pandaseq_amd_compat.h)
+            assert _host_parse(L, h, po.TAG_OPTIONAL)[0] == 0 or not h.startswith(("x" * 99, "i:" + "y" * 99))
+            continue
+        for policy in (po.TAG_PRESENT, po.TAG_ABSENT, po.TAG_OPTIONAL):
+            d, fmt, sid, end = _host_parse(L, h, policy)
+            od, ofmt, osid, oend = po.seqid_parse(h, policy)
+            assert (d, fmt, end) == (od, ofmt, oend), (h, policy, (d, fmt, end), (od, ofmt, oend))
+            if d != 0:
+                assert sid.fields() == osid.fields(), h
+                parsed += 1
+            checked += 1
+    assert checked > 1000 and parsed > 150
+
+
+def test_writer_and_output_functions(built, tmp_path):
+    """panda_output_fasta / panda_output_fastq through a PandaWriter (pandaseq.h:293-304, output.c:85-126, writer.c): the bytes of the
+    oracle's formatter; a record reaches the write callback whole, at commit; an empty sequence writes nothing; slaves commit too."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    from pandaseq_amd import _lib, synth
+    L = _lib.lib()
+
+    class Result(C.Structure):
+        _fields_ = [("nt", C.c_char), ("p", C.c_double)]
+
+    class ResultSeq(C.Structure):
+        _fields_ = [("quality", C.c_double), ("degenerates", C.c_size_t), ("name", po.SeqId), ("sequence", C.POINTER(Result)), ("sequence_length", C.c_size_t),
+                    ("forward", C.c_void_p), ("forward_length", C.c_size_t), ("forward_offset", C.c_size_t), ("reverse", C.c_void_p), ("reverse_length", C.c_size_t),
+                    ("reverse_offset", C.c_size_t), ("overlap_mismatches", C.c_size_t), ("overlaps_examined", C.c_size_t), ("overlap", C.c_size_t), ("estimated_overlap_probability", C.c_double)]
+    assert C.sizeof(ResultSeq) == 480 and C.sizeof(po.SeqId) == 368
+    WRITE = C.CFUNCTYPE(None, C.POINTER(C.c_char), C.c_size_t, C.c_void_p)
+    chunks = []
+    cb = WRITE(lambda buf, n, data: chunks.append(C.string_at(buf, n)))
+    L.panda_writer_new.restype = C.c_void_p
+    L.panda_writer_new.argtypes = [WRITE, C.c_void_p, C.c_void_p]
+    L.panda_writer_new_null.restype = C.c_void_p
+    L.panda_writer_open_file.restype = C.c_void_p
+    L.panda_writer_open_file.argtypes = [C.c_char_p, C.c_bool]
+    for f in ("panda_writer_unref", "panda_writer_commit", "panda_writer_flush"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = None
+    L.panda_writer_set_slave.argtypes = [C.c_void_p, C.c_void_p]
+    L.panda_writer_set_slave.restype = None
+    L.panda_writer_get_slave.argtypes = [C.c_void_p]
+    L.panda_writer_get_slave.restype = C.c_void_p
+    for f in ("panda_output_fasta", "panda_output_fastq"):
+        getattr(L, f).argtypes = [C.POINTER(ResultSeq), C.c_void_p]
+        getattr(L, f).restype = C.c_bool
+    w = L.panda_writer_new(cb, None, None)
+    spec = synth.config_spec(1)
+    fwd, rev, fl, rl = synth.generate_numpy(spec, 9, 60)
+    res, nt, p, _ = po.assemble_batch(po.make_config("simple_bayesian"), fwd, rev, fl, rl)
+    want_a, want_q, n_ok = [], [], 0
+    for i in range(60):
+        if res["status"][i] != 0:
+            continue
+        m = int(res["seq_len"][i])
+        _, _, sid, _ = po.seqid_parse(f"M0{i}:7:FC:1:1101:{100 + i}:{7 * i} 1:N:0:ACGT")
+        rows = (Result * m)()
+        for j in range(m):
+            rows[j].nt = bytes([int(nt[i, j])])
+            rows[j].p = float(p[i, j])
+        rs = ResultSeq(quality=float(res["quality"][i]), name=sid, sequence=rows, sequence_length=m)
+        before = len(chunks)
+        assert L.panda_output_fasta(C.byref(rs), w) and len(chunks) == before + 1       # one write per committed record
+        assert chunks[-1] == po.output_fasta(sid, float(res["quality"][i]), nt[i, :m])
+        assert L.panda_output_fastq(C.byref(rs), w)
+        assert chunks[-1] == po.output_fastq(sid, float(res["quality"][i]), nt[i, :m], p[i, :m])
+        n_ok += 1
+    assert n_ok > 40
+    empty = ResultSeq(quality=-0.1, sequence_length=0)
+    before = len(chunks)
+    assert L.panda_output_fasta(C.byref(empty), w) and L.panda_output_fastq(C.byref(empty), w) and len(chunks) == before
+    # a file writer as slave of the callback writer: committing the master commits what was appended to the slave as well
+    path = tmp_path / "slave.txt"
+    fw = L.panda_writer_open_file(str(path).encode(), False)
+    assert fw and L.panda_writer_open_file(str(tmp_path / "x.bz2").encode(), True) is None
+    L.panda_writer_set_slave(w, fw)
+    assert L.panda_writer_get_slave(w) == fw
+    L.panda_writer_set_slave(fw, w)          # a cycle is refused (writer.c:288-306)
+    assert L.panda_writer_get_slave(fw) is None
+    L.panda_writer_append_c.argtypes = [C.c_void_p, C.c_char]
+    L.panda_writer_append.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.panda_writer_append_c(fw, b"#")
+    L.panda_writer_append(fw, b"%d\n", 42)
+    L.panda_writer_commit(w)
+    L.panda_writer_unref(fw)                 # (the master still holds it)
+    L.panda_writer_unref(w)                  # closes the file through the slave's destroy
+    assert path.read_bytes() == b"#42\n"
