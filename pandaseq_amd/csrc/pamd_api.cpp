@@ -92,6 +92,8 @@ struct pamd_assembler {
 	void *small_h = nullptr, *small_d = nullptr;	// pamd_assemble_host, a few pairs: one pinned block and its device twin
 	size_t small_cap = 0;
 	double *d_scratch = nullptr;	// parked score terms (pear / rdp_mle), sized for the largest launch so far
+	void *d_fast_scratch = nullptr;	// the lean kernel's rows of table indices (sums in the reference's order), likewise
+	size_t fast_scratch_bytes = 0;
 	size_t scratch_rows = 0;	// 10 words, only written by -DPAMD_PHASE_TIMING builds
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 	bool timed = false;
@@ -206,6 +208,8 @@ void pamd_assembler_destroy(pamd_assembler *a) {
 		(void) hipFree(a->d_phase);
 	if (a->d_scratch)
 		(void) hipFree(a->d_scratch);
+	if (a->d_fast_scratch)
+		(void) hipFree(a->d_fast_scratch);
 	if (a->d_defer)
 		(void) hipFree(a->d_defer);
 	if (a->d_primer_off)
@@ -773,6 +777,17 @@ static int assemble_device_impl(pamd_assembler *a, const pamd_batch *b, void *st
 		if (getenv("PAMD_MAX_WAVES") && waves < cap)	// occupancy experiments only
 			cap = waves;
 		pamd_fast_geometry(pf, a->cu_count, LDS_LIMIT, cap, &fwgs, &fwaves, &flds);
+		if (const size_t want = pamd_fast_scratch_bytes(pf, fwgs, fwaves)) {	// (a buffer of its own: the general kernel's second launch may use d_scratch)
+			if (want > a->fast_scratch_bytes) {
+				if (a->d_fast_scratch)
+					HIP_TRY(hipFree(a->d_fast_scratch));
+				a->d_fast_scratch = nullptr;
+				a->fast_scratch_bytes = 0;
+				HIP_TRY(hipMalloc(&a->d_fast_scratch, want));
+				a->fast_scratch_bytes = want;
+			}
+			pf.score_scratch = static_cast<double *>(a->d_fast_scratch);
+		}
 		rc = pamd_launch_fast(pf, fwgs, fwaves, flds, stream);
 		if (rc != PAMD_OK)
 			return rc;

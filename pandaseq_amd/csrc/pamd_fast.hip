@@ -1160,6 +1160,112 @@ __device__ __forceinline__ int fk_phred_of(const double *score, const unsigned c
 }
 
 
+// ---- sums in the reference's order without a second pass over the rows (round 5) -------------------------------------------
+// `quality` is three ordered chains over a row's log-probabilities (assembler.c:171,226,236: the forward-only bases, the overlap,
+// the reverse-only bases) and (f + r + o) / len (assembler.c:244).  A chain is a dependent sequence of additions: one lane's work,
+// and 63 lanes can walk 63 chains at once -- IF each finds its chain's values without a memory round trip per step.  Rounds 2-4
+// walked the rows themselves where the merge had put them, in HBM, sixty-four pairs later: 8 bytes per base read back, every lane
+// in another row (1.85x the algorithmic traffic, +32 % time at full size).  Now the merge also leaves each base's TABLE ENTRY (u16:
+// the log-p is an entry of the staged image; stored as its byte offset there) in a scratch row of this wave's -- FK_XG rows of
+// FK_XSTRIDE entries, 90-110 MB for the whole grid --, and every FK_XG pairs sixty-three lanes walk their three chains each from
+// there: two bytes per base, sixteen per load, a block of loads under way while the block before it is added up, the values from the
+// tables in LDS.  The result goes into the pair's parked record as its final quality (finish64's "q is final").
+// Measured (config 1, 50 M pairs): 555 -> 645 M pairs/s (+17 % over any-order sums instead of +32 %), L2 <-> fabric traffic 8 256 ->
+// 6 315 B per pair (1.85x -> 1.42x of the algorithmic bytes: the scratch rows, 10 MB per XCD, do not stay in its 4 MB L2; what
+// lies behind the fabric -- the 256 MB memory-side cache or HBM -- the counters cannot tell apart).  What the walk costs, by
+// ablation on 8 M pairs: the entry stores and the wait for them 1 %, the table reads and additions 11 % (five vector instructions
+// per element when first measured, three now), the loads' latency the rest -- 27 % with eight 2-byte loads per lane in flight, the
+// compiler waiting for each; 9 % with four 16-byte loads issued a block ahead.  Eight a block ahead cost the callee 120 registers and
+// the pair loop spills: slower than four.  Groups of 16 pairs (48 lanes): 630 M; of 21 (63 lanes, finish after 63 pairs): 640 M; the
+// reads' rows loaded with the nontemporal hint, so that they do not push the scratch rows out of the L2: 645 M.
+constexpr int FK_XG = 21;	// pairs per group: 3 x 21 chains in 63 lanes; three groups per finish (which then takes 63 pairs, not 64)
+template <bool LONG>
+constexpr unsigned fk_xstride() {
+	return (unsigned) Lay<LONG>::NR * 64u;	// indices per slot: every round of the merge writes its 64
+}
+struct GroupSums {
+	unsigned q_lo, q_hi;	// lane base + s: the quality of the group's s-th pair, if `done`
+	bool done;
+};
+// len_bo / pid / ro_st / off_*: the lane's parked fields (lane = slot of the wave's pending pairs); base: first slot of the group,
+// count: pairs in it.  Out of line: it runs once per FK_XG pairs and what it clobbers the pair loop does not keep across the call.
+template <bool LONG>
+__device__ __attribute__((noinline)) GroupSums exact_sums_group(unsigned lT, const uint16_t *xs, unsigned len_bo, unsigned pid, unsigned ro_st, unsigned off_lo, unsigned off_hi, int base, int count, int lane) {
+	constexpr unsigned XS = fk_xstride<LONG>();
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// this wave's index stores have left (a CU's vector L1 is coherent for its own stores)
+	const int chain = lane >= 2 * FK_XG ? 2 : (lane >= FK_XG ? 1 : 0), s = lane - FK_XG * chain;	// (lane 63: idle, reads as slot 0 of a fourth chain)
+	const int src = 4 * (base + s);	// ds_bpermute takes a byte address: lane * 4
+	const unsigned g_len_bo = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) len_bo), g_pid = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) pid);
+	const unsigned g_ro_st = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) ro_st);
+	const unsigned g_off = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) (off_lo & off_hi));	// all ones: the row found no room (the pair ends as NOSPACE)
+	const int seqlen = (int) (g_len_bo & 0xFFFFu), a0 = (int) (g_pid & 0xFFFFu), af = (int) (g_pid >> 16);
+	const bool valid = s < count && lane < 3 * FK_XG && ((g_ro_st >> 16) & 0xFFu) == (unsigned) PAMD_ST_OK && g_off != 0xFFFFFFFFu;
+	const int lo = !valid || chain == 0 ? 0 : (chain == 1 ? a0 : af), hi = chain == 0 ? a0 : (chain == 1 ? af : seqlen);
+	const int n = valid && hi > lo ? hi - lo : 0;
+	const int steps = wave_max_i32(n);
+	// Eight entries per 16-byte load (the chain starts at any entry: the loads are unaligned, which global loads may be), a block of
+	// FK_XD loads per lane under way while the block before it is added up: a lane's chain is a few hundred dependent additions
+	// behind a few dozen loads from lines the merge wrote some microseconds ago -- what it must not do is wait for each in turn.
+	// An entry is the byte offset of its value in the table image; a lane past its chain's end adds the image's spare 0.0.
+	typedef unsigned u32x4u __attribute__((ext_vector_type(4), aligned(2)));
+	typedef __attribute__((address_space(1))) const u32x4u gbl_cu128u;
+	gbl_cu128u *const row = (gbl_cu128u *) (xs + (unsigned) s * XS + (unsigned) lo);
+	constexpr int FK_XD = 4;
+	constexpr unsigned ZERO_OFF = 8u * PAMD_LT_ZERO;
+	const int nv = (n + 7) >> 3, last = nv > 0 ? nv - 1 : 0;	// (a lane past its chain's end re-reads the chain's last vector)
+	const int vsteps = (steps + 7) >> 3;
+	u32x4u nxt[FK_XD];
+#pragma unroll
+	for (int d = 0; d < FK_XD; d++)
+		nxt[d] = row[d < last ? d : last];
+	double acc = 0.0;
+	for (int k0 = 0; k0 < vsteps; k0 += FK_XD) {
+		u32x4u cur[FK_XD];
+#pragma unroll
+		for (int d = 0; d < FK_XD; d++)
+			cur[d] = nxt[d];
+		if (k0 + FK_XD < vsteps) {	// the next block's loads, all of them, before this block's additions
+#pragma unroll
+			for (int d = 0; d < FK_XD; d++)
+				nxt[d] = row[k0 + FK_XD + d < last ? k0 + FK_XD + d : last];
+		}
+#pragma unroll
+		for (int d = 0; d < FK_XD; d++) {
+			const int left = n - 8 * (k0 + d);	// entries of this vector that belong to the chain (<= 0: none)
+			double v[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) {
+				const unsigned w = u < 2 ? cur[d].x : (u < 4 ? cur[d].y : (u < 6 ? cur[d].z : cur[d].w));
+				const unsigned e = (u & 1) ? w >> 16 : w & 0xFFFFu;
+				v[u] = lds_read_f64(lT + (u < left ? e : ZERO_OFF));
+			}
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				acc += v[u];	// left to right: the reference's order (x + 0.0 is x)
+			__builtin_amdgcn_sched_barrier(0);	// (one vector's table reads at a time: hoisted together they take a hundred registers, which the caller then spills)
+		}
+	}
+	// lane s (chain 0) gathers its pair's other two sums; then lane base + s takes the quality
+	union {
+		double d;
+		int i[2];
+	} f, o, r, q;
+	f.d = acc;
+	o.i[0] = __builtin_amdgcn_ds_bpermute(4 * (s + FK_XG), f.i[0]);
+	o.i[1] = __builtin_amdgcn_ds_bpermute(4 * (s + FK_XG), f.i[1]);
+	r.i[0] = __builtin_amdgcn_ds_bpermute(4 * (s + 2 * FK_XG), f.i[0]);
+	r.i[1] = __builtin_amdgcn_ds_bpermute(4 * (s + 2 * FK_XG), f.i[1]);
+	q.d = (f.d + r.d + o.d) / (double) (seqlen + 1);	// assembler.c:244
+	// (lanes 0 .. FK_XG-1 hold the group's qualities; lane base + t of the parked records takes the t-th)
+	const int from = 4 * ((lane - base) & 63);
+	const int okv = __builtin_amdgcn_ds_bpermute(from, valid ? 1 : 0);	// (chain 0's verdict: the pair has a row)
+	GroupSums out;
+	out.q_lo = (unsigned) __builtin_amdgcn_ds_bpermute(from, q.i[0]);
+	out.q_hi = (unsigned) __builtin_amdgcn_ds_bpermute(from, q.i[1]);
+	out.done = lane >= base && lane < base + count && okv != 0;
+	return out;
+}
+
 template <bool LONG>
 struct Carry;
 template <>
@@ -1180,28 +1286,40 @@ __device__ __forceinline__ void settle(Carry<true> &c) {
 	asm volatile("" : "+v"(c.flen_v), "+v"(c.rlen_v), "+v"(c.f.x), "+v"(c.f.y), "+v"(c.f.z), "+v"(c.f.w), "+v"(c.r.x), "+v"(c.r.y), "+v"(c.r.z), "+v"(c.r.w));
 }
 
+// STREAM (sums in the reference's order): the rows are read once; with the nontemporal hint they leave the L2 to the scratch rows
+// of table indices, which are written and read back within a group of pairs (exact_sums_group)
+template <bool STREAM>
 __device__ __forceinline__ uint2 load_row(const uint8_t *row, unsigned row_bytes, int lane) {
 	unsigned off = (unsigned) lane * 8u;
 	off = off < row_bytes ? off : row_bytes - 8u;	// lanes past the row's end re-read its last bytes (rows are whole multiples of 16 B)
+	if (STREAM) {
+		const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(row + off));
+		return make_uint2(v.x, v.y);
+	}
 	return *reinterpret_cast<const uint2 *>(row + off);
 }
+template <bool STREAM>
 __device__ __forceinline__ uint4 load_row16(const uint8_t *row, unsigned row_bytes, int lane) {
 	unsigned off = (unsigned) lane * 16u;
 	off = off < row_bytes ? off : row_bytes - 16u;
+	if (STREAM) {
+		const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(row + off));
+		return make_uint4(v.x, v.y, v.z, v.w);
+	}
 	return *reinterpret_cast<const uint4 *>(row + off);
 }
 // (measured and not kept: the row's address made in the scalar ALU and the load given a scalar base -- the quarter-rate 64-bit
 // multiply-add per lane goes, a dozen more scalar registers spill into vector lanes, the rate does not move)
-template <bool LONG>
+template <bool LONG, bool STREAM = false>
 __device__ __forceinline__ void load_pair(Carry<LONG> &c, const PamdKernelParams &P, unsigned q, int lane) {
 	c.flen_v = P.flen[q];
 	c.rlen_v = P.rlen[q];
 	if constexpr (LONG) {
-		c.f = load_row16(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
-		c.r = load_row16(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
+		c.f = load_row16<STREAM>(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+		c.r = load_row16<STREAM>(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
 	} else {
-		c.f = load_row(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
-		c.r = load_row(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
+		c.f = load_row<STREAM>(P.fwd + (u64) q * P.fwd_row_bytes, P.fwd_row_bytes, lane);
+		c.r = load_row<STREAM>(P.rev + (u64) q * P.rev_row_bytes, P.rev_row_bytes, lane);
 	}
 }
 
@@ -1309,7 +1427,7 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 // NARROW (short geometry only): reads of at most 192 bases seed three bases per lane, on windows of the code streams
 // POST (LONG only, any-order sums): `-a`, the primers are looked for in the merged sequence and cut off it
 template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW, bool POST>
-__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, const unsigned char *places, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases) {
+__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, const unsigned char *places, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases, uint16_t *xs) {
 	typedef Lay<LONG> L;
 	constexpr int BPL = NARROW ? 3 : L::BPL;
 	constexpr bool WINDOWS = BPL != 4;	// k-mers from unaligned words of the code streams (else from the neighbouring lanes' registers)
@@ -1969,6 +2087,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		const unsigned nN = lN + (unsigned) lane;
 		// (explicitly global: through a generic pointer these would be flat_store, which every later LDS wait waits for as well)
 		gbl_f64 *const gP = (gbl_f64 *) (row_p + lane);
+		typedef __attribute__((address_space(1))) uint16_t gbl_u16;
+		gbl_u16 *const xsP = (gbl_u16 *) (xs + (unsigned) lane);	// (xs: this pair's scratch row)
 		lds_wait_all(ef);
 		lds_wait_all(er);
 		MARK("merge");
@@ -2054,6 +2174,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 						qacc += pv[k];
 				} else if (lane < lim - 64 * (R0 + k)) {
 					store_stream(&gP[64 * (R0 + k)], pv[k]);
+					if (EXACT)	// the base's table index for the ordered sums (exact_sums_group): a cached store, read back within FK_XG pairs
+						xsP[64 * (R0 + k)] = (uint16_t) (8u * qi[k]);	// (as the entry's byte offset in the image: 8 x 6 723 fits sixteen bits)
 					qacc += pv[k];
 					if (PHRED) {
 						// (a log-p at or below qual_score[0] loses its high word: what is left is a tiny positive number, which
@@ -2308,6 +2430,8 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 		lctr[i] = 0;
 	unsigned char *wb = lds + P.lds_primer_off + (size_t) wave * Geo<LONG, t1_bits<ALGO, LONG>()>::WAVE_BYTES;	// (the per-wave regions start where the general kernel keeps its primers)
 	unsigned char *places = lds + P.lds_primer_off + (size_t) nwaves * Geo<LONG, t1_bits<ALGO, LONG>()>::WAVE_BYTES;	// PHRED: 96 bytes behind the last wave's region (fk_phred_places)
+	// EXACT: this wave's scratch rows for the table indices of FK_XG pairs (exact_sums_group)
+	uint16_t *const xs = EXACT ? reinterpret_cast<uint16_t *>(P.score_scratch) + ((size_t) blockIdx.x * (size_t) nwaves + (size_t) wave) * (size_t) (FK_XG * fk_xstride<LONG>()) : nullptr;
 	unsigned primer_bases = 0;	// PRIM: this lane's base of the forward primer | of the reverse primer << 8 (N past their ends) | << 16: lanes 0..31 the forward, lanes 32..63 the reverse primer's bases 0..31
 	// what lies before a read reads as N: the word before the forward N map (seed windows start eight bases early)
 	if (lane < 4)
@@ -2342,9 +2466,9 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 	const unsigned last = n_pairs - 1u;
 	unsigned q = pair < n_pairs ? pair : last;
 	Carry<LONG> cur;
-	load_pair<LONG>(cur, P, q, lane);
+	load_pair<LONG, EXACT>(cur, P, q, lane);
 	settle(cur);
-	int npend = 0;
+	int npend = 0, xg = 0;	// pairs parked for finish64; of those, pairs of the current group of ordered sums (EXACT)
 	bool deep_dirty = true;	// the first pair clears all four tables
 	Pend64 pd = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
 	unsigned group_first = pair;
@@ -2352,7 +2476,7 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 		const unsigned next = pair + total_waves;
 		q = next < n_pairs ? next : last;
 		Carry<LONG> nxt;
-		load_pair<LONG>(nxt, P, q, lane);
+		load_pair<LONG, EXACT>(nxt, P, q, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
 		int lane_now = lane;
 		if constexpr (LONG || ALGO == PAMD_ALGO_EA_UTIL || ALGO == PAMD_ALGO_STITCH || !counting_algo<ALGO>() || (dense_geo<ALGO, LONG>() && NARROW && FK_OPAQUE_NARROW)) {	// (the two table-scored counting scorers spill in the short geometry too; so do pear and rdp_mle, whose many-candidate scan is a call the hot path's registers have to survive)
@@ -2362,18 +2486,31 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 			// here, the lane number's derivatives are recomputed where they are used (an instruction or two each).
 			asm volatile("" : "+v"(lane_now));
 		}
-		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST>(P, ltab, places, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases);
+		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST>(P, ltab, places, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases, EXACT ? xs + (unsigned) xg * fk_xstride<LONG>() : nullptr);
 		MARK("loop");
 		npend++;
-		if (npend == 64) {
-			finish64<false, true, EXACT>(P, lctr, pd, npend, group_first, total_waves, lane);
+		if (EXACT && ++xg == FK_XG) {	// sums in the reference's order: a group of pairs is complete
+			const GroupSums g = exact_sums_group<LONG>(lds_addr(ltab), xs, pd.len_bo, pd.pid, pd.ro_st, pd.off_lo, pd.off_hi, npend - FK_XG, FK_XG, lane);
+			pd.q_lo = g.done ? g.q_lo : pd.q_lo;
+			pd.q_hi = g.done ? g.q_hi : pd.q_hi;
+			pd.ro_st |= g.done ? 1u << 25 : 0u;	// "the quality is final"
+			xg = 0;
+		}
+		if (npend == (EXACT ? 3 * FK_XG : 64)) {
+			finish64<false, true, false>(P, lctr, pd, npend, group_first, total_waves, lane);
 			npend = 0;
 			group_first = next;
 		}
 		pair = next;
 	}
+	if (EXACT && xg != 0) {
+		const GroupSums g = exact_sums_group<LONG>(lds_addr(ltab), xs, pd.len_bo, pd.pid, pd.ro_st, pd.off_lo, pd.off_hi, npend - xg, xg, lane);
+		pd.q_lo = g.done ? g.q_lo : pd.q_lo;
+		pd.q_hi = g.done ? g.q_hi : pd.q_hi;
+		pd.ro_st |= g.done ? 1u << 25 : 0u;
+	}
 	if (npend > 0)
-		finish64<false, true, EXACT>(P, lctr, pd, npend, group_first, total_waves, lane);
+		finish64<false, true, false>(P, lctr, pd, npend, group_first, total_waves, lane);
 	__syncthreads();
 	if (P.counters != nullptr) {
 		for (unsigned i = tid; i < PAMD_NUM_COUNTERS; i += blockDim.x) {
@@ -2459,6 +2596,14 @@ void pamd_fast_geometry(PamdKernelParams &p, int cu_count, size_t lds_limit, int
 	*lds_bytes = (size_t) p.lds_primer_off + (size_t) waves * wave + 96u;
 }
 
+// bytes of PamdKernelParams::score_scratch the lean kernel wants for this launch (sums in the reference's order: FK_XG rows of
+// table indices per wave, exact_sums_group); 0 when it wants none
+size_t pamd_fast_scratch_bytes(const PamdKernelParams &p, int workgroups, int waves_per_wg) {
+	if (!p.exact_sums || pamd_fast_supports(p) == 0 || pamd_fast_supports(p) == PAMD_FAST_POST)
+		return 0;
+	return (size_t) workgroups * (size_t) waves_per_wg * (size_t) FK_XG * (size_t) fk_xstride<true>() * sizeof(uint16_t);
+}
+
 int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg, size_t lds_bytes, void *stream) {
 	const dim3 grid((unsigned) workgroups), block((unsigned) waves_per_wg * 64u);
 	hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2472,7 +2617,10 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 										: (p.exact_sums ? FK_PICK4(A, PH, true) : FK_PICK4(A, PH, false)))
 #define FK_PICK(A) (p.has_min_phred ? FK_PICK2(A, true) : FK_PICK2(A, false))
 #ifdef FK_DEV_ONE	/* development: one instantiation family, for quick compiles */
-	kern = narrow ? pamd_fast_kernel<PAMD_ALGO_SIMPLE_BAYES, false, false, false, false, true> : pamd_fast_kernel<PAMD_ALGO_SIMPLE_BAYES, false, false, false, false, false>;
+#ifndef FK_DEV_EXACT
+#define FK_DEV_EXACT false
+#endif
+	kern = narrow ? pamd_fast_kernel<PAMD_ALGO_SIMPLE_BAYES, FK_DEV_EXACT, false, false, false, true> : pamd_fast_kernel<PAMD_ALGO_SIMPLE_BAYES, FK_DEV_EXACT, false, false, false, false>;
 #else
 	switch (variant == 0 ? -1 : p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
@@ -2505,6 +2653,10 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 #undef FK_PICK2
 #undef FK_PICK3
 #undef FK_PICK4
+	if (pamd_fast_scratch_bytes(p, workgroups, waves_per_wg) > 0 && p.score_scratch == nullptr) {
+		pamd_set_error("the lean kernel's ordered sums need their scratch rows");
+		return PAMD_EINVAL;
+	}
 	if (fast_dense(p) && !p.tables_symmetric) {	// (every scorer's matrices but uparse's are: tests/test_oracle_cpu.py holds the generator to it)
 		pamd_set_error("the lean kernel's dense geometry needs symmetric matrices (algorithm %d)", p.algo);
 		return PAMD_EINVAL;
