@@ -182,7 +182,7 @@ int pamd_set_exact_sums(pamd_assembler *a, int exact);
 int pamd_set_fast_path(pamd_assembler *a, int enable);
 /* how many pairs of the most recent launch the lean kernel handed to the general one (synchronises); < 0 if none ran */
 long long pamd_last_deferred(pamd_assembler *a);
-/* which instantiation of the lean kernel served the most recent launch (a probe for tests and profiles):
+/* which instantiation of the lean kernel served the most recent launch (a probe for tests and profiles; DESIGN.md 3.1, docs/NOTEBOOK.md 3.1-3.1e):
  * 0 = none (the general kernel took the launch whole); else PAMD_LEAN_SHORT (reads of at most 256 bases), PAMD_LEAN_LONG (at
  * most 320), PAMD_LEAN_PRIMERS (the same with `-p` / `-q` primers or trims found inside it) or PAMD_LEAN_AFTER (`-a`), plus
  * PAMD_LEAN_NARROW when reads of at most 192 bases were seeded three bases per lane */

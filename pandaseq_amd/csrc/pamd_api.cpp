@@ -636,7 +636,7 @@ static int assemble_device_impl(pamd_assembler *a, const pamd_batch *b, void *st
 		if (a->modules[m].kind == 1)
 			p.has_min_phred = 1;
 
-	// LDS carve-up (DESIGN.md "LDS layout")
+	// LDS carve-up (docs/NOTEBOOK.md 3.2, "LDS carve-up")
 	const uint32_t smax = (uint32_t) (b->fwd_stride > b->rev_stride ? b->fwd_stride : b->rev_stride);
 	uint32_t mmax = 2 * smax;
 	if (mmax > 2 * PAMD_MAX_LEN)

@@ -123,7 +123,7 @@ __device__ __forceinline__ int primer_offset_scan(const double threshold, const 
 	constexpr bool logdomain = LOGDOMAIN;
 	bool close = false;
 	// bestpr = exp(primerlen * threshold); with a zero penalty every candidate is exp(x) of some x
-	// and exp is monotone, so we compare x (see DESIGN.md "exp in the primer scan").
+	// and exp is monotone, so we compare x (docs/NOTEBOOK.md 3.3).
 	double best = (double) plen * threshold;
 	if (!logdomain)
 		best = exp(best);

@@ -78,7 +78,7 @@ def test_primers_after_adversarial_with_modules(built, penalty):
 def test_primers_after_one_primer_and_trims(built, exact):
     """Only one primer set (the other side trimmed by a fixed count), and no primer at all (both trims
     applied to the merged sequence, assembler.c:311,322); trims that eat the whole sequence count as NOFP.
-    (exact: the general kernel's `-a`; any-order sums: the lean kernel's)"""
+    (exact: the general kernel's `-a`; any-order sums: the lean kernel's, DESIGN.md 3.1, docs/NOTEBOOK.md 3.1e)"""
     from pandaseq_amd import synth
     spec = synth.config_spec(2)
     fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 3000)
