@@ -2173,6 +2173,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 					if (lane < seqlen - 64 * (R0 + k))
 						qacc += pv[k];
 				} else if (lane < lim - 64 * (R0 + k)) {
+					// (measured and not kept, round 5: the lanes between the row's end and the end of its last 16-base unit storing 0.0,
+					// so that the row's last cache line leaves whole: reads unchanged, 47 more bytes written per pair, -2 % -- the extra
+					// select per round costs more than partial lines do)
 					store_stream(&gP[64 * (R0 + k)], pv[k]);
 					if (EXACT)	// the base's table index for the ordered sums (exact_sums_group): a cached store, read back within FK_XG pairs
 						xsP[64 * (R0 + k)] = (uint16_t) (8u * qi[k]);	// (as the entry's byte offset in the image: 8 x 6 723 fits sixteen bits)

@@ -97,6 +97,41 @@ def test_reader_stops_where_the_reference_stops(pipe, tmp_path):
     assert got == want and stop == (st2.stop_code, 1100)
 
 
+def test_pump_with_unequal_files(pipe, tmp_path):
+    """What pamd_pipe_run() gathers on the device, chunk after chunk, when the two files do not move in step: forward reads of
+    ~300 bases against reverse reads of ~60 (the forward text is consumed four times as fast as the reverse: the reverse side's
+    unconsumed tail grows with every block until the gathers balance it), small chunks, many blocks; then a forward file with
+    more records than the reverse one (the reader stops where the shorter file ends, fastq.c:123,130); then empty files."""
+    rng = np.random.default_rng(11)
+    n = 9000
+    fo, ro = [], []
+    for i in range(n):
+        h = f"@M1:7:FC:1:{1101 + i % 40}:{i}:{7 * i % 9973}"
+        lf, lr = int(rng.integers(280, 301)), int(rng.integers(40, 80))
+        for hh, ln, dst in ((h + " 1:N:0:ACGT", lf, fo), (h + " 2:N:0:ACGT", lr, ro)):
+            seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=ln).tobytes()
+            dst.append(hh.encode() + b"\n" + seq + b"\n+\n" + bytes([int(q) for q in rng.integers(35, 74, size=ln)]) + b"\n")
+    ft, rt = b"".join(fo), b"".join(ro)
+    for chunk in (300, 2500):
+        got, stat, stop = _run(pipe, tmp_path, ft, rt, "simple_bayesian", "fasta", chunk)
+        want, ctr, st = _oracle_text(ft, rt, "simple_bayesian", "fasta")
+        assert got == want and stat["READS"] == int(ctr["count"]) == n and stop == (0, 0), chunk
+    # 500 forward records without a mate: nothing of them is assembled, nothing fails
+    cut = b"".join(ro[:n - 500])
+    got, stat, stop = _run(pipe, tmp_path, ft, cut, "simple_bayesian", "fasta", 1000)
+    want, ctr, st = _oracle_text(ft, cut, "simple_bayesian", "fasta")
+    assert got == want and stat["READS"] == n - 500 == int(ctr["count"]) and stop == (0, 0)
+    # ... and a reverse file that ends inside a record
+    part = cut[:-30]
+    got, stat, stop = _run(pipe, tmp_path, ft, part, "simple_bayesian", "fasta", 1000)
+    want, ctr, st = _oracle_text(ft, part, "simple_bayesian", "fasta")
+    assert got == want and stat["READS"] == int(ctr["count"]) == n - 501
+    got, stat, stop = _run(pipe, tmp_path, b"", b"", "simple_bayesian", "fasta", 1000)
+    assert got == b"" and stat["READS"] == 0 and stop == (0, 0)
+    got, stat, stop = _run(pipe, tmp_path, ft, b"", "pear", "fastq", 1000)
+    assert got == b"" and stat["READS"] == 0
+
+
 # ---- the reference's own file-level API: panda_assembler_open() + panda_assembler_next() ------------------
 @pytest.fixture(scope="module")
 def open_client(built, tmp_path_factory):
