@@ -2176,6 +2176,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 					// (measured and not kept, round 5: the lanes between the row's end and the end of its last 16-base unit storing 0.0,
 					// so that the row's last cache line leaves whole: reads unchanged, 47 more bytes written per pair, -2 % -- the extra
 					// select per round costs more than partial lines do)
+					// (measured, round 5: the same launch writing a u16 table entry per base instead of the f64 -- a quarter of the row's
+					// bytes -- is no faster at 8 M pairs and 8 % SLOWER at 50 M: the kernel is bound by vector issue, not by what it writes)
 					store_stream(&gP[64 * (R0 + k)], pv[k]);
 					if (EXACT)	// the base's table index for the ordered sums (exact_sums_group): a cached store, read back within FK_XG pairs
 						xsP[64 * (R0 + k)] = (uint16_t) (8u * qi[k]);	// (as the entry's byte offset in the image: 8 x 6 723 fits sixteen bits)
