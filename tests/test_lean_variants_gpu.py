@@ -58,3 +58,64 @@ def test_what_the_lean_kernel_does_not_serve(built):
     assert asm.last_lean_variant() == "general"
     asm, _ = _run(1, tweak=lambda a: (a.set_forward_trim(7), a.set_reverse_trim(3)))
     assert asm.last_lean_variant() == "primers"     # trims are served by the primers' instantiation
+
+
+ALGOS = ["simple_bayesian", "pear", "rdp_mle", "uparse", "flash", "ea_util", "stitch"]
+# geometry -> (config whose data selects it, expected instantiation name, what to set)
+GEOMETRIES = {
+    "short": (1, "short", None),
+    "narrow": (4, "short+narrow", None),
+    "long": (2, "long", None),                                     # 2x300 reads without primers or trims
+    "prim": (2, "primers", "primers"),
+    "post": (2, "after", "after"),
+}
+
+
+@pytest.mark.parametrize("geometry", list(GEOMETRIES))
+@pytest.mark.parametrize("algo", ALGOS)
+def test_every_instantiation_of_the_lean_kernel(built, algo, geometry):
+    """pamd_fast.hip is compiled with its own flags (-Os, uniform regions left unstructurized: Makefile FAST_FLAGS) into 126
+    instantiations -- seven scorers x {any-order, reference-order sums} x {with, without min_phred} x {short, narrow, long, primers},
+    and `-a` x seven x two.  Each of them, on data that selects it: the instantiation the launch reports, and records, rows and
+    counters of the two-kernel launch equal to the general kernel's alone and to the oracle's."""
+    import torch
+    import pandaseq_amd as pa
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import compare_counters, compare_results
+    cfg, want, extra = GEOMETRIES[geometry]
+    spec = synth.config_spec(cfg)
+    n = 3000
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 4242, n)
+    if algo == "pear":
+        rlen = np.minimum(rlen, flen)
+    fp = rp = None
+    if cfg == 2:
+        fp, rp = synth.nt_codes(spec.fprimer), synth.nt_codes(spec.rprimer, complement=True)
+    for exact in ((False,) if geometry == "post" else (False, True)):
+        for phred in (False, True):
+            okw = {}
+            if extra:
+                okw = dict(fprimer=fp, rprimer=rp, primers_after=extra == "after")
+            if phred:
+                okw["modules"] = [("min_phred", 2)]
+            o_res, o_nt, o_p, o_ctr = po.assemble_batch(po.make_config(algo, **okw), fwd, rev, flen, rlen)
+            for fast in (True, False):
+                asm = pa.Assembler(0)
+                asm.set_algorithm(algo)
+                asm.set_exact_sums(exact)
+                asm.set_fast_path(fast)
+                if extra:
+                    asm.set_primers_after(extra == "after")
+                    asm.set_forward_primer(fp)
+                    asm.set_reverse_primer(rp)
+                if phred:
+                    asm.add_module("min_phred:2")
+                b = pa.upload_batch(fwd, rev, flen, rlen, device="cuda:0", seq_stride=0, capacity=n * 640 + (1 << 25))
+                asm.assemble_device(b)
+                torch.cuda.synchronize()
+                asm.check_overflow()
+                assert asm.last_lean_variant() == (want if fast else "general"), (algo, geometry, exact, phred, asm.last_lean_variant())
+                compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), o_res, o_nt, o_p, exact_sums=exact)
+                compare_counters(b.counters_dict(), o_ctr)
