@@ -1195,10 +1195,11 @@ __device__ __attribute__((noinline)) GroupSums exact_sums_group(unsigned lT, con
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// this wave's index stores have left (a CU's vector L1 is coherent for its own stores)
 	const int chain = lane >= 2 * FK_XG ? 2 : (lane >= FK_XG ? 1 : 0), s = lane - FK_XG * chain;	// (lane 63: idle, reads as slot 0 of a fourth chain)
 	const int src = 4 * (base + s);	// ds_bpermute takes a byte address: lane * 4
-	const unsigned g_len_bo = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) len_bo), g_pid = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) pid);
+	const unsigned g_pid = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) pid);
+	(void) len_bo;
 	const unsigned g_ro_st = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) ro_st);
 	const unsigned g_off = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) (off_lo & off_hi));	// all ones: the row found no room (the pair ends as NOSPACE)
-	const int seqlen = (int) (g_len_bo & 0xFFFFu), a0 = (int) (g_pid & 0xFFFFu), af = (int) (g_pid >> 16);
+	const int a0 = (int) (g_pid & 0x3FFu), af = (int) ((g_pid >> 10) & 0x3FFu), seqlen = (int) (g_pid >> 20);	// (the merge's length: `-a` has clipped the record's)
 	const bool valid = s < count && lane < 3 * FK_XG && ((g_ro_st >> 16) & 0xFFu) == (unsigned) PAMD_ST_OK && g_off != 0xFFFFFFFFu;
 	const int lo = !valid || chain == 0 ? 0 : (chain == 1 ? a0 : af), hi = chain == 0 ? a0 : (chain == 1 ? af : seqlen);
 	const int n = valid && hi > lo ? hi - lo : 0;
@@ -1425,7 +1426,8 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 
 // LONG: the geometry (Lay<LONG>).  PRIM (LONG only): primers (`-p` / `-q`, found by primer_quick) or trims are configured.
 // NARROW (short geometry only): reads of at most 192 bases seed three bases per lane, on windows of the code streams
-// POST (LONG only, any-order sums): `-a`, the primers are looked for in the merged sequence and cut off it
+// POST (LONG only): `-a`, the primers are looked for in the merged sequence and cut off it (reference-order sums since round 5:
+// `quality` is the whole merge's, assembler.c:244 precedes the clipping, and comes from the group walk like any other row's)
 template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW, bool POST>
 __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, const unsigned char *places, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases, uint16_t *xs) {
 	typedef Lay<LONG> L;
@@ -1433,11 +1435,11 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	constexpr bool WINDOWS = BPL != 4;	// k-mers from unaligned words of the code streams (else from the neighbouring lanes' registers)
 	static_assert(!NARROW || !LONG, "three bases per lane belong to the short geometry");
 	static_assert(!PRIM || LONG, "primers and trims are served by the LONG geometry");
-	static_assert(!POST || (LONG && !PRIM && !EXACT), "`-a` is served by the LONG geometry, with any-order sums");
+	static_assert(!POST || (LONG && !PRIM), "`-a` is served by the LONG geometry");
 	const auto fv = cur.f, rv = cur.r;
 	bool rotated = false;
 	int fo = 0, ro = 0;	// bases clipped from the reads' 5' ends (primers, trims): assembler.c:262-288
-	int region_a0 = 0, region_af = 0;	// the merged row's overlap region, for the exact finish
+	int region_a0 = 0, region_af = 0, region_len = 0;	// the merged row's overlap region and length, for the ordered sums
 	bool primers_known = false;
 	int status = PAMD_ST_OK;
 	u64 off = ~0ull;
@@ -2084,6 +2086,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		const int AF = PRIM ? A0 + novl + (A < 0 ? A : 0) + (Bn < 0 ? Bn : 0) : A + novl;	// ... and ends here (assembler.c:181)
 		region_a0 = A0;
 		region_af = AF;
+		region_len = A + novl + Bn;	// (= seqlen; `-a` clips seqlen later, the chains and the divisor are the whole merge's)
 		const unsigned nN = lN + (unsigned) lane;
 		// (explicitly global: through a generic pointer these would be flat_store, which every later LDS wait waits for as well)
 		gbl_f64 *const gP = (gbl_f64 *) (row_p + lane);
@@ -2170,6 +2173,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				if constexpr (POST) {
 					// (the row leaves once the primers are off it: until then it is its table indices, beside the nt bytes)
 					*reinterpret_cast<__attribute__((address_space(3))) uint16_t *>(lN + (L::PIDX - L::NT) + 2u * (unsigned) (64 * (R0 + k) + lane)) = (uint16_t) qi[k];
+					if (EXACT)
+						xsP[64 * (R0 + k)] = (uint16_t) (8u * qi[k]);
 					if (lane < seqlen - 64 * (R0 + k))
 						qacc += pv[k];
 				} else if (lane < lim - 64 * (R0 + k)) {
@@ -2398,7 +2403,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		     : "+v"(pd.len_bo), "+v"(pd.ex_mm), "+v"(pd.dg_fo), "+v"(pd.ro_st)
 		     : "s"(slot_idx), "s"(uni((int) f_len_bo)), "s"(uni((int) f_ex_mm)), "s"(uni((int) f_dg_fo)), "s"(uni((int) f_ro_st)));
 	if (EXACT) {	// exact sums: where the row's three chains begin and end (assembler.c:171,226,236): the overlap is [A0, AF)
-		const unsigned f_pid = (unsigned) region_a0 | ((unsigned) region_af << 16);
+		const unsigned f_pid = (unsigned) region_a0 | ((unsigned) region_af << 10) | ((unsigned) region_len << 20);	// (each at most 640)
 		asm volatile("s_mov_b32 m0, %1\n\tv_writelane_b32 %0, %2, m0" : "+v"(pd.pid) : "s"(slot_idx), "s"(uni((int) f_pid)));
 	}
 }
@@ -2529,7 +2534,7 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 }	// namespace
 
 // ---- host side: does the lean kernel serve this configuration, and its launch ---------------------------------
-// PAMD_FAST_POST: `-a`, reads of at most 320 bases (the LONG geometry), any-order sums.
+// PAMD_FAST_POST: `-a`, reads of at most 320 bases (the LONG geometry), either summation mode.
 // 0: not served (the general kernel takes the launch whole); PAMD_FAST_SHORT: reads of at most 256 bases, no primers or
 // trims; PAMD_FAST_LONG: reads of at most 320 bases; PAMD_FAST_PRIM: the same with `-p` / `-q` primers (at most 24 bases, no
 // penalty) and / or trims.
@@ -2540,9 +2545,8 @@ int pamd_fast_supports(const PamdKernelParams &p) {
 		return 0;	// 32-bit pair indices in the kernel and in the deferred list
 	if (p.post_primers) {
 		// `-a` (assembler.c:300-333): the lean scan sums only alignments without a disagreeing base, which is exact when a
-		// disagreement makes an alignment's value NaN or -inf (notp_never_finite); any-order sums only (the finish of the
-		// exact mode walks rows in HBM, which a clipped row no longer holds whole); no penalty; primers of at most 24 bases
-		if (!p.notp_never_finite || p.exact_sums || p.primer_penalty != 0.0 || p.smax > (uint32_t) Lay<true>::MAXLEN)
+		// disagreement makes an alignment's value NaN or -inf (notp_never_finite); no penalty; primers of at most 24 bases
+		if (!p.notp_never_finite || p.primer_penalty != 0.0 || p.smax > (uint32_t) Lay<true>::MAXLEN)
 			return 0;
 		if (p.fprimer_len > 24 || p.rprimer_len > 24 || p.ftrim < 0 || p.rtrim < 0 || p.ftrim > 2 * Lay<true>::MAXLEN || p.rtrim > 2 * Lay<true>::MAXLEN)
 			return 0;
@@ -2604,7 +2608,7 @@ void pamd_fast_geometry(PamdKernelParams &p, int cu_count, size_t lds_limit, int
 // bytes of PamdKernelParams::score_scratch the lean kernel wants for this launch (sums in the reference's order: FK_XG rows of
 // table indices per wave, exact_sums_group); 0 when it wants none
 size_t pamd_fast_scratch_bytes(const PamdKernelParams &p, int workgroups, int waves_per_wg) {
-	if (!p.exact_sums || pamd_fast_supports(p) == 0 || pamd_fast_supports(p) == PAMD_FAST_POST)
+	if (!p.exact_sums || pamd_fast_supports(p) == 0)
 		return 0;
 	return (size_t) workgroups * (size_t) waves_per_wg * (size_t) FK_XG * (size_t) fk_xstride<true>() * sizeof(uint16_t);
 }
@@ -2617,7 +2621,7 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 	const bool narrow = p.smax <= 192;	// three bases per lane cover the reads
 #define FK_PICK3(A, PH, E) (narrow ? pamd_fast_kernel<A, E, PH, false, false, true> : pamd_fast_kernel<A, E, PH, false, false, false>)
 #define FK_PICK4(A, PH, E) (variant == PAMD_FAST_LONG ? pamd_fast_kernel<A, E, PH, true, false, false> : pamd_fast_kernel<A, E, PH, true, true, false>)
-#define FK_PICK2(A, PH) (variant == PAMD_FAST_POST ? pamd_fast_kernel<A, false, PH, true, false, false, true>                                         \
+#define FK_PICK2(A, PH) (variant == PAMD_FAST_POST ? (p.exact_sums ? pamd_fast_kernel<A, true, PH, true, false, false, true> : pamd_fast_kernel<A, false, PH, true, false, false, true>) \
 						   : variant == PAMD_FAST_SHORT ? (p.exact_sums ? FK_PICK3(A, PH, true) : FK_PICK3(A, PH, false)) \
 										: (p.exact_sums ? FK_PICK4(A, PH, true) : FK_PICK4(A, PH, false)))
 #define FK_PICK(A) (p.has_min_phred ? FK_PICK2(A, true) : FK_PICK2(A, false))

@@ -43,8 +43,8 @@ def test_baseline_configs_run_in_their_lean_instantiation(built, cfg, want):
 def test_primers_after_routing(built):
     asm, _ = _run(2, primers_after=True)
     assert asm.last_lean_variant() == "after"
-    asm, _ = _run(2, primers_after=True, exact=True)      # the reference-order finish walks rows a clipped row no longer holds whole
-    assert asm.last_lean_variant() == "general" and asm.last_deferred() == -1
+    asm, _ = _run(2, primers_after=True, exact=True)      # (round 5: the ordered sums come from the scratch rows of table entries, whole merge)
+    assert asm.last_lean_variant() == "after" and asm.last_deferred() >= 0
     asm, _ = _run(2, primers_after=True, tweak=lambda a: a.set_primer_penalty(0.01))
     assert asm.last_lean_variant() == "general"
 
@@ -74,9 +74,9 @@ GEOMETRIES = {
 @pytest.mark.parametrize("geometry", list(GEOMETRIES))
 @pytest.mark.parametrize("algo", ALGOS)
 def test_every_instantiation_of_the_lean_kernel(built, algo, geometry):
-    """pamd_fast.hip is compiled with its own flags (-Os, uniform regions left unstructurized: Makefile FAST_FLAGS) into 126
+    """pamd_fast.hip is compiled with its own flags (-Os, uniform regions left unstructurized: Makefile FAST_FLAGS) into 140
     instantiations -- seven scorers x {any-order, reference-order sums} x {with, without min_phred} x {short, narrow, long, primers},
-    and `-a` x seven x two.  Each of them, on data that selects it: the instantiation the launch reports, and records, rows and
+    and `-a` x seven x two x two.  Each of them, on data that selects it: the instantiation the launch reports, and records, rows and
     counters of the two-kernel launch equal to the general kernel's alone and to the oracle's."""
     import torch
     import pandaseq_amd as pa
@@ -93,7 +93,7 @@ def test_every_instantiation_of_the_lean_kernel(built, algo, geometry):
     fp = rp = None
     if cfg == 2:
         fp, rp = synth.nt_codes(spec.fprimer), synth.nt_codes(spec.rprimer, complement=True)
-    for exact in ((False,) if geometry == "post" else (False, True)):
+    for exact in (False, True):
         for phred in (False, True):
             okw = {}
             if extra:
