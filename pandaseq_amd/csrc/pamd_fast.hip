@@ -1178,41 +1178,55 @@ __device__ __forceinline__ int fk_phred_of(const double *score, const unsigned c
 // compiler waiting for each; 9 % with four 16-byte loads issued a block ahead.  Eight a block ahead cost the callee 120 registers and
 // the pair loop spills: slower than four.  Groups of 16 pairs (48 lanes): 630 M; of 21 (63 lanes, finish after 63 pairs): 640 M; the
 // reads' rows loaded with the nontemporal hint, so that they do not push the scratch rows out of the L2: 645 M.
-constexpr int FK_XG = 21;	// pairs per group: 3 x 21 chains in 63 lanes; three groups per finish (which then takes 63 pairs, not 64)
-template <bool LONG>
+// pairs per group: 3 x 21 chains in 63 lanes, three groups per finish (which then takes 63 pairs, not 64); pear / rdp_mle (SCORE):
+// a fourth chain per pair, the winning overlap's score (algo_pear.c:32-59, algo_rdp_mle.c:43-74: an ordered sum as well): 4 x 15
+// chains in 60 lanes, four groups per finish
+template <bool SCORE>
+constexpr int fk_xg() {
+	return SCORE ? 15 : 21;
+}
+constexpr int FK_XG_MAX = 21;
+template <bool LONG, bool SCORE>
 constexpr unsigned fk_xstride() {
-	return (unsigned) Lay<LONG>::NR * 64u;	// indices per slot: every round of the merge writes its 64
+	return (unsigned) Lay<LONG>::NR * 64u + (SCORE ? (unsigned) Lay<LONG>::SR * 64u : 0u);	// entries per slot: every round of the merge writes its 64; then the score's terms
 }
 struct GroupSums {
 	unsigned q_lo, q_hi;	// lane base + s: the quality of the group's s-th pair, if `done`
+	unsigned b_lo, b_hi;	// SCORE: its score
 	bool done;
 };
 // len_bo / pid / ro_st / off_*: the lane's parked fields (lane = slot of the wave's pending pairs); base: first slot of the group,
-// count: pairs in it.  Out of line: it runs once per FK_XG pairs and what it clobbers the pair loop does not keep across the call.
-template <bool LONG>
-__device__ __attribute__((noinline)) GroupSums exact_sums_group(unsigned lT, const uint16_t *xs, unsigned len_bo, unsigned pid, unsigned ro_st, unsigned off_lo, unsigned off_hi, int base, int count, int lane) {
-	constexpr unsigned XS = fk_xstride<LONG>();
+// count: pairs in it.  sub (SCORE): what every term of the score has subtracted before it is added (rdp_mle: qual_nn,
+// algo_rdp_mle.c:68-70; pear: nothing).  Out of line: it runs once per group and what it clobbers the pair loop does not keep
+// across the call.
+template <bool LONG, bool SCORE, bool SUBTRACT>
+__device__ __attribute__((noinline)) GroupSums exact_sums_group(unsigned lT, const uint16_t *xs, unsigned len_bo, unsigned pid, unsigned ro_st, unsigned off_lo, unsigned off_hi, double sub, int base, int count, int lane) {
+	constexpr unsigned XS = fk_xstride<LONG, SCORE>();
+	constexpr int XG = fk_xg<SCORE>(), NCH = SCORE ? 4 : 3;
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// this wave's index stores have left (a CU's vector L1 is coherent for its own stores)
-	const int chain = lane >= 2 * FK_XG ? 2 : (lane >= FK_XG ? 1 : 0), s = lane - FK_XG * chain;	// (lane 63: idle, reads as slot 0 of a fourth chain)
-	const int src = 4 * (base + s);	// ds_bpermute takes a byte address: lane * 4
-	const unsigned g_pid = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) pid);
-	(void) len_bo;
+	const int chain = lane >= 3 * XG ? 3 : (lane >= 2 * XG ? 2 : (lane >= XG ? 1 : 0)), s = lane - XG * chain;	// (lanes past NCH * XG: idle, they read as a further chain of slot 0..)
+	const int src = 4 * (base + (s < XG ? s : 0));	// ds_bpermute takes a byte address: lane * 4
+	const unsigned g_pid = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) pid), g_len_bo = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) len_bo);
 	const unsigned g_ro_st = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) ro_st);
 	const unsigned g_off = (unsigned) __builtin_amdgcn_ds_bpermute(src, (int) (off_lo & off_hi));	// all ones: the row found no room (the pair ends as NOSPACE)
 	const int a0 = (int) (g_pid & 0x3FFu), af = (int) ((g_pid >> 10) & 0x3FFu), seqlen = (int) (g_pid >> 20);	// (the merge's length: `-a` has clipped the record's)
-	const bool valid = s < count && lane < 3 * FK_XG && ((g_ro_st >> 16) & 0xFFu) == (unsigned) PAMD_ST_OK && g_off != 0xFFFFFFFFu;
-	const int lo = !valid || chain == 0 ? 0 : (chain == 1 ? a0 : af), hi = chain == 0 ? a0 : (chain == 1 ? af : seqlen);
+	const int bo = (int) (g_len_bo >> 16);
+	const bool valid = s < count && s < XG && lane < NCH * XG && ((g_ro_st >> 16) & 0xFFu) == (unsigned) PAMD_ST_OK && g_off != 0xFFFFFFFFu;
+	const int lo = !valid || chain == 0 || chain == 3 ? 0 : (chain == 1 ? a0 : af), hi = chain == 0 ? a0 : (chain == 1 ? af : (chain == 2 ? seqlen : bo));
 	const int n = valid && hi > lo ? hi - lo : 0;
 	const int steps = wave_max_i32(n);
 	// Eight entries per 16-byte load (the chain starts at any entry: the loads are unaligned, which global loads may be), a block of
 	// FK_XD loads per lane under way while the block before it is added up: a lane's chain is a few hundred dependent additions
 	// behind a few dozen loads from lines the merge wrote some microseconds ago -- what it must not do is wait for each in turn.
-	// An entry is the byte offset of its value in the table image; a lane past its chain's end adds the image's spare 0.0.
+	// An entry is the byte offset of its value in the table image; a lane past its chain's end adds the image's spare 0.0 (the
+	// score's chain, whose terms have `sub` subtracted: the entry that holds `sub` itself).
 	typedef unsigned u32x4u __attribute__((ext_vector_type(4), aligned(2)));
 	typedef __attribute__((address_space(1))) const u32x4u gbl_cu128u;
-	gbl_cu128u *const row = (gbl_cu128u *) (xs + (unsigned) s * XS + (unsigned) lo);
+	gbl_cu128u *const row = (gbl_cu128u *) (xs + (unsigned) (s < XG ? s : 0) * XS + (chain == 3 ? (unsigned) Lay<LONG>::NR * 64u : (unsigned) lo));
 	constexpr int FK_XD = 4;
-	constexpr unsigned ZERO_OFF = 8u * PAMD_LT_ZERO;
+	const bool scoring = SCORE && chain == 3;
+	const unsigned pad_off = (SUBTRACT && scoring) ? 8u * (PAMD_LT_SCORE + 47u) : 8u * PAMD_LT_ZERO;	// (slot 47 of the score block holds qual_nn)
+	const double my_sub = (SUBTRACT && scoring) ? sub : 0.0;
 	const int nv = (n + 7) >> 3, last = nv > 0 ? nv - 1 : 0;	// (a lane past its chain's end re-reads the chain's last vector)
 	const int vsteps = (steps + 7) >> 3;
 	u32x4u nxt[FK_XD];
@@ -1238,31 +1252,38 @@ __device__ __attribute__((noinline)) GroupSums exact_sums_group(unsigned lT, con
 			for (int u = 0; u < 8; u++) {
 				const unsigned w = u < 2 ? cur[d].x : (u < 4 ? cur[d].y : (u < 6 ? cur[d].z : cur[d].w));
 				const unsigned e = (u & 1) ? w >> 16 : w & 0xFFFFu;
-				v[u] = lds_read_f64(lT + (u < left ? e : ZERO_OFF));
+				v[u] = lds_read_f64(lT + (u < left ? e : pad_off));
 			}
 #pragma unroll
 			for (int u = 0; u < 8; u++)
-				acc += v[u];	// left to right: the reference's order (x + 0.0 is x)
+				acc += SUBTRACT ? v[u] - my_sub : v[u];	// left to right: the reference's order (x - 0.0 and x + 0.0 are x)
 			__builtin_amdgcn_sched_barrier(0);	// (one vector's table reads at a time: hoisted together they take a hundred registers, which the caller then spills)
 		}
 	}
-	// lane s (chain 0) gathers its pair's other two sums; then lane base + s takes the quality
+	// lane s (chain 0) gathers its pair's other sums; then lane base + s takes them
 	union {
 		double d;
 		int i[2];
-	} f, o, r, q;
+	} f, o, r, q, sc;
 	f.d = acc;
-	o.i[0] = __builtin_amdgcn_ds_bpermute(4 * (s + FK_XG), f.i[0]);
-	o.i[1] = __builtin_amdgcn_ds_bpermute(4 * (s + FK_XG), f.i[1]);
-	r.i[0] = __builtin_amdgcn_ds_bpermute(4 * (s + 2 * FK_XG), f.i[0]);
-	r.i[1] = __builtin_amdgcn_ds_bpermute(4 * (s + 2 * FK_XG), f.i[1]);
+	o.i[0] = __builtin_amdgcn_ds_bpermute(4 * (s + XG), f.i[0]);
+	o.i[1] = __builtin_amdgcn_ds_bpermute(4 * (s + XG), f.i[1]);
+	r.i[0] = __builtin_amdgcn_ds_bpermute(4 * (s + 2 * XG), f.i[0]);
+	r.i[1] = __builtin_amdgcn_ds_bpermute(4 * (s + 2 * XG), f.i[1]);
+	sc.d = 0.0;
+	if (SCORE) {
+		sc.i[0] = __builtin_amdgcn_ds_bpermute(4 * ((s + 3 * XG) & 63), f.i[0]);
+		sc.i[1] = __builtin_amdgcn_ds_bpermute(4 * ((s + 3 * XG) & 63), f.i[1]);
+	}
 	q.d = (f.d + r.d + o.d) / (double) (seqlen + 1);	// assembler.c:244
-	// (lanes 0 .. FK_XG-1 hold the group's qualities; lane base + t of the parked records takes the t-th)
+	// (lanes 0 .. XG-1 hold the group's results; lane base + t of the parked records takes the t-th)
 	const int from = 4 * ((lane - base) & 63);
 	const int okv = __builtin_amdgcn_ds_bpermute(from, valid ? 1 : 0);	// (chain 0's verdict: the pair has a row)
 	GroupSums out;
 	out.q_lo = (unsigned) __builtin_amdgcn_ds_bpermute(from, q.i[0]);
 	out.q_hi = (unsigned) __builtin_amdgcn_ds_bpermute(from, q.i[1]);
+	out.b_lo = (unsigned) __builtin_amdgcn_ds_bpermute(from, sc.i[0]);
+	out.b_hi = (unsigned) __builtin_amdgcn_ds_bpermute(from, sc.i[1]);
 	out.done = lane >= base && lane < base + count && okv != 0;
 	return out;
 }
@@ -1849,19 +1870,13 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				}
 				nloop = 0;
 				if (uni(ms.bo) >= 0) {
-					if (EXACT) {	// the winner's score once more, its terms added in the reference's order
-						ov0 = uni(ms.bo);
-						nloop = 1;
-					} else {
-						best = uni_f64(ms.best);
-						bo = uni(ms.bo);
-					}
+					best = uni_f64(ms.best);
+					bo = uni(ms.bo);
 				}
 				wave_sync();
+				deep_dirty = true;	// (the candidate list lay over the k-mer tables)
 			}
 			const unsigned lF = lds_addr(wb + L::F), lR = lds_addr(wb + L::R), lT = lds_addr(ltab);
-			double *const ps = reinterpret_cast<double *>(wb + L::T1);	// the terms of one candidate, where the k-mer tables were
-			deep_dirty = deep_dirty || EXACT;
 			for (int c = 0; c < nloop; c++) {
 				const int ov = c == 0 ? ov0 : (c == 1 ? ov1 : (c == 2 ? ov2 : ov3));
 				double part = 0.0;
@@ -1882,41 +1897,11 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 						} else {
 							term = lds_read_f64(lT + 8u * mat_index<DENSE>(agree, qa, er >> 8)) - nn;
 						}
-						if (EXACT)
-							ps[i] = term;
-						else
-							part += term;
+						part += term;
 					}
 				}
-				double pr;
-				if (EXACT) {
-					wave_sync();
-					double acc = 0.0;
-					if (lane == 0) {	// the reference's own order, eight reads in flight
-						int i = 0;
-						for (; i + 8 <= ov; i += 8) {
-							const double v0 = ps[i], v1 = ps[i + 1], v2 = ps[i + 2], v3 = ps[i + 3];
-							const double v4 = ps[i + 4], v5 = ps[i + 5], v6 = ps[i + 6], v7 = ps[i + 7];
-							acc += v0;
-							acc += v1;
-							acc += v2;
-							acc += v3;
-							acc += v4;
-							acc += v5;
-							acc += v6;
-							acc += v7;
-						}
-						for (; i < ov; i++)
-							acc += ps[i];
-					}
-					wave_sync();
-					pr = uni_f64(acc);
-					if (pr > best) {	// strict: the ascending scan keeps the smallest overlap on ties
-						best = pr;
-						bo = ov;
-					}
-				} else {
-					pr = wave_sum_any_order(part);
+				{
+					const double pr = wave_sum_any_order(part);
 					if (pr > best + 1e-6) {
 						best = pr;
 						bo = ov;
@@ -1925,17 +1910,42 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 					}
 				}
 			}
-			if (!EXACT) {
+			if (!EXACT) {	// (with sums in the reference's order the module sees the ordered sum itself: exact_sums_group delivers it before finish64)
 				for (int mi = 0; mi < P.n_modules; mi++)	// plugin_min_overlapbits.c:17-23 reads this sum
 					ambiguous |= P.modules[mi].kind == 2 && fabs(P.modules[mi].nats - best) <= 1e-6;
-				if (ambiguous) {
-					note(P, 2, lane);
-					status = PAMD_ST_DEFER;
-					break;
-				}
+			}
+			if (ambiguous) {
+				note(P, 2, lane);
+				status = PAMD_ST_DEFER;
+				break;
 			}
 			bo = uni(bo);
 			best = uni_f64(best);
+			if (EXACT && bo >= 0) {
+				// Sums in the reference's order (round 5): the DECISION above is made from any-order sums behind the same 1e-6 guard
+				// as in the other mode (what is closer goes to the general kernel, which adds in order); the SCORE the record reports is
+				// the winner's terms added in order -- by a lane of the group walk, from their table entries left here beside the row's.
+				typedef __attribute__((address_space(1))) uint16_t gbl_u16s;
+				gbl_u16s *const sc = (gbl_u16s *) (xs + (unsigned) L::NR * 64u + (unsigned) lane);
+#pragma unroll
+				for (int r = 0; r < L::SR; r++) {
+					const int i = 64 * r + lane;
+					if (64 * r < bo && i < bo) {
+						const int fi = flen - bo + i, ri = rlen - 1 - i;
+						const unsigned ef = lds_read_u16(lF + 2u * (unsigned) fi), er = lds_read_u16(lR + 2u * (unsigned) ri);
+						const unsigned a = ef & 0xFFu, b = er & 0xFFu, qa = ef >> 8;
+						const bool agree = (a & b) != 0;
+						unsigned entry;
+						if (ALGO == PAMD_ALGO_PEAR) {
+							const unsigned qb = ri < flen ? lds_read_u16(lF + 2u * (unsigned) ri) >> 8 : 0u;
+							entry = (a == 15u || b == 15u) ? (unsigned) PAMD_LT_C : mat_index<DENSE>(agree, qa, qb);	// (the slot behind the matrices holds -random_base: the kernel's prologue)
+						} else {
+							entry = mat_index<DENSE>(agree, qa, er >> 8);
+						}
+						sc[64 * r] = (uint16_t) (8u * entry);
+					}
+				}
+			}
 		} else if (LONG && (all || ncand > 4)) {	// (the candidate-per-lane scan below is laid out for 256 overlaps)
 			note(P, 3, lane);
 			status = PAMD_ST_DEFER;
@@ -2441,7 +2451,7 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 	unsigned char *wb = lds + P.lds_primer_off + (size_t) wave * Geo<LONG, t1_bits<ALGO, LONG>()>::WAVE_BYTES;	// (the per-wave regions start where the general kernel keeps its primers)
 	unsigned char *places = lds + P.lds_primer_off + (size_t) nwaves * Geo<LONG, t1_bits<ALGO, LONG>()>::WAVE_BYTES;	// PHRED: 96 bytes behind the last wave's region (fk_phred_places)
 	// EXACT: this wave's scratch rows for the table indices of FK_XG pairs (exact_sums_group)
-	uint16_t *const xs = EXACT ? reinterpret_cast<uint16_t *>(P.score_scratch) + ((size_t) blockIdx.x * (size_t) nwaves + (size_t) wave) * (size_t) (FK_XG * fk_xstride<LONG>()) : nullptr;
+	uint16_t *const xs = EXACT ? reinterpret_cast<uint16_t *>(P.score_scratch) + ((size_t) blockIdx.x * (size_t) nwaves + (size_t) wave) * (size_t) (fk_xg<EXACT && !counting_algo<ALGO>()>() * fk_xstride<LONG, EXACT && !counting_algo<ALGO>()>()) : nullptr;
 	unsigned primer_bases = 0;	// PRIM: this lane's base of the forward primer | of the reverse primer << 8 (N past their ends) | << 16: lanes 0..31 the forward, lanes 32..63 the reverse primer's bases 0..31
 	// what lies before a read reads as N: the word before the forward N map (seed windows start eight bases early)
 	if (lane < 4)
@@ -2454,6 +2464,11 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 				       | ((lane < 32 ? (lane < P.fprimer_len ? (unsigned) P.primers[lane] : 15u) : (lane - 32 < P.rprimer_len ? (unsigned) P.primers[456 + lane - 32] : 15u)) << 16);
 	}
 	__syncthreads();
+	if (EXACT && ALGO == PAMD_ALGO_PEAR) {	// the slot behind the two matrices: what an N adds to pear's score (algo_pear.c:47-49), for the score's chain
+		if (tid == 0)
+			ltab[PAMD_LT_C] = -P.pear_random_base;
+		__syncthreads();
+	}
 	if (PHRED) {	// (after the tables are staged: the places are made from the staged score table)
 		fk_phred_places(ltab + PAMD_LT_SCORE, places, tid);
 		__syncthreads();
@@ -2479,8 +2494,20 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 	load_pair<LONG, EXACT>(cur, P, q, lane);
 	settle(cur);
 	int npend = 0, xg = 0;	// pairs parked for finish64; of those, pairs of the current group of ordered sums (EXACT)
+	constexpr bool XSCORE = EXACT && !counting_algo<ALGO>();
+	constexpr int XG = fk_xg<XSCORE>();
 	bool deep_dirty = true;	// the first pair clears all four tables
 	Pend64 pd = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+	auto take_group = [&](int base, int count) __attribute__((always_inline)) {
+		const GroupSums g = exact_sums_group<LONG, XSCORE, ALGO == PAMD_ALGO_RDP_MLE>(lds_addr(ltab), xs, pd.len_bo, pd.pid, pd.ro_st, pd.off_lo, pd.off_hi, P.qual_nn, base, count, lane);
+		pd.q_lo = g.done ? g.q_lo : pd.q_lo;
+		pd.q_hi = g.done ? g.q_hi : pd.q_hi;
+		if (XSCORE) {
+			pd.b_lo = g.done ? g.b_lo : pd.b_lo;
+			pd.b_hi = g.done ? g.b_hi : pd.b_hi;
+		}
+		pd.ro_st |= g.done ? 1u << 25 : 0u;	// "the quality is final"
+	};
 	unsigned group_first = pair;
 	while (pair < n_pairs) {
 		const unsigned next = pair + total_waves;
@@ -2496,29 +2523,22 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 			// here, the lane number's derivatives are recomputed where they are used (an instruction or two each).
 			asm volatile("" : "+v"(lane_now));
 		}
-		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST>(P, ltab, places, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases, EXACT ? xs + (unsigned) xg * fk_xstride<LONG>() : nullptr);
+		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST>(P, ltab, places, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases, EXACT ? xs + (unsigned) xg * fk_xstride<LONG, XSCORE>() : nullptr);
 		MARK("loop");
 		npend++;
-		if (EXACT && ++xg == FK_XG) {	// sums in the reference's order: a group of pairs is complete
-			const GroupSums g = exact_sums_group<LONG>(lds_addr(ltab), xs, pd.len_bo, pd.pid, pd.ro_st, pd.off_lo, pd.off_hi, npend - FK_XG, FK_XG, lane);
-			pd.q_lo = g.done ? g.q_lo : pd.q_lo;
-			pd.q_hi = g.done ? g.q_hi : pd.q_hi;
-			pd.ro_st |= g.done ? 1u << 25 : 0u;	// "the quality is final"
+		if (EXACT && ++xg == XG) {	// sums in the reference's order: a group of pairs is complete
+			take_group(npend - XG, XG);
 			xg = 0;
 		}
-		if (npend == (EXACT ? 3 * FK_XG : 64)) {
+		if (npend == (EXACT ? (XSCORE ? 4 : 3) * XG : 64)) {
 			finish64<false, true, false>(P, lctr, pd, npend, group_first, total_waves, lane);
 			npend = 0;
 			group_first = next;
 		}
 		pair = next;
 	}
-	if (EXACT && xg != 0) {
-		const GroupSums g = exact_sums_group<LONG>(lds_addr(ltab), xs, pd.len_bo, pd.pid, pd.ro_st, pd.off_lo, pd.off_hi, npend - xg, xg, lane);
-		pd.q_lo = g.done ? g.q_lo : pd.q_lo;
-		pd.q_hi = g.done ? g.q_hi : pd.q_hi;
-		pd.ro_st |= g.done ? 1u << 25 : 0u;
-	}
+	if (EXACT && xg != 0)
+		take_group(npend - xg, xg);
 	if (npend > 0)
 		finish64<false, true, false>(P, lctr, pd, npend, group_first, total_waves, lane);
 	__syncthreads();
@@ -2585,6 +2605,11 @@ static bool fast_dense(const PamdKernelParams &p) {
 void pamd_fast_geometry(PamdKernelParams &p, int cu_count, size_t lds_limit, int max_waves, int *workgroups, int *waves_per_wg, size_t *lds_bytes) {
 	const bool rdp = p.algo == PAMD_ALGO_RDP_MLE, dense = fast_dense(p);
 	const int cus = cu_count > 0 ? cu_count : 256;
+	if (p.algo == PAMD_ALGO_PEAR && p.exact_sums && pamd_fast_supports(p) != 0) {	// (the slot behind the matrices: -random_base, for the score's chain)
+		p.lds_table_doubles = PAMD_LT_C + 1;
+		p.lds_ctr_off = (p.lds_table_doubles * 8u + 15u) & ~15u;
+		p.lds_primer_off = (p.lds_ctr_off + PAMD_NUM_COUNTERS * 4u + 15u) & ~15u;
+	}
 	if (dense) {
 		p.lds_table_doubles = FK_DLT_END;
 		p.lds_ctr_off = (FK_DLT_END * 8u + 15u) & ~15u;
@@ -2610,7 +2635,7 @@ void pamd_fast_geometry(PamdKernelParams &p, int cu_count, size_t lds_limit, int
 size_t pamd_fast_scratch_bytes(const PamdKernelParams &p, int workgroups, int waves_per_wg) {
 	if (!p.exact_sums || pamd_fast_supports(p) == 0)
 		return 0;
-	return (size_t) workgroups * (size_t) waves_per_wg * (size_t) FK_XG * (size_t) fk_xstride<true>() * sizeof(uint16_t);
+	return (size_t) workgroups * (size_t) waves_per_wg * (size_t) FK_XG_MAX * (size_t) fk_xstride<true, true>() * sizeof(uint16_t);	// (an upper bound over the instantiations)
 }
 
 int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg, size_t lds_bytes, void *stream) {
