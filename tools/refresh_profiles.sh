@@ -18,6 +18,8 @@ export PAMD_BUILD=$(cat .build_id 2>/dev/null || git rev-parse --short HEAD 2>/d
 python3 bench.py --steps 5 --warmup 1 2> "$OUT/bench_config1_fast.err" | tail -1 > "$OUT/bench_config1_fast.json"
 python3 bench.py --steps 5 --warmup 1 --sums exact --no-cpu --no-e2e 2> /dev/null | tail -1 > "$OUT/bench_config1_exact.json"
 for c in 2 3 4; do python3 bench.py --steps 3 --warmup 1 --config $c --no-cpu --no-e2e 2> /dev/null | tail -1 > "$OUT/bench_config$c.json"; done
+for c in 2 3 4; do python3 bench.py --steps 3 --warmup 1 --config $c --sums exact --no-cpu --no-e2e 2> /dev/null | tail -1 > "$OUT/bench_config${c}_exact.json"; done
+python3 bench.py --steps 3 --warmup 1 --config 2 --primers-after --sums exact --no-cpu --no-e2e 2> /dev/null | tail -1 > "$OUT/bench_config2_primers_after_exact.json"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o t -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu --no-e2e > "$OUT/prof.log" 2>&1)
 python3 profiles/summarize_rocprof.py --like '%pamd_%' $(find "$OUT/prof" -name '*_results.db' | head -1) > "$OUT/rocprof.txt"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof2" -o t -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --config 2 --no-cpu --no-e2e > "$OUT/prof2.log" 2>&1)
