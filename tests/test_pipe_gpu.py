@@ -132,6 +132,21 @@ def test_pump_with_unequal_files(pipe, tmp_path):
     assert got == b"" and stat["READS"] == 0
 
 
+def test_pump_fails_cleanly(pipe, tmp_path):
+    """pamd_pipe_run() on files that are not there, or an output that cannot be made: an error code and a message, no threads
+    left behind (the client exits non-zero, promptly)."""
+    ft, rt = util.random_fastq(200, 3)
+    f, r = tmp_path / "f.fastq", tmp_path / "r.fastq"
+    f.write_bytes(ft)
+    r.write_bytes(rt)
+    for args in ((str(tmp_path / "missing.fastq"), str(r), str(tmp_path / "o.txt")), (str(f), str(tmp_path / "missing.fastq"), str(tmp_path / "o.txt")),
+                 (str(f), str(r), str(tmp_path / "no_such_dir" / "o.txt"))):
+        out = subprocess.run([pipe, *args, "0", "fasta", "1000"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 3 and "cannot" in out.stderr, (args, out.returncode, out.stderr[-300:])
+    out = subprocess.run([pipe, str(f), str(r), str(tmp_path / "o.txt"), "0", "fasta", "4000000"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3 and "3 000 000" in out.stderr     # more pairs per chunk than a text chunk below 4 GiB can hold
+
+
 # ---- the reference's own file-level API: panda_assembler_open() + panda_assembler_next() ------------------
 @pytest.fixture(scope="module")
 def open_client(built, tmp_path_factory):
