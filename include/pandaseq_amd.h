@@ -72,7 +72,7 @@ enum {
 /* What panda_result_seq (pandaseq-common.h:277-330) carries per pair, minus the pointers. 48 bytes. */
 typedef struct {
 	double quality;			/* result.quality */
-	double est_overlap_prob;	/* result.estimated_overlap_probability */
+	double est_overlap_prob;	/* result.estimated_overlap_probability (assembler.c:247; 0 when the pair did not merge: BADR .. NOALGN) */
 	uint64_t seq_offset;		/* index of the first merged base in seq_nt / seq_p (valid when status == OK) */
 	uint16_t seq_len;		/* result.sequence_length */
 	uint16_t overlap;		/* result.overlap */

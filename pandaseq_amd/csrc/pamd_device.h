@@ -253,6 +253,8 @@ __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64
 		e.u[0] = pd.b_lo;
 		e.u[1] = pd.b_hi;
 		status = (int) ((pd.ro_st >> 16) & 0xFFu);
+		if (status != PAMD_ST_OK)
+			e.d = 0.0;	// (assembler.c:247 sets it once the pair has merged; a scorer's running best of a pair that found no overlap is not a result)
 		slow = ((pd.ro_st >> 24) & 1u) != 0;
 		const bool q_final = ((pd.ro_st >> 25) & 1u) != 0;
 		const int seqlen = (int) (pd.len_bo & 0xFFFFu), bo = (int) (pd.len_bo >> 16);

@@ -695,7 +695,7 @@ __device__ void finish_group(const PamdKernelParams &P, const double *ltab, unsi
 			unsigned u[2];
 		} q, e;
 		q.d = quality;
-		e.d = r.best;
+		e.d = r.st == PAMD_ST_OK ? r.best : 0.0;	// (assembler.c:247: set once the pair has merged, as in finish64)
 		uint4 *dst = reinterpret_cast<uint4 *>(&P.results[r.pair]);
 		dst[0] = make_uint4(q.u[0], q.u[1], e.u[0], e.u[1]);
 		dst[1] = make_uint4((unsigned) off, (unsigned) (off >> 32), (unsigned) r.seqlen | ((unsigned) r.bo << 16), (unsigned) r.examined | ((unsigned) r.mism << 16));

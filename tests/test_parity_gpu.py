@@ -45,6 +45,55 @@ def test_synthetic_configs(built, algo, cfg, sums):
     compare_counters(b.counters_dict(), o_ctr)
 
 
+@pytest.mark.parametrize("algo,cfg,after", [("simple_bayesian", 1, False), ("pear", 1, False), ("rdp_mle", 1, False), ("simple_bayesian", 4, False),
+                                            ("pear", 2, False), ("pear", 2, True), ("rdp_mle", 2, True)])
+def test_reference_order_sums_through_full_groups(built, algo, cfg, after):
+    """Sums in the reference's order at a size where every wave of the lean kernel goes through full groups of its walk (21
+    pairs, 15 with a score chain), the finish after 63 / 60 pairs and a partial last group: 300 000 pairs against the oracle,
+    `quality` and `est_overlap_prob` bit for bit, every record and counter; the rows through their checksums."""
+    import torch
+    import pandaseq_amd as pa
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    spec = synth.config_spec(cfg)
+    n = 300_000
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 31_000_000, n)
+    if algo == "pear":
+        rlen = np.minimum(rlen, flen)
+    okw = {}
+    asm = pa.Assembler(0)
+    asm.set_algorithm(algo)
+    asm.set_exact_sums(True)
+    if cfg == 2:
+        fp, rp = synth.nt_codes(spec.fprimer), synth.nt_codes(spec.rprimer, complement=True)
+        asm.set_forward_primer(fp)
+        asm.set_reverse_primer(rp)
+        asm.set_primers_after(after)
+        okw = dict(fprimer=fp, rprimer=rp, primers_after=after)
+    b = pa.upload_batch(fwd, rev, flen, rlen, device="cuda:0", seq_stride=0, capacity=n * (620 if cfg == 2 else 440) + (1 << 27))
+    asm.assemble_device(b)
+    torch.cuda.synchronize()
+    asm.check_overflow()
+    assert asm.last_lean_variant() != "general" and 0 <= asm.last_deferred() < n // 20
+    ocfg = po.make_config(algo, **okw)
+    o_res, o_cs_nt, o_cs_p = po.row_checksums(ocfg, fwd, rev, flen, rlen, threads=8)
+    o_ctr = po.assemble_batch(ocfg, fwd, rev, flen, rlen, want_seq=False, threads=8)[3]
+    res = b.results_numpy()
+    assert np.array_equal(res["status"], o_res["status"])
+    ok = o_res["status"] == 0
+    assert int(ok.sum()) > n // 2
+    for name in ("overlap", "seq_len", "mismatches", "degenerates", "examined", "fwd_offset", "rev_offset"):
+        assert np.array_equal(res[name][ok], o_res[name][ok]), name
+    merged = ok | (o_res["status"] == 5) | (o_res["status"] == 6)      # (LOWQ and module rejects carry both sums too, assembler.c:244-247)
+    for name, o_name in (("quality", "quality"), ("est_overlap_prob", "est_prob")):     # the two ordered sums: the very bits
+        d_bits, o_bits = res[name][merged].view(np.uint64), o_res[o_name][merged].view(np.uint64)
+        assert np.array_equal(d_bits, o_bits), (name, int((d_bits != o_bits).sum()), np.nonzero(merged)[0][np.nonzero(d_bits != o_bits)[0][:8]])
+    assert not res["est_overlap_prob"][~merged].any() and not res["quality"][~merged].any()     # a pair that did not merge has neither
+    d_nt, d_p = pa.row_checksums(b.results, b.seq_nt, b.seq_p)
+    assert np.array_equal(d_nt.cpu().numpy().view(np.uint64), o_cs_nt) and np.array_equal(d_p.cpu().numpy().view(np.uint64), o_cs_p)
+    compare_counters(b.counters_dict(), o_ctr)
+
+
 @pytest.mark.parametrize("algo", ["simple_bayesian", "pear", "rdp_mle"])
 def test_adversarial_strided(built, algo, sums):
     import pandaseq_amd as pa

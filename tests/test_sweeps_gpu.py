@@ -121,11 +121,15 @@ def _launch(pa, bench, synth, cfg, mode, rows, n, sums_exact, primers_after=Fals
     return asm, b
 
 
+@pytest.mark.parametrize("sums", ["fast", "exact"])
 @pytest.mark.parametrize("cfg", [1, 2, 3, 4], ids=lambda c: f"config{c}-8Mpairs-start{ROUND}0M")
-def test_lean_plus_general_equals_general_alone(built, cfg):
-    """The two-kernel launch defers, never approximates: on 8 M pairs of each BASELINE configuration (any-order sums, the
-    bench's mode) every record field, every counter and every merged base and log-p of every accepted pair is what the
-    general kernel alone produces.  `quality` (and the pear / rdp_mle score) are sums in any order in both: within 1e-9."""
+def test_lean_plus_general_equals_general_alone(built, cfg, sums):
+    """The two-kernel launch defers, never approximates: on 8 M pairs of each BASELINE configuration every record field, every
+    counter and every merged base and log-p of every accepted pair is what the general kernel alone produces.  Any-order sums
+    (the bench's mode): `quality` and the pear / rdp_mle score are sums in any order in both, within 1e-9.  Sums in the
+    reference's order (round 5): both doubles BIT for bit -- the lean kernel makes them in its group walk (63 or 60 chains at a
+    time from scratch rows of table entries, every wave through some two thousand pairs: full groups, the finish after 63 / 60
+    pairs, the last partial group), the general kernel in its own in-wave finish from the f64 rows."""
     import torch
     sys.path.insert(0, ROOT)
     import bench
@@ -134,17 +138,18 @@ def test_lean_plus_general_equals_general_alone(built, cfg):
     n = 8_000_000
     spec = synth.config_spec(cfg)
     rows = synth.generate_device(spec, ROUND * 10_000_000, n)
-    asm_a, a = _launch(pa, bench, synth, cfg, "two-kernel", rows, n, False)
+    exact = sums == "exact"
+    asm_a, a = _launch(pa, bench, synth, cfg, "two-kernel", rows, n, exact)
     assert asm_a.last_launch_info() is not None
     deferred = asm_a.last_deferred()
     assert 0 <= deferred < n // 4, f"the lean kernel deferred {deferred} of {n} pairs"
-    asm_b, b = _launch(pa, bench, synth, cfg, "general", rows, n, False)
+    asm_b, b = _launch(pa, bench, synth, cfg, "general", rows, n, exact)
     assert np.array_equal(a.counters.cpu().numpy(), b.counters.cpu().numpy()), "counters"
     ra, rb = a.results_numpy(), b.results_numpy()
     for name in ra.dtype.names:
         if name in ("seq_offset", "reserved"):
             continue
-        if name in ("quality", "est_overlap_prob"):
+        if name in ("quality", "est_overlap_prob") and not exact:
             ok = np.abs(ra[name] - rb[name]) <= 1e-9 * np.maximum(1.0, np.abs(rb[name]))
         else:
             ok = ra[name] == rb[name]

@@ -1,12 +1,23 @@
-O=gpurun_out/r05_sweeps; mkdir -p $O
-timeout 1500 python tests/parity_sweep.py 24 plain 11000 > $O/parity_plain4.log 2>&1; tail -1 $O/parity_plain4.log
-timeout 1500 python tests/parity_sweep.py 24 wide 11100 > $O/parity_wide4.log 2>&1; tail -1 $O/parity_wide4.log
-timeout 900 python tests/primer_sweep.py 100 11200 > $O/primer4.log 2>&1; tail -1 $O/primer4.log
-timeout 900 python tests/primer_sweep.py 80 11400 after > $O/primer_after4.log 2>&1; tail -1 $O/primer_after4.log
-timeout 600 python tests/primer_sweep.py 40 11600 penalty > $O/primer_penalty4.log 2>&1; tail -1 $O/primer_penalty4.log
-timeout 900 python tests/length_sweep.py 48 11700 > $O/length4.log 2>&1; tail -1 $O/length4.log
-timeout 600 python tests/compat_sweep.py 60 11800 > $O/compat4.log 2>&1; tail -1 $O/compat4.log
-timeout 600 python tests/per_pair_sweep.py 40 11900 > $O/per_pair4.log 2>&1; tail -1 $O/per_pair4.log
-timeout 600 python tests/textio_sweep.py 100 12000 > $O/textio4.log 2>&1; tail -1 $O/textio4.log
-timeout 300 python tests/stress_determinism.py > $O/determinism4.log 2>&1; tail -1 $O/determinism4.log
-grep -l "MISMATCH" $O/*4.log
+#!/bin/bash
+# scratch: which pairs differ between lean+general and general alone, sums in the reference's order, config 2
+cd "$(dirname "$0")/.."
+python3 - <<'PY'
+import sys, numpy as np, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import bench, pandaseq_amd as pa
+from pandaseq_amd import synth
+import test_sweeps_gpu as t
+n = 2_000_000
+rows = synth.generate_device(synth.config_spec(2), 50_000_000, n)
+asm_a, a = t._launch(pa, bench, synth, 2, "two-kernel", rows, n, True)
+print("variant", asm_a.last_lean_variant(), "deferred", asm_a.last_deferred())
+asm_b, b = t._launch(pa, bench, synth, 2, "general", rows, n, True)
+ra, rb = a.results_numpy(), b.results_numpy()
+bad = np.nonzero(ra["est_overlap_prob"] != rb["est_overlap_prob"])[0]
+print(len(bad), "differ")
+print("statuses", np.unique(ra["status"][bad], return_counts=True), np.unique(rb["status"][bad], return_counts=True))
+for i in bad[:10]:
+    print(i, ra[i], rb[i])
+badq = np.nonzero(ra["quality"] != rb["quality"])[0]
+print(len(badq), "quality differ", np.unique(ra["status"][badq], return_counts=True))
+PY
