@@ -2487,7 +2487,14 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 	const unsigned n_pairs = (unsigned) P.n_pairs;
 	// Persistent loop with a one-pair software prefetch: the four loads of pair k+1 (two lengths, two rows) are
 	// issued, branch-free, before pair k is assembled and are first touched when k is done.
-	unsigned pair = blockIdx.x * (unsigned) nwaves + (unsigned) wave;
+	// Which pairs a wave takes.  Strided (pair w, w + W, w + 2W, .. for wave w of W): even to the last pair, but a read's row is
+	// not a whole number of cache lines and its neighbours belong to other waves, which drift apart by far more than a line lives
+	// in the L2 -- every row fetches its first and last line whole, and every 2-byte length a sector (config 1: 1 230 B read per
+	// pair for 1 000, config 4: 983 for 600).  In blocks (P.pair_blocks, large launches): F consecutive pairs, F = the pairs of one
+	// finish, then the block W * F further on -- consecutive rows come one pair's time apart, and a finish writes F consecutive records.
+	constexpr unsigned F = EXACT ? (unsigned) ((EXACT && !counting_algo<ALGO>() ? 4 : 3) * fk_xg<EXACT && !counting_algo<ALGO>()>()) : 64u;
+	const unsigned step_in = P.pair_blocks ? 1u : total_waves;
+	unsigned pair = (blockIdx.x * (unsigned) nwaves + (unsigned) wave) * (P.pair_blocks ? F : 1u);
 	const unsigned last = n_pairs - 1u;
 	unsigned q = pair < n_pairs ? pair : last;
 	Carry<LONG> cur;
@@ -2510,7 +2517,7 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 	};
 	unsigned group_first = pair;
 	while (pair < n_pairs) {
-		const unsigned next = pair + total_waves;
+		const unsigned next = npend + 1 == (int) F ? group_first + total_waves * F : pair + step_in;	// (strided: the same pair either way)
 		q = next < n_pairs ? next : last;
 		Carry<LONG> nxt;
 		load_pair<LONG, EXACT>(nxt, P, q, lane);
@@ -2530,8 +2537,8 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 			take_group(npend - XG, XG);
 			xg = 0;
 		}
-		if (npend == (EXACT ? (XSCORE ? 4 : 3) * XG : 64)) {
-			finish64<false, true, false>(P, lctr, pd, npend, group_first, total_waves, lane);
+		if (npend == (int) F) {
+			finish64<false, true, false>(P, lctr, pd, npend, group_first, step_in, lane);
 			npend = 0;
 			group_first = next;
 		}
@@ -2540,7 +2547,7 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 	if (EXACT && xg != 0)
 		take_group(npend - xg, xg);
 	if (npend > 0)
-		finish64<false, true, false>(P, lctr, pd, npend, group_first, total_waves, lane);
+		finish64<false, true, false>(P, lctr, pd, npend, group_first, step_in, lane);
 	__syncthreads();
 	if (P.counters != nullptr) {
 		for (unsigned i = tid; i < PAMD_NUM_COUNTERS; i += blockDim.x) {
@@ -2638,6 +2645,9 @@ size_t pamd_fast_scratch_bytes(const PamdKernelParams &p, int workgroups, int wa
 	return (size_t) workgroups * (size_t) waves_per_wg * (size_t) FK_XG_MAX * (size_t) fk_xstride<true, true>() * sizeof(uint16_t);	// (an upper bound over the instantiations)
 }
 
+#ifndef FK_BLOCKS_MIN
+#define FK_BLOCKS_MIN 32ull
+#endif
 int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg, size_t lds_bytes, void *stream) {
 	const dim3 grid((unsigned) workgroups), block((unsigned) waves_per_wg * 64u);
 	hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2695,12 +2705,21 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 		pamd_set_error("the lean kernel's dense geometry needs symmetric matrices (algorithm %d)", p.algo);
 		return PAMD_EINVAL;
 	}
+	// pairs in blocks (see the kernel): when every wave has FK_BLOCKS_MIN blocks or more, so that the last, uneven round of blocks
+	// is a small share of the launch
+	PamdKernelParams pk = p;
+	{
+		const unsigned long long per_finish = !p.exact_sums ? 64ull : (p.algo == PAMD_ALGO_PEAR || p.algo == PAMD_ALGO_RDP_MLE ? 60ull : 63ull);
+		pk.pair_blocks = p.n_pairs >= (unsigned long long) workgroups * (unsigned long long) waves_per_wg * per_finish * FK_BLOCKS_MIN ? 1 : 0;
+		if (const char *e = getenv("PAMD_FK_BLOCKS"))	// measurements only
+			pk.pair_blocks = atoi(e) != 0;
+	}
 	hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);
 	if (e0 != hipSuccess) {
 		pamd_set_error("hipFuncSetAttribute(%zu bytes LDS, lean kernel): %s", lds_bytes, hipGetErrorString(e0));
 		return PAMD_ENODEVICE;
 	}
-	hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, p);
+	hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, pk);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) {
 		pamd_set_error("lean kernel launch: %s", hipGetErrorString(e));

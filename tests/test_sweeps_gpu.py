@@ -39,25 +39,28 @@ def _verdict(name, bad, done, want_done, lines):
     assert bad == 0, f"{name}: {bad} of {done} launches differ from the oracle:\n" + "\n".join(l for l in lines if l.startswith("MISMATCH"))
 
 
-# (campaign, mode, first round, rounds, launches the slice must have compared)
+# (campaign, mode, first round, rounds, launches the slice must have compared, pairs per launch | copies of the round's 3 000)
 # parity: per round 4 configurations x (7 + 7 + 3 + 7 scorers) x 2 sum modes = 48 launches
-PARITY = [("plain", 100 * ROUND, 8, 8 * 48), ("wide", 100 * ROUND, 12, 12 * 48)]
-PRIMER = [("plain", 2000 * ROUND, 60, 120), ("after", 2000 * ROUND + 500, 20, 40), ("penalty", 2000 * ROUND + 700, 20, 40)]
+# The last slice of each (round 5): launches of 100 000 pairs, where every wave of the lean kernel goes through whole groups of its
+# reference-order sums and several finishes (2 000 pairs are less than one per wave); the rows there through their checksums.
+PARITY = [("plain", 100 * ROUND, 8, 8 * 48, 2000), ("wide", 100 * ROUND, 12, 12 * 48, 2000), ("wide", 100 * ROUND + 50, 3, 3 * 48, 100_000)]
+PRIMER = [("plain", 2000 * ROUND, 60, 120, 1), ("after", 2000 * ROUND + 500, 20, 40, 1), ("penalty", 2000 * ROUND + 700, 20, 40, 1),
+          ("plain", 2000 * ROUND + 800, 9, 18, 30), ("after", 2000 * ROUND + 900, 9, 18, 30)]
 
 
-@pytest.mark.parametrize("mode,first,rounds,launches", PARITY, ids=[f"parity-{m}-first{f}-rounds{r}-launches{l}" for m, f, r, l in PARITY])
-def test_parity_campaign(built, mode, first, rounds, launches):
+@pytest.mark.parametrize("mode,first,rounds,launches,n", PARITY, ids=[f"parity-{m}-first{f}-rounds{r}-launches{l}-pairs{n}" for m, f, r, l, n in PARITY])
+def test_parity_campaign(built, mode, first, rounds, launches, n):
     import parity_sweep
     lines = []
-    bad, done = parity_sweep.run(rounds, mode == "wide", first, n=2000, log=_log(lines))
+    bad, done = parity_sweep.run(rounds, mode == "wide", first, n=n, log=_log(lines))
     _verdict(f"parity_sweep {mode}", bad, done, launches, lines)
 
 
-@pytest.mark.parametrize("mode,first,rounds,launches", PRIMER, ids=[f"primer-{m}-first{f}-rounds{r}-launches{l}" for m, f, r, l in PRIMER])
-def test_primer_campaign(built, mode, first, rounds, launches):
+@pytest.mark.parametrize("mode,first,rounds,launches,copies", PRIMER, ids=[f"primer-{m}-first{f}-rounds{r}-launches{l}-copies{c}" for m, f, r, l, c in PRIMER])
+def test_primer_campaign(built, mode, first, rounds, launches, copies):
     import primer_sweep
     lines = []
-    bad, done = primer_sweep.run(rounds, first, mode, log=_log(lines))
+    bad, done = primer_sweep.run(rounds, first, mode, log=_log(lines), copies=copies)
     _verdict(f"primer_sweep {mode}", bad, done, launches, lines)
 
 
