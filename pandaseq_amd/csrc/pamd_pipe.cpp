@@ -6,6 +6,8 @@
 // directions of the link busy while they run:
 //
 //   reader threads   pread() blocks of each input file into a ring of PINNED blocks           (async.c's reader, per block)
+//                    -- a gzip file, a FIFO or a terminal-less stdin-like path has one reader instead, which inflates / reads it
+//                    in order through zlib, as the reference opens every input (fileio.c:86-96); its size is known when it ends
 //   copier threads   one per input: hipMemcpyAsync of each block into a device ring, on a stream of its own
 //   the pump         (the calling thread) gathers a chunk's text from the two device rings behind the previous chunk's
 //                    unconsumed tail (device-to-device: records straddle blocks and the two files' records differ in size),
@@ -18,6 +20,7 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -74,9 +77,56 @@ struct Input {
 	std::vector<std::thread> readers;
 	std::thread copier;
 
+	gzFile gz = nullptr;		// a streamed input (gzip text, or not a regular file): read in order by one thread; `size` is ~0 until it ends
+
 	uint64_t block_len(uint64_t b) const {
 		const uint64_t at = b * block;
 		return at >= size ? 0 : std::min<uint64_t>(block, size - at);
+	}
+	uint64_t size_now() {
+		std::lock_guard<std::mutex> g(m);
+		return size;
+	}
+	void stream_main() {	// fileio.c:31-46's gzread(), a block at a time
+		for (uint64_t b = 0;; b++) {
+			{
+				std::unique_lock<std::mutex> g(m);
+				if (b >= limit)
+					return;
+				next_read = b + 1;
+				cv.wait(g, [&] { return sh->failed.load() || pin_free_upto + NB > b; });
+				if (sh->failed.load())
+					return;
+			}
+			char *dst = pin[b % NB];
+			uint64_t got = 0;
+			while (got < block) {
+				const int r = gzread(gz, dst + got, (unsigned) std::min<uint64_t>(block - got, 1u << 30));
+				if (r < 0) {
+					int e = 0;
+					const char *why = gzerror(gz, &e);
+					sh->fail("gzread", e == Z_ERRNO ? strerror(errno) : why);
+					cv.notify_all();
+					return;
+				}
+				if (r == 0)
+					break;
+				got += (uint64_t) r;
+			}
+			{
+				std::lock_guard<std::mutex> g(m);
+				if (got < block) {	// the input ends in this block
+					size = b * block + got;
+					n_blocks = got > 0 ? b + 1 : b;
+					limit = std::min(limit, n_blocks);
+				}
+				if (got > 0)
+					filled[b % NB] = b;
+			}
+			cv.notify_all();
+			if (got < block)
+				return;
+		}
 	}
 	void reader_main() {
 		for (;;) {
@@ -120,7 +170,7 @@ struct Input {
 			bool issue;
 			{
 				std::unique_lock<std::mutex> g(m);
-				cv.wait(g, [&] { return sh->failed.load() || b >= limit || (filled[b % NB] == b && consumed + (uint64_t) nr * block >= (b + 1) * block); });	// read, and its ring slot's previous bytes gathered
+				cv.wait(g, [&] { return sh->failed.load() || b >= limit || (filled[b % NB] == b && consumed >= (b + 1) * block - std::min<uint64_t>((b + 1) * block, (uint64_t) nr * block)); });	// read, and its ring slot's previous bytes gathered
 				if (sh->failed.load())
 					return;
 				issue = b < limit;
@@ -326,9 +376,14 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 	DeviceBuffers mem;
 	const char *paths[2] = { o->forward_path, o->reverse_path };
 	auto close_all = [&]() {
-		for (Input &s : in)
-			if (s.fd >= 0)
+		for (Input &s : in) {
+			if (s.gz)
+				gzclose(s.gz);	// (closes the descriptor it was opened on)
+			else if (s.fd >= 0)
 				close(s.fd);
+			s.gz = nullptr;
+			s.fd = -1;
+		}
 		if (out.fd >= 0)
 			close(out.fd);
 	};
@@ -342,12 +397,23 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 			return PAMD_EINVAL;
 		}
 		in[s].size = (uint64_t) sb.st_size;
+		unsigned char magic[2] = { 0, 0 };
+		if (!S_ISREG(sb.st_mode) || (pread(in[s].fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+			in[s].gz = gzdopen(in[s].fd, "rb");	// (reads plain text as it is: a FIFO need not carry gzip)
+			if (in[s].gz == nullptr) {
+				pamd_set_error("pamd_pipe_run: zlib cannot open %s", paths[s]);
+				close_all();
+				return PAMD_EINVAL;
+			}
+			gzbuffer(in[s].gz, 1u << 20);
+			in[s].size = ~0ull;
+		}
 		// blocks of a quarter of a chunk's text (64 KiB .. 32 MiB); a device ring of eight: twice what a chunk may ask for
 		uint64_t b = (text_cap / 4 + 65535) & ~65535ull;
 		b = std::min<uint64_t>(std::max<uint64_t>(b, 65536), 32u << 20);
 		in[s].block = b;
 		in[s].nr = (int) ((2 * text_cap + b - 1) / b) + 1;
-		in[s].n_blocks = in[s].limit = (in[s].size + b - 1) / b;
+		in[s].n_blocks = in[s].limit = in[s].gz ? ~0ull : (in[s].size + b - 1) / b;
 		for (uint64_t &f : in[s].filled)
 			f = ~0ull;
 	}
@@ -420,8 +486,11 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 	}
 	const int n_readers = o->reader_threads > 0 ? o->reader_threads : 3, n_writers = o->writer_threads > 0 ? o->writer_threads : 1;
 	for (Input &s : in) {
-		for (int t = 0; t < n_readers; t++)
-			s.readers.emplace_back(&Input::reader_main, &s);
+		if (s.gz)
+			s.readers.emplace_back(&Input::stream_main, &s);
+		else
+			for (int t = 0; t < n_readers; t++)
+				s.readers.emplace_back(&Input::reader_main, &s);
 		s.copier = std::thread(&Input::copier_main, &s);
 	}
 	for (int t = 0; t < n_writers; t++)
@@ -457,7 +526,7 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 				sh.fail("hipMemcpyAsync", "gather");
 			pos[s] += take;
 			have[s] = tail_len[s] + take;
-			more_input |= pos[s] < in[s].size;
+			more_input |= pos[s] < in[s].size_now();
 		}
 		if (sh.failed.load())
 			break;
@@ -568,7 +637,7 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 			std::lock_guard<std::mutex> g(s.m);
 			s.limit = std::min(s.limit, s.next_read);
 		}
-		s.publish_consumed(s.size + (uint64_t) s.nr * s.block);
+		s.publish_consumed(~0ull);
 		for (std::thread &t : s.readers)
 			t.join();
 		s.copier.join();

@@ -204,3 +204,61 @@ def test_reference_file_api_with_reference_headers(built, tmp_path):
     got, stat, stop = _run_open(exe, tmp_path, ft, rt, "rdp_mle")
     want, ctr, st = _oracle_text(ft, rt, "rdp_mle", "fasta")
     assert got == want and stat["OK"] == int(ctr["ok"])
+
+
+@pytest.mark.parametrize("which", ["both", "forward", "reverse"])
+def test_gzip_inputs(pipe, tmp_path, which):
+    """fileio.c:86-96 opens every input through zlib; the pump does when a file begins with the gzip magic: one reader inflating in
+    order, the size known only at the end, blocks of 64 KiB (chunks of 700 pairs), several gzip members in one file (zlib reads
+    them on, as `cat a.gz b.gz` needs)."""
+    import gzip
+    ft, rt = util.random_fastq(9000, 43)
+    want, ctr, st = _oracle_text(ft, rt, "simple_bayesian", "fasta")
+    f, r, o = tmp_path / "f.fastq.gz", tmp_path / "r.fastq", tmp_path / "out.txt"
+    half = ft.index(b"\n@", len(ft) // 2) + 1
+    f.write_bytes((gzip.compress(ft[:half]) + gzip.compress(ft[half:])) if which != "reverse" else ft)
+    r.write_bytes(gzip.compress(rt, 1) if which != "forward" else rt)
+    out = subprocess.check_output([pipe, str(f), str(r), str(o), str(po.ALGO["simple_bayesian"]), "fasta", "700"], timeout=300).decode()
+    assert o.read_bytes() == want
+    stat = {k: int(v) for k, v in (line.split("\t")[1:3] for line in out.splitlines() if line.startswith("STAT"))}
+    assert stat["READS"] == int(ctr["count"]) and stat["OK"] == int(ctr["ok"])
+
+
+def test_inputs_from_fifos(pipe, tmp_path):
+    """Inputs that are not regular files (`-f <(bzcat x.bz2)`): read in order, no size to go by."""
+    import threading
+    ft, rt = util.random_fastq(6000, 44)
+    want, ctr, st = _oracle_text(ft, rt, "pear", "fastq")
+    f, r, o = tmp_path / "f.fifo", tmp_path / "r.fifo", tmp_path / "out.txt"
+    os.mkfifo(f)
+    os.mkfifo(r)
+
+    def feed(path, text):
+        with open(path, "wb") as h:
+            for at in range(0, len(text), 50_000):
+                h.write(text[at:at + 50_000])
+    feeders = [threading.Thread(target=feed, args=(f, ft)), threading.Thread(target=feed, args=(r, rt))]
+    for t in feeders:
+        t.start()
+    subprocess.check_output([pipe, str(f), str(r), str(o), str(po.ALGO["pear"]), "fastq", "1000"], timeout=300)
+    for t in feeders:
+        t.join()
+    assert o.read_bytes() == want
+
+
+def test_truncated_gzip_is_the_end_of_the_input(pipe, tmp_path):
+    """A gzip stream cut short: zlib hands out what it could inflate and then reports the end of the file, and fileio.c:31-46 takes
+    that for the end of the input (gzread() < 1, gzeof() true) -- so does the pump: the pairs before the cut, then a record
+    without its end."""
+    import gzip
+    import zlib
+    ft, rt = util.random_fastq(4000, 45)
+    f, r, o = tmp_path / "f.fastq.gz", tmp_path / "r.fastq.gz", tmp_path / "out.txt"
+    cut = gzip.compress(ft)[:-2000]
+    f.write_bytes(cut)
+    r.write_bytes(gzip.compress(rt))
+    seen = zlib.decompressobj(31).decompress(cut)
+    assert 0 < len(seen) < len(ft)
+    want, ctr, st = _oracle_text(seen, rt, "simple_bayesian", "fasta")
+    subprocess.check_output([pipe, str(f), str(r), str(o), str(po.ALGO["simple_bayesian"]), "fasta", "700"], timeout=300)
+    assert o.read_bytes() == want and len(want) > 100_000

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--sink", default=None, help="write the output here instead of a file in --dir (e.g. /dev/null: the pump without the output file system)")
+    ap.add_argument("--gzip", action="store_true", help="gzip inputs (level 1; one member per 250 000 pairs): one inflating reader per file")
     args = ap.parse_args()
     import bench
     import bench_next
@@ -47,6 +48,10 @@ def main():
         pf, pr, po = (os.path.join(tmp, x) for x in ("f.fastq", "r.fastq", "out.fasta"))
         if args.sink:
             po = args.sink
+        if args.gzip:
+            import gzip
+            ft, rt = gzip.compress(ft, 1), gzip.compress(rt, 1)
+            pf, pr = pf + ".gz", pr + ".gz"
         with open(pf, "wb") as fh:
             for _ in range(reps):
                 fh.write(ft)
@@ -72,7 +77,7 @@ def main():
          "config": args.config, "pairs": n, "pairs_per_chunk": args.chunk, "seconds": best["process_seconds"], "pairs_per_s": n / best["process_seconds"],
          "pump_seconds": best["pump_seconds"], "pump_pairs_per_s": n / best["pump_seconds"], "setup_seconds": best["setup_seconds"],
          "input_bytes": in_bytes, "output_bytes": out_bytes, "input_GBps": in_bytes / best["process_seconds"] / 1e9, "pump_input_GBps": in_bytes / best["pump_seconds"] / 1e9,
-         "pump_output_GBps": out_bytes / best["pump_seconds"] / 1e9 if out_bytes else None, "sink": args.sink, "reader_threads_per_file": int(os.environ.get("PAMD_PIPE_READERS", 3)), "writer_threads": int(os.environ.get("PAMD_PIPE_WRITERS", 1)), "runs": runs}
+         "pump_output_GBps": out_bytes / best["pump_seconds"] / 1e9 if out_bytes else None, "sink": args.sink, "gzip_inputs": bool(args.gzip), "reader_threads_per_file": int(os.environ.get("PAMD_PIPE_READERS", 3)), "writer_threads": int(os.environ.get("PAMD_PIPE_WRITERS", 1)), "runs": runs}
     print(json.dumps(d))
     if args.out:
         with open(args.out, "w") as fh:
