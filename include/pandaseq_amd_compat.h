@@ -118,7 +118,7 @@ struct panda_algorithm_class {	/* pandaseq-common.h:594-605 */
 
 /* ---- constructors / lifetime (pandaseq-assembler.h:40-66,183-192) ---- */
 /* ---- the FASTQ reader (pandaseq.h:111-127,238-264, pandaseq-assembler.h:77-101), parsing whole chunks of text on
- * the device (pamd_compat_fastq.cpp).  Plain and gzip files; no bzip2, no separate index-read file (`index` must
+ * the device (pamd_compat_fastq.cpp).  Plain, gzip and bzip2 files (by their first two bytes, fileio.c:70-96; libbz2.so.1 is bound at run time); no separate index-read file (`index` must
  * be NULL). ---- */
 PandaNextSeq panda_create_fastq_reader(PandaBufferRead forward, void *forward_data, PandaDestroy forward_destroy, PandaBufferRead reverse, void *reverse_data, PandaDestroy reverse_destroy, PandaLogProxy logger, unsigned char qualmin, PandaTagging policy, PandaBufferRead index, void *index_data, PandaDestroy index_destroy, void **user_data, PandaDestroy *destroy);
 PandaBufferRead panda_open_buffer(const char *file_name, PandaLogProxy logger, void **user_data, PandaDestroy *destroy);
@@ -278,8 +278,8 @@ int panda_seqid_parse_fail(panda_seq_identifier *id, const char *input, PandaTag
 /* ---- the writer object and the two formatters of a result (pandaseq-writer.h:36-141, writer.c; pandaseq.h:293-304, output.c:85-126):
  * what a caller of panda_assembler_next() does with a record, under the reference's names and signatures.  A writer gathers
  * what a thread appends and hands it to its `write` callback, whole, when that thread commits (records of different threads
- * never interleave, as with the reference's per-thread buffers).  panda_writer_open_file() writes plain files (bzip: NULL, no
- * libbz2 here).  The batched formatter -- text made on the device for a whole batch -- is pamd_format_device()
+ * never interleave, as with the reference's per-thread buffers).  panda_writer_open_file() writes plain files, or bzip2 through
+ * libbz2.so.1 bound at run time (writer.c:147-151; NULL where that library cannot be loaded).  The batched formatter -- text made on the device for a whole batch -- is pamd_format_device()
  * (pandaseq_amd_io.h); these are the per-record forms. ---- */
 typedef struct panda_writer *PandaWriter;	/* pandaseq-common.h:117 */
 typedef void (*PandaBufferWrite) (const char *buffer, size_t buffer_length, void *data);	/* pandaseq-common.h:449-453 */

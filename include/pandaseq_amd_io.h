@@ -135,9 +135,9 @@ int pamd_format_last_kernel_ms(pamd_formatter *f, float *ms);
  * replaced by the device and the host reduced to keeping both directions of the PCIe link busy: reader threads pread() blocks
  * of either file into pinned memory, a copier thread per file sends them up on a stream of its own, the calling thread gathers
  * each chunk's text on the device (records straddle blocks; the unconsumed tail of a chunk is carried into the next), runs the
- * stages and sends the text back in pieces, writer threads pwrite() the pieces.  An input that is gzip text (by its first two bytes)
- * or not a regular file (a FIFO: `<(bzcat x.bz2)`) is read in order by ONE thread through zlib, the way the reference opens every
- * input (fileio.c:86-96; stats->in_bytes then counts the inflated text), at the rate zlib inflates; the output file is always plain.
+ * stages and sends the text back in pieces, writer threads pwrite() the pieces.  An input that is gzip or bzip2 text (by its first two
+ * bytes) or not a regular file (a FIFO) is read in order by ONE thread through zlib / libbz2, the way the reference opens every
+ * input (fileio.c:70-96; stats->in_bytes then counts the inflated text), at the rate those inflate; the output file is always plain.
  * The bytes written are those the reference's reader -> assembler -> output.c chain writes for the same input, in input order.
  *   a        a configured assembler (algorithm, primers, modules ... as set by the caller); its counters are not touched:
  *            the run's own are returned in stats->counters (PAMD_CTR_* of pandaseq_amd.h; as with pamd_fastq_parse_device,

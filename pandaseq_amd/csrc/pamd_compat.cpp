@@ -23,6 +23,7 @@
 #include <thread>
 #include <vector>
 #include "pamd_internal.h"
+#include "pamd_bz2.h"
 #include "pamd_host_scorers.h"
 
 static_assert(sizeof(panda_qual) == 2, "panda_qual ABI");
@@ -2119,6 +2120,14 @@ void file_write(const char *buffer, size_t buffer_length, void *file) {
 	if (fwrite(buffer, 1, buffer_length, static_cast<FILE *>(file)) != buffer_length)
 		perror("writer");
 }
+void bzip_write(const char *buffer, size_t buffer_length, void *data) {	// writer.c:108-114
+	int bzerror;
+	pamd_bz2()->bzWrite(&bzerror, data, const_cast<char *>(buffer), (int) buffer_length);
+}
+void bzip_close(void *data) {
+	pamd_bz2()->bzclose(data);
+}
+
 void null_write(const char *, size_t, void *) {
 }
 void close_file(void *file) {
@@ -2153,9 +2162,14 @@ PandaWriter panda_writer_new_stdout(void) {
 }
 
 PandaWriter panda_writer_open_file(const char *filename, bool bzip) {
-	if (bzip) {
-		pamd_set_error("%s: bzip2 output is not supported here (no libbz2 in this build)", filename);
-		return nullptr;
+	if (bzip) {	// writer.c:108-151: BZ2_bzopen / BZ2_bzWrite / BZ2_bzclose (libbz2 bound at run time, pamd_bz2.h)
+		const PamdBz2 *bz = pamd_bz2();
+		if (bz == nullptr) {
+			pamd_set_error("%s: bzip2 output needs libbz2.so.1, which cannot be loaded here", filename);
+			return nullptr;
+		}
+		void *file = bz->bzopen(filename, "w");
+		return file == nullptr ? nullptr : panda_writer_new(bzip_write, file, bzip_close);
 	}
 	FILE *file = fopen(filename, "w");
 	return file == nullptr ? nullptr : panda_writer_new_file(file);

@@ -16,6 +16,8 @@
 // (include/pandaseq_amd_io.h); this file is the drop-in for code written against
 // pandaseq.h.  The index-read file (`-i`, fastq.c:155-187) is not supported: with one the constructors fail.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +25,7 @@
 #include <new>
 #include <vector>
 #include "pamd_internal.h"
+#include "pamd_bz2.h"
 #include "../../include/pandaseq_amd_compat.h"
 #include "../../include/pandaseq_amd_io.h"
 
@@ -50,8 +53,14 @@ struct Source {
 		}
 		while (!eof && len < CHUNK_BYTES) {
 			size_t got = 0;
-			if (!read(buf.data() + len, CHUNK_BYTES - len, &got, data))
-				return false;
+			if (!read(buf.data() + len, CHUNK_BYTES - len, &got, data)) {
+				// linebuf.c:66-70 returns NULL at the first line it cannot complete: the whole lines already read are still handed
+				// out, the broken one is not (a bzip2 source ends this way: fileio.c:48-58 reports the call after BZ_STREAM_END)
+				eof = true;
+				while (len > 0 && buf[len - 1] != '\n')
+					len--;
+				break;
+			}
 			if (got == 0)
 				eof = true;
 			len += got;
@@ -204,6 +213,17 @@ void gz_close(void *user_data) {
 	gzclose(static_cast<gzFile>(user_data));
 }
 
+bool bz_read(char *buffer, size_t buffer_length, size_t *read, void *user_data) {	// fileio.c:48-58
+	int bzerror = 0;
+	const int got = pamd_bz2()->bzRead(&bzerror, user_data, buffer, (int) (buffer_length > (1u << 30) ? (1u << 30) : buffer_length));
+	*read = got > 0 ? (size_t) got : 0;
+	return bzerror == PAMD_BZ_OK || bzerror == PAMD_BZ_STREAM_END;
+}
+
+void bz_close(void *user_data) {
+	pamd_bz2()->bzclose(user_data);
+}
+
 int g_fastq_device = 0;
 
 }	// namespace
@@ -282,14 +302,30 @@ PandaBufferRead panda_open_buffer(const char *file_name, PandaLogProxy logger, v
 	(void) logger;
 	*user_data = nullptr;
 	*destroy = nullptr;
-	const size_t len = strlen(file_name);
-	if (len > 4 && strcmp(file_name + len - 4, ".bz2") == 0) {
-		pamd_set_error("%s: bzip2 input is not supported here (no libbz2 in this build); decompress it first", file_name);
+	char magic[2];
+	const int fd = open(file_name, O_RDONLY);
+	if (fd < 0 || ::read(fd, magic, 2) != 2 || lseek(fd, 0, SEEK_SET) != 0) {	// fileio.c:70-74
+		pamd_set_error("%s: cannot open", file_name);
+		if (fd >= 0)
+			close(fd);
 		return nullptr;
 	}
-	gzFile f = gzopen(file_name, "rb");	// reads gzip and plain files alike (fileio.c:86-96)
+	if (magic[0] == 'B' && magic[1] == 'Z') {	// fileio.c:75-85
+		const PamdBz2 *bz = pamd_bz2();
+		void *b = bz ? bz->bzdopen(fd, "r") : nullptr;
+		if (b == nullptr) {
+			pamd_set_error(bz ? "%s: cannot open" : "%s: bzip2 input needs libbz2.so.1, which cannot be loaded here", file_name);
+			close(fd);
+			return nullptr;
+		}
+		*user_data = b;
+		*destroy = bz_close;
+		return bz_read;
+	}
+	gzFile f = gzdopen(fd, "rb");	// reads gzip and plain files alike (fileio.c:86-96)
 	if (f == nullptr) {
 		pamd_set_error("%s: cannot open", file_name);
+		close(fd);
 		return nullptr;
 	}
 	gzbuffer(f, 1u << 20);

@@ -35,6 +35,7 @@
 #include <thread>
 #include <vector>
 #include "pamd_internal.h"
+#include "pamd_bz2.h"
 #include "../../include/pandaseq_amd_io.h"
 
 namespace {
@@ -78,6 +79,34 @@ struct Input {
 	std::thread copier;
 
 	gzFile gz = nullptr;		// a streamed input (gzip text, or not a regular file): read in order by one thread; `size` is ~0 until it ends
+	void *bz = nullptr;		// ... or bzip2 text (fileio.c:75-85)
+	bool streamed() const {
+		return gz != nullptr || bz != nullptr;
+	}
+	// up to `want` bytes of the stream; 0 = it has ended; < 0 = failed (message set)
+	long stream_read(char *dst, uint64_t want) {
+		const unsigned ask = (unsigned) std::min<uint64_t>(want, 1u << 30);
+		if (bz != nullptr) {
+			if (bz_ended)
+				return 0;	// (fileio.c:48-58 asks once more and takes the BZ_SEQUENCE_ERROR for the end: further streams of the file are not read there either)
+			int e = 0;
+			const int r = pamd_bz2()->bzRead(&e, bz, dst, (int) ask);
+			bz_ended = e == PAMD_BZ_STREAM_END;
+			if (e != PAMD_BZ_OK && e != PAMD_BZ_STREAM_END) {
+				sh->fail("BZ2_bzRead", ("libbz2 error " + std::to_string(e)).c_str());
+				return -1;
+			}
+			return r;
+		}
+		const int r = gzread(gz, dst, ask);
+		if (r < 0) {
+			int e = 0;
+			const char *why = gzerror(gz, &e);
+			sh->fail("gzread", e == Z_ERRNO ? strerror(errno) : why);
+		}
+		return r;
+	}
+	bool bz_ended = false;
 
 	uint64_t block_len(uint64_t b) const {
 		const uint64_t at = b * block;
@@ -101,11 +130,8 @@ struct Input {
 			char *dst = pin[b % NB];
 			uint64_t got = 0;
 			while (got < block) {
-				const int r = gzread(gz, dst + got, (unsigned) std::min<uint64_t>(block - got, 1u << 30));
+				const long r = stream_read(dst + got, block - got);
 				if (r < 0) {
-					int e = 0;
-					const char *why = gzerror(gz, &e);
-					sh->fail("gzread", e == Z_ERRNO ? strerror(errno) : why);
 					cv.notify_all();
 					return;
 				}
@@ -379,9 +405,12 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 		for (Input &s : in) {
 			if (s.gz)
 				gzclose(s.gz);	// (closes the descriptor it was opened on)
+			else if (s.bz)
+				pamd_bz2()->bzclose(s.bz);	// (likewise)
 			else if (s.fd >= 0)
 				close(s.fd);
 			s.gz = nullptr;
+			s.bz = nullptr;
 			s.fd = -1;
 		}
 		if (out.fd >= 0)
@@ -398,7 +427,17 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 		}
 		in[s].size = (uint64_t) sb.st_size;
 		unsigned char magic[2] = { 0, 0 };
-		if (!S_ISREG(sb.st_mode) || (pread(in[s].fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+		const bool regular = S_ISREG(sb.st_mode);
+		if (regular && pread(in[s].fd, magic, 2, 0) == 2 && magic[0] == 'B' && magic[1] == 'Z') {	// fileio.c:75-85
+			const PamdBz2 *bz = pamd_bz2();
+			in[s].bz = bz ? bz->bzdopen(in[s].fd, "r") : nullptr;
+			if (in[s].bz == nullptr) {
+				pamd_set_error(bz ? "pamd_pipe_run: libbz2 cannot open %s" : "pamd_pipe_run: %s is bzip2 text and libbz2.so.1 cannot be loaded here", paths[s]);
+				close_all();
+				return PAMD_EINVAL;
+			}
+			in[s].size = ~0ull;
+		} else if (!regular || (magic[0] == 0x1f && magic[1] == 0x8b)) {
 			in[s].gz = gzdopen(in[s].fd, "rb");	// (reads plain text as it is: a FIFO need not carry gzip)
 			if (in[s].gz == nullptr) {
 				pamd_set_error("pamd_pipe_run: zlib cannot open %s", paths[s]);
@@ -413,7 +452,7 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 		b = std::min<uint64_t>(std::max<uint64_t>(b, 65536), 32u << 20);
 		in[s].block = b;
 		in[s].nr = (int) ((2 * text_cap + b - 1) / b) + 1;
-		in[s].n_blocks = in[s].limit = in[s].gz ? ~0ull : (in[s].size + b - 1) / b;
+		in[s].n_blocks = in[s].limit = in[s].streamed() ? ~0ull : (in[s].size + b - 1) / b;
 		for (uint64_t &f : in[s].filled)
 			f = ~0ull;
 	}
@@ -486,7 +525,7 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 	}
 	const int n_readers = o->reader_threads > 0 ? o->reader_threads : 3, n_writers = o->writer_threads > 0 ? o->writer_threads : 1;
 	for (Input &s : in) {
-		if (s.gz)
+		if (s.streamed())
 			s.readers.emplace_back(&Input::stream_main, &s);
 		else
 			for (int t = 0; t < n_readers; t++)

@@ -427,7 +427,7 @@ def test_writer_and_output_functions(built, tmp_path):
     # a file writer as slave of the callback writer: committing the master commits what was appended to the slave as well
     path = tmp_path / "slave.txt"
     fw = L.panda_writer_open_file(str(path).encode(), False)
-    assert fw and L.panda_writer_open_file(str(tmp_path / "x.bz2").encode(), True) is None
+    assert fw
     L.panda_writer_set_slave(w, fw)
     assert L.panda_writer_get_slave(w) == fw
     L.panda_writer_set_slave(fw, w)          # a cycle is refused (writer.c:288-306)
@@ -440,3 +440,51 @@ def test_writer_and_output_functions(built, tmp_path):
     L.panda_writer_unref(fw)                 # (the master still holds it)
     L.panda_writer_unref(w)                  # closes the file through the slave's destroy
     assert path.read_bytes() == b"#42\n"
+
+
+def test_bzip2_in_and_out(lib, tmp_path):
+    """fileio.c:70-96 decides by an input's first two bytes -- "BZ": libbz2, anything else: zlib, which also reads plain text --
+    and writer.c:147-151 writes `-j` output through libbz2.  The library binds libbz2.so.1 at run time (pamd_bz2.h): a bzip2
+    writer's file inflates to what was committed, and panda_open_buffer() hands out the text of a bzip2, a gzip and a plain file
+    alike (the callback's `false` after the last bytes of a bzip2 stream is the reference's, fileio.c:48-58)."""
+    import bz2
+    import gzip
+    C = ctypes
+    L = lib
+    L.panda_writer_open_file.argtypes = [C.c_char_p, C.c_bool]
+    L.panda_writer_open_file.restype = C.c_void_p
+    L.panda_writer_append.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    for f in ("panda_writer_commit", "panda_writer_unref"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = None
+    w = L.panda_writer_open_file(str(tmp_path / "out.bz2").encode(), True)
+    assert w, "libbz2.so.1 is in this image"
+    for i in range(5000):
+        L.panda_writer_append(w, b">record %d\nACGTACGTTTGACA\n", i)
+        L.panda_writer_commit(w)
+    L.panda_writer_unref(w)
+    want = b"".join(b">record %d\nACGTACGTTTGACA\n" % i for i in range(5000))
+    assert bz2.decompress((tmp_path / "out.bz2").read_bytes()) == want
+
+    READ = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p)
+    DESTROY = C.CFUNCTYPE(None, C.c_void_p)
+    L.panda_open_buffer.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.panda_open_buffer.restype = C.c_void_p
+    text = b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(200_000))
+    for name, data in (("t.fastq.bz2", bz2.compress(text)), ("t.fastq.gz", gzip.compress(text)), ("t.fastq", text), ("noext", bz2.compress(text))):
+        (tmp_path / name).write_bytes(data)
+        ud, destroy = C.c_void_p(), C.c_void_p()
+        fn = L.panda_open_buffer(str(tmp_path / name).encode(), None, C.byref(ud), C.byref(destroy))
+        assert fn and destroy.value, name
+        read = READ(fn)
+        buf = C.create_string_buffer(1 << 20)
+        got, n = bytearray(), C.c_size_t(0)
+        while True:
+            more = read(C.cast(buf, C.c_void_p), len(buf), C.byref(n), ud)
+            got += buf.raw[:n.value]
+            if not more or n.value == 0:
+                break
+        DESTROY(destroy.value)(ud)
+        assert bytes(got) == text, name
+    ud, destroy = C.c_void_p(), C.c_void_p()
+    assert not L.panda_open_buffer(str(tmp_path / "absent").encode(), None, C.byref(ud), C.byref(destroy))

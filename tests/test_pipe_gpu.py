@@ -159,19 +159,21 @@ def open_client(built, tmp_path_factory):
 
 
 def _run_open(exe, tmp_path, ft, rt, algo, gz=False):
+    import bz2
     import gzip
     f, r, o = tmp_path / ("f.fastq.gz" if gz else "f.fastq"), tmp_path / ("r.fastq.gz" if gz else "r.fastq"), tmp_path / "out.fasta"
-    f.write_bytes(gzip.compress(ft, 1) if gz else ft)
-    r.write_bytes(gzip.compress(rt, 1) if gz else rt)
+    pack = {False: lambda t: t, True: lambda t: gzip.compress(t, 1), "bz2": bz2.compress}[gz]    # (the file's name says nothing: fileio.c:70-96 goes by its first two bytes)
+    f.write_bytes(pack(ft))
+    r.write_bytes(pack(rt))
     out = subprocess.check_output([exe, str(f), str(r), str(o), algo], timeout=600).decode()
     stat = {line.split("\t")[1]: int(line.split("\t")[2]) for line in out.splitlines() if line.startswith("STAT")}
     stop = int([line.split("\t")[1] for line in out.splitlines() if line.startswith("STOP")][0])
     return o.read_bytes(), stat, stop
 
 
-@pytest.mark.parametrize("algo,gz", [("simple_bayesian", False), ("pear", True), ("uparse", False)])
+@pytest.mark.parametrize("algo,gz", [("simple_bayesian", False), ("pear", True), ("uparse", False), ("rdp_mle", "bz2")])
 def test_reference_file_api(open_client, tmp_path, algo, gz):
-    """panda_assembler_open(forward, reverse, ...) on plain and gzip files, then the pool.c:76 loop: the FASTQ text is
+    """panda_assembler_open(forward, reverse, ...) on plain, gzip and bzip2 files, then the pool.c:76 loop: the FASTQ text is
     parsed on the device a chunk at a time behind the per-pair PandaNextSeq contract, names included."""
     ft, rt = util.random_fastq(3000, 47)
     got, stat, stop = _run_open(open_client, tmp_path, ft, rt, algo, gz)
@@ -260,5 +262,21 @@ def test_truncated_gzip_is_the_end_of_the_input(pipe, tmp_path):
     seen = zlib.decompressobj(31).decompress(cut)
     assert 0 < len(seen) < len(ft)
     want, ctr, st = _oracle_text(seen, rt, "simple_bayesian", "fasta")
+    subprocess.check_output([pipe, str(f), str(r), str(o), str(po.ALGO["simple_bayesian"]), "fasta", "700"], timeout=300)
+    assert o.read_bytes() == want and len(want) > 100_000
+
+
+@pytest.mark.parametrize("streams", [1, 2])
+def test_bzip2_inputs(pipe, tmp_path, streams):
+    """fileio.c:75-85: an input that begins with "BZ" is read through libbz2 (bound at run time here).  Two streams in one file
+    (what pbzip2 writes): BZ2_bzRead() stops at the end of the first and fileio.c:48-58 takes the next call's error for the end
+    of the input -- the pairs of the first stream, and nothing of the second, here as there."""
+    import bz2
+    ft, rt = util.random_fastq(5000, 46)
+    half = ft.index(b"\n@", len(ft) // 2) + 1
+    f, r, o = tmp_path / "f.fastq.bz2", tmp_path / "r.fastq.bz2", tmp_path / "out.txt"
+    f.write_bytes(bz2.compress(ft) if streams == 1 else bz2.compress(ft[:half]) + bz2.compress(ft[half:]))
+    r.write_bytes(bz2.compress(rt))
+    want, ctr, st = _oracle_text(ft if streams == 1 else ft[:half], rt, "simple_bayesian", "fasta")
     subprocess.check_output([pipe, str(f), str(r), str(o), str(po.ALGO["simple_bayesian"]), "fasta", "700"], timeout=300)
     assert o.read_bytes() == want and len(want) > 100_000
