@@ -137,7 +137,8 @@ int pamd_format_last_kernel_ms(pamd_formatter *f, float *ms);
  * each chunk's text on the device (records straddle blocks; the unconsumed tail of a chunk is carried into the next), runs the
  * stages and sends the text back in pieces, writer threads pwrite() the pieces.  An input that is gzip or bzip2 text (by its first two
  * bytes) or not a regular file (a FIFO) is read in order by ONE thread through zlib / libbz2, the way the reference opens every
- * input (fileio.c:70-96; stats->in_bytes then counts the inflated text), at the rate those inflate; the output file is always plain.
+ * input (fileio.c:70-96; stats->in_bytes then counts the inflated text), at the rate those inflate; the output is always plain text, into
+ * a file (pieces written at their offsets) or into something that cannot seek (a pipe, a FIFO: one writer, the pieces in order).
  * The bytes written are those the reference's reader -> assembler -> output.c chain writes for the same input, in input order.
  *   a        a configured assembler (algorithm, primers, modules ... as set by the caller); its counters are not touched:
  *            the run's own are returned in stats->counters (PAMD_CTR_* of pandaseq_amd.h; as with pamd_fastq_parse_device,

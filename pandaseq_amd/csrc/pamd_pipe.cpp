@@ -248,6 +248,7 @@ struct Output {
 	Shared *sh = nullptr;
 	int fd = -1;
 	static constexpr int NP = 6;
+	bool seekable = true;
 	uint64_t piece = 0;
 	char *pin[NP] = { nullptr };
 	hipEvent_t ev[NP] = { nullptr };
@@ -309,9 +310,11 @@ struct Output {
 			// 3.4-5.4 GB/s; fallocate first, then mappings, 7 GB/s; tools/probe/shm_rate.cpp, profiles/r05_pipe_shm_rate.txt)
 			uint64_t put = 0;
 			while (put < j.len && !sh->failed.load()) {
-				const ssize_t w = pwrite(fd, pin[j.slot] + put, j.len - put, (off_t) (j.off + put));
+				// (an output that cannot seek -- a pipe, a FIFO: `| bzip2 > merged.fasta.bz2` -- has one writer, which takes the
+				// pieces in the order they were queued: plain write())
+				const ssize_t w = seekable ? pwrite(fd, pin[j.slot] + put, j.len - put, (off_t) (j.off + put)) : write(fd, pin[j.slot] + put, j.len - put);
 				if (w <= 0) {
-					sh->fail("pwrite", strerror(errno));
+					sh->fail(seekable ? "pwrite" : "write", strerror(errno));
 					break;
 				}
 				put += (uint64_t) w;
@@ -462,6 +465,7 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 		close_all();
 		return PAMD_EINVAL;
 	}
+	out.seekable = lseek(out.fd, 0, SEEK_CUR) != (off_t) -1;
 	out.piece = std::min<uint64_t>(std::max<uint64_t>((out_cap / 4 + 65535) & ~65535ull, 65536), 32u << 20);
 
 	pamd_fastq_parser *fq = pamd_fastq_parser_create(device, o->qualmin ? o->qualmin : 33, o->policy);
@@ -523,7 +527,7 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 		destroy_all();
 		return PAMD_ENODEVICE;
 	}
-	const int n_readers = o->reader_threads > 0 ? o->reader_threads : 3, n_writers = o->writer_threads > 0 ? o->writer_threads : 1;
+	const int n_readers = o->reader_threads > 0 ? o->reader_threads : 3, n_writers = !out.seekable ? 1 : (o->writer_threads > 0 ? o->writer_threads : 1);
 	for (Input &s : in) {
 		if (s.streamed())
 			s.readers.emplace_back(&Input::stream_main, &s);

@@ -280,3 +280,20 @@ def test_bzip2_inputs(pipe, tmp_path, streams):
     want, ctr, st = _oracle_text(ft if streams == 1 else ft[:half], rt, "simple_bayesian", "fasta")
     subprocess.check_output([pipe, str(f), str(r), str(o), str(po.ALGO["simple_bayesian"]), "fasta", "700"], timeout=300)
     assert o.read_bytes() == want and len(want) > 100_000
+
+
+def test_output_into_a_pipe(pipe, tmp_path):
+    """An output that cannot seek (`... /dev/stdout | bzip2 > merged.bz2`): one writer, the pieces in order, plain write()."""
+    import threading
+    ft, rt = util.random_fastq(6000, 48)
+    want, ctr, st = _oracle_text(ft, rt, "simple_bayesian", "fastq")
+    f, r, o = tmp_path / "f.fastq", tmp_path / "r.fastq", tmp_path / "out.fifo"
+    f.write_bytes(ft)
+    r.write_bytes(rt)
+    os.mkfifo(o)
+    got = []
+    reader = threading.Thread(target=lambda: got.append(open(o, "rb").read()))
+    reader.start()
+    subprocess.check_output([pipe, str(f), str(r), str(o), str(po.ALGO["simple_bayesian"]), "fastq", "700"], env=dict(os.environ, PAMD_PIPE_WRITERS="3"), timeout=300)
+    reader.join()
+    assert got[0] == want and len(want) > 1_000_000
