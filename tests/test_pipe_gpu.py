@@ -297,3 +297,22 @@ def test_output_into_a_pipe(pipe, tmp_path):
     subprocess.check_output([pipe, str(f), str(r), str(o), str(po.ALGO["simple_bayesian"]), "fastq", "700"], env=dict(os.environ, PAMD_PIPE_WRITERS="3"), timeout=300)
     reader.join()
     assert got[0] == want and len(want) > 1_000_000
+
+
+def test_reader_stops_early_in_streamed_inputs(pipe, tmp_path):
+    """The reader gives up at a record far from the end of gzip inputs much longer than what has been read: what came before is
+    written, the streaming readers are wound down (no further block is inflated for nobody) and the run ends."""
+    import gzip
+    ft, rt = util.random_fastq(40_000, 50)
+    lines = ft.split(b"\n")
+    k = 4 * 3100 + 1
+    lines[k] = b"1" + lines[k][1:]
+    bad = b"\n".join(lines)
+    f, r, o = tmp_path / "f.fastq.gz", tmp_path / "r.fastq.gz", tmp_path / "out.txt"
+    f.write_bytes(gzip.compress(bad, 1))
+    r.write_bytes(gzip.compress(rt, 1))
+    out = subprocess.check_output([pipe, str(f), str(r), str(o), str(po.ALGO["simple_bayesian"]), "fasta", "500"], timeout=120).decode()
+    stop = [line.split("\t")[1:] for line in out.splitlines() if line.startswith("STOP")][0]
+    want, ctr, st = _oracle_text(bad, rt, "simple_bayesian", "fasta")
+    assert st.n_records == 3100 and (int(stop[0]), int(stop[1])) == (st.stop_code, 3100)
+    assert o.read_bytes() == want
