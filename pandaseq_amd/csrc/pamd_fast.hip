@@ -1696,7 +1696,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		STOP(1);
 		MARK("seed-rev");
 		int ncand = 0, ov0 = 0, ov1 = 0, ov2 = 0, ov3 = 0;
-		bool all = false, quick = false;
+		bool all = false;
+		int quick = 0;	// (an int: a wave-uniform bool that is set in nested branches comes out of them as a lane mask made from a 0 / 1 vector register)
 		// ---- seed: reverse k-mers flag candidate overlaps (assembler.c:104-110) ----
 		// The k-mer at p covers bases p .. p+7 and is emitted iff p <= rlen-9 and none of p .. p+8 is N: the codes of
 		// lanes l, l+1, l+2.  Its two smallest forward positions are the reference's first two (kmerseen[2k], [2k+1]).
@@ -1747,15 +1748,15 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 					m2[j] = hi < h ? hi : h;
 				}
 			}
-			bool second = false;
+			u64 second = 0;
 			unsigned idx1[BPL];	// the overlap (less minov) this k-mer's first forward position votes for; out of range: none
 #pragma unroll
 			for (int j = 0; j < BPL; j++) {
 				const unsigned idx = top - (unsigned) j - m1[j];	// no match: m1 >= 0x10000 wraps far beyond size
 				idx1[j] = ok[j] && idx < (unsigned) size ? idx : EMPTY;
-				second |= ok[j] && m2[j] < 0xFFFFu;	// (an empty slot reads as 0xFFFF for the k-mer 0xFFFF)
+				second |= ballot(ok[j]) & ballot(m2[j] < 0xFFFFu);	// (an empty slot reads as 0xFFFF for the k-mer 0xFFFF.  Two compares and scalar logic: the ballot of a conjunction goes through a vector register)
 			}
-			const bool twice = ballot(second) != 0;	// a k-mer that occurs twice in the forward read
+			const bool twice = second != 0;	// a k-mer that occurs twice in the forward read
 			// Nearly every pair's k-mers vote for one overlap, or for that and a stray one: settled here in registers, the
 			// candidates need neither the flag bytes nor the walk over them.
 			if (__builtin_expect(!twice, 1)) {
@@ -1774,7 +1775,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 					if (__builtin_expect(oth == 0, 1)) {
 						ncand = 1;
 						ov0 = (int) c0 + minov;
-						quick = true;
+						quick = 1;
 					} else {
 						const unsigned c1 = (unsigned) __builtin_amdgcn_readlane((int) other, __builtin_ctzll(oth));
 						bool third = false;
@@ -1785,7 +1786,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 							ncand = 2;
 							ov0 = (int) (c0 < c1 ? c0 : c1) + minov;	// ascending, as the scan walks them (assembler.c:120)
 							ov1 = (int) (c0 < c1 ? c1 : c0) + minov;
-							quick = true;
+							quick = 1;
 						}
 					}
 				}
@@ -2131,6 +2132,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			const unsigned ab = e_f & e_r;	// low byte: the bases the two reads agree on
 			const unsigned fq = e_f >> 8, rq = e_r >> 8;
 			const bool match = (ab & 0xFFu) != 0;
+			const u64 match_lanes = ballot(match);	// (taken where the comparison is made: past the B-cliff branch below the predicate has become a 0 / 1 register, and its ballot two more vector instructions)
 			unsigned nt = match ? ab : (fq < rq ? e_r : e_f);	// assembler.c:212-220 (low byte)
 			unsigned qi;
 			if (ALGO == PAMD_ALGO_EA_UTIL) {	// algo_ea_util.c:58-67
@@ -2156,7 +2158,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			nt = inF ? nt : e_r;
 			qi_out = qi;
 			nt_out = ok ? nt : 0u;
-			mism += __popcll(ballot(inF) & ballot(inR) & ~ballot(match));
+#ifndef FK_NO_COUNTS	/* experiment: what do the two counts of the merge cost? (results are wrong) */
+			mism += __popcll(ballot(inF) & ballot(inR) & ~match_lanes);
+#endif
 		};
 		// N rounds per trip, straight-line: their table reads are in flight together; trips nest so that nothing but the
 		// accumulators lives across them.  Four rounds per trip in the short geometry (a round past the row's end costs three
@@ -2207,7 +2211,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 						pmin = min_f64(pmin, above);
 					}
 				}
+#ifndef FK_NO_COUNTS
 				degen += __popcll(ballot((ntv[k] & 0xFFu) == 15u));	// PANDA_NT_IS_DEGN: only N here
+#endif
 			}
 		};
 		typedef std::integral_constant<int, 2> two;
