@@ -55,8 +55,8 @@ def test_reference_order_sums_through_full_groups(built, algo, cfg, after):
 
 
 @pytest.mark.parametrize("algo,cfg,after,exact", [("simple_bayesian", 1, False, False), ("simple_bayesian", 1, False, True), ("rdp_mle", 1, False, True),
-                                                  ("simple_bayesian", 4, False, False), ("pear", 2, False, False), ("pear", 2, False, True),
-                                                  ("pear", 2, True, True), ("uparse", 1, False, False)])
+                                                  ("simple_bayesian", 4, False, False), ("pear", 2, False, True), ("pear", 2, True, True),
+                                                  ("uparse", 1, False, False)])
 def test_pairs_in_blocks(built, monkeypatch, algo, cfg, after, exact):
     """The lean kernel's other assignment of pairs to waves (large launches: a wave takes blocks of consecutive pairs, one block per
     finish -- 64, or 63 / 60 with sums in the reference's order -- instead of every W-th pair), forced here on a launch whose last

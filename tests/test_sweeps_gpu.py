@@ -43,8 +43,8 @@ def _verdict(name, bad, done, want_done, lines):
 # parity: per round 4 configurations x (7 + 7 + 3 + 7 scorers) x 2 sum modes = 48 launches
 # The last slice of each (round 5): launches of 100 000 pairs, where every wave of the lean kernel goes through whole groups of its
 # reference-order sums and several finishes (2 000 pairs are less than one per wave); the rows there through their checksums.
-PARITY = [("plain", 100 * ROUND, 8, 8 * 48, 2000), ("wide", 100 * ROUND, 12, 12 * 48, 2000), ("wide", 100 * ROUND + 50, 3, 3 * 48, 100_000)]
-PRIMER = [("plain", 2000 * ROUND, 60, 120, 1), ("after", 2000 * ROUND + 500, 20, 40, 1), ("penalty", 2000 * ROUND + 700, 20, 40, 1),
+PARITY = [("plain", 100 * ROUND, 6, 6 * 48, 2000), ("wide", 100 * ROUND, 9, 9 * 48, 2000), ("wide", 100 * ROUND + 50, 3, 3 * 48, 100_000)]
+PRIMER = [("plain", 2000 * ROUND, 45, 90, 1), ("after", 2000 * ROUND + 500, 20, 40, 1), ("penalty", 2000 * ROUND + 700, 20, 40, 1),
           ("plain", 2000 * ROUND + 800, 9, 18, 30), ("after", 2000 * ROUND + 900, 9, 18, 30)]
 
 
@@ -64,7 +64,7 @@ def test_primer_campaign(built, mode, first, rounds, launches, copies):
     _verdict(f"primer_sweep {mode}", bad, done, launches, lines)
 
 
-LENGTH = (300 * ROUND, 16, 16 * 14)
+LENGTH = (300 * ROUND, 12, 12 * 14)
 
 
 @pytest.mark.parametrize("first,rounds,launches", [LENGTH], ids=["length-first%d-rounds%d-launches%d" % LENGTH])
