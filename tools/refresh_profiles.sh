@@ -58,6 +58,7 @@ python3 bench.py --config 3 --min-phred 3 --no-cpu --no-e2e --steps 3 --warmup 1
 python3 tools/pipeline_pcie.py --out "$OUT/pipeline_pcie.json" > "$OUT/pipeline_pcie.log" 2>&1
 python3 tools/pipe_file_rate.py --pairs 64000000 --reps 2 --out "$OUT/pipe_file_rate.json" > "$OUT/pipe_file_rate.log" 2>&1
 python3 tools/pipe_file_rate.py --pairs 64000000 --reps 2 --sink /dev/null --out "$OUT/pipe_null_rate.json" > "$OUT/pipe_null_rate.log" 2>&1
+python3 tools/pipe_file_rate.py --pairs 8000000 --reps 2 --gzip --sink /dev/null --out "$OUT/pipe_gzip_rate.json" > "$OUT/pipe_gzip_rate.log" 2>&1
 python3 bench.py --io --no-e2e --cpu-seconds 0 --steps 3 --warmup 1 2> /dev/null | tail -1 | python3 -c "import json,sys; json.dump(json.load(sys.stdin)['io'], open(sys.argv[1], 'w'), indent=1)" "$OUT/io_bench.json"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_io" -o t -- python3 "$ROOT/tools/bench_io.py" --pairs 4000000 > "$OUT/prof_io.log" 2>&1)
 python3 profiles/summarize_rocprof.py --like '%f%_kernel%' $(find "$OUT/prof_io" -name '*_results.db' | head -1) > "$OUT/io_rocprof.txt"
