@@ -175,8 +175,8 @@ int pamd_clear_modules(pamd_assembler *a);
 int pamd_set_exact_sums(pamd_assembler *a, int exact);
 /* Two kernels serve a launch: a lean one for ordinary pairs (reads of at most 256 bases holding only
  * A C G T N with qualities 0..46, a handful of seeded overlaps) and the general one, which then assembles whatever the
- * lean kernel deferred -- and everything, when the configuration is outside the lean kernel's (a maximum overlap, reads
- * longer than 320 bases, a primer penalty, `-a` with sums in the reference's order: DESIGN.md section 3).  Results do not
+ * lean kernel deferred -- and everything, when the configuration is outside the lean kernel's (a maximum overlap below the
+ * minimum, reads longer than 320 bases, a primer penalty, primers of more than 24 bases: DESIGN.md section 3).  Results do not
  * depend on which kernel produced them.  enable = 0 sends every pair
  * to the general kernel (tests use it to compare the two); default 1. */
 int pamd_set_fast_path(pamd_assembler *a, int enable);

@@ -1623,7 +1623,15 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		// This lane's four positions p = 4*lane + j.  The k-mer ending at p covers bases p-7 .. p and is emitted iff
 		// p >= 8 and none of the nine bases p-8 .. p is N (misc.h:41): both windows lie in the codes of lanes l-2, l-1, l
 		// (what lies before the read, like what lies behind it, reads as N).
-		const int maxov = flen < rlen ? flen : rlen;	// assembler.c:59 with no configured maximum
+		// The largest overlap looked at: the shorter read's length (assembler.c:79-80), or a configured maximum (assembler.c:59,
+		// 81-82): the smaller of it and flen + rlen - minov - offsets - 1.  Up to the shorter read's length that is this kernel's
+		// arithmetic with a smaller `size`; beyond it an overlap runs past a read's end (assembler.c:162,181,231's VEEZ / WEDGEZ),
+		// and below minov the bit list degenerates: the general kernel's pairs.  (Scalar selects, and the verdict rides on the
+		// test for a k-mer without a slot below: a branch of its own costs the pair loop two scalar registers it does not have.)
+		const int shorter = flen < rlen ? flen : rlen, room = flen + rlen - minov - fo - ro - 1;
+		const int cap = P.maxoverlap != 0 ? (P.maxoverlap < room ? P.maxoverlap : room) : shorter;
+		const bool beyond = cap > shorter || cap < minov;
+		const int maxov = beyond ? shorter : cap;	// (a pair that is handed on is seeded with the usual range: nothing of it is kept)
 		const int size = maxov - minov + 1;		// minov <= maxov here
 		bool deep = false;
 		{
@@ -1661,7 +1669,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 					addr[j] = lshl_add<2>(__builtin_amdgcn_ubfe(mul24(carry[j] >> 16, HASH_C), 14, 8), l2);
 				insert_all<BPL>(addr, carry);
 			}
-			bool lost = false;
+			bool lost = beyond;
 #pragma unroll
 			for (int j = 0; j < BPL; j++) {
 				// (measured and not kept, round 4: all of a lane's words sent through the last two tables under one test, one
@@ -2054,8 +2062,14 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		} else {
 			if (__builtin_expect(arena.cur + need16 > arena.end, 0)) {
 				u64 got = 0;
-				if (lane == 0)
-					got = atomicAdd(P.seq_cursor, P.arena_chunk);
+				if (lane == 0) {
+					// (the instruction itself: given atomicAdd() the compiler's atomic optimizer wraps it in a wave-wide prefix sum whose
+					// 64-bit multiply-add reads a register pair with an undefined upper half -- harmless, but that half can be a
+					// register with one of the bare LDS reads above pending, which tools/isa_hazards.py rightly refuses to tell apart)
+					u64 chunk = P.arena_chunk;
+					unsigned long long *cursor = P.seq_cursor;
+					asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(got) : "v"(cursor), "v"(chunk) : "memory");
+				}
 				const unsigned chunk16 = (unsigned) (P.arena_chunk >> 4);
 				arena.cur = (unsigned) uni((int) (unsigned) (got >> 4));	// (the cursor only ever moves by whole chunks: a multiple of 16)
 				arena.end = arena.cur + chunk16;
@@ -2572,8 +2586,8 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 // trims; PAMD_FAST_LONG: reads of at most 320 bases; PAMD_FAST_PRIM: the same with `-p` / `-q` primers (at most 24 bases, no
 // penalty) and / or trims.
 int pamd_fast_supports(const PamdKernelParams &p) {
-	if (p.maxoverlap != 0)
-		return 0;
+	if (p.maxoverlap != 0 && (p.maxoverlap < p.minoverlap || p.maxoverlap > 0x7FFF))
+		return 0;	// (a maximum the reads can reach is served pair by pair: fast_pair)
 	if (p.n_pairs > 0x7FFFFFFFull)
 		return 0;	// 32-bit pair indices in the kernel and in the deferred list
 	if (p.post_primers) {

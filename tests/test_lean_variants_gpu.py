@@ -50,7 +50,9 @@ def test_primers_after_routing(built):
 
 
 def test_what_the_lean_kernel_does_not_serve(built):
-    asm, _ = _run(1, tweak=lambda a: a.set_maximum_overlap(200))
+    asm, _ = _run(1, tweak=lambda a: a.set_maximum_overlap(200))    # (round 5: a maximum the reads can reach is served, tests/test_max_overlap_gpu.py)
+    assert asm.last_lean_variant() != "general"
+    asm, _ = _run(1, tweak=lambda a: (a.set_minimum_overlap(50), a.set_maximum_overlap(20)))     # a maximum below the minimum is not
     assert asm.last_lean_variant() == "general"
     asm, _ = _run(2, tweak=lambda a: a.set_primer_penalty(0.01))
     assert asm.last_lean_variant() == "general"
