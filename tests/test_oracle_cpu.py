@@ -498,3 +498,28 @@ def test_row_checksums_two_ways(built):
     w = np.arange(1, m + 1, dtype=np.uint64)
     assert int(o_nt[i]) == int((nt[i, :m].astype(np.uint64) * w).sum()) and int(o_p[i]) == int((p[i, :m].view(np.uint64) * w).sum(dtype=np.uint64))
     assert int(o_nt[res["status"] != 0].sum()) == 0
+
+
+def test_the_isa_hazard_scan_sees_what_it_is_for():
+    """tools/isa_hazards.py on listings made for it: a register read, written or carried across a branch between a bare
+    `ds_read_u16` and the wait is reported; the same code with the wait in place is not; M0 outside inline asm is."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_hazards
+
+    def kernel(body):
+        return ["_ZN12_GLOBAL__N_116pamd_fast_kernelILi0ELb0ELb0ELb0ELb0ELb0ELb0EEEv16PamdKernelParams:"] + body + ["\ts_endpgm"]
+    read = ["\t;;#ASMSTART", "\tds_read_u16 v7, v3 offset:128", "\t;;#ASMEND"]
+    wait = ["\ts_waitcnt lgkmcnt(0)"]
+    clean = kernel(read + ["\ts_add_i32 s4, s4, s5", "\tv_mov_b32_e32 v9, v8"] + wait + ["\tv_lshrrev_b32_e32 v1, 8, v7"])
+    assert isa_hazards.count_bare_reads(clean) == 1 and isa_hazards.scan_bare_reads(clean) == []
+    copied = kernel(read + ["\tv_mov_b32_e32 v9, v7"] + wait)
+    assert [h[3] for h in isa_hazards.scan_bare_reads(copied)] == [7]
+    overwritten = kernel(read + ["\tv_add_u32_e32 v7, v1, v2"] + wait)
+    assert [h[3] for h in isa_hazards.scan_bare_reads(overwritten)] == [7]
+    wide = kernel(read + ["\tv_mad_u64_u32 v[12:13], s[4:5], s13, v4, v[6:7]"] + wait)     # (the upper half of a 64-bit operand counts)
+    assert [h[3] for h in isa_hazards.scan_bare_reads(wide)] == [7]
+    across = kernel(read + ["\ts_cbranch_scc1 .LBB0_2", "\ts_waitcnt lgkmcnt(0)", ".LBB0_2:", "\tv_mov_b32_e32 v1, v7"])      # one path skips the wait
+    assert 7 in [h[3] for h in isa_hazards.scan_bare_reads(across)]    # (and -1: the kernel ends with the read still pending on that path)
+    both = kernel(read + ["\ts_cbranch_scc1 .LBB0_2", "\ts_waitcnt lgkmcnt(0)", "\ts_branch .LBB0_3", ".LBB0_2:", "\ts_waitcnt lgkmcnt(0)", ".LBB0_3:", "\tv_mov_b32_e32 v1, v7"])
+    assert isa_hazards.scan_bare_reads(both) == []
+    assert isa_hazards.scan_m0(kernel(["\ts_mov_b32 m0, s3"])) != [] and isa_hazards.scan_m0(kernel(["\t;;#ASMSTART", "\ts_mov_b32 m0, s3", "\t;;#ASMEND"])) == []
