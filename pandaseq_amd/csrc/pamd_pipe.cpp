@@ -6,8 +6,9 @@
 // directions of the link busy while they run:
 //
 //   reader threads   pread() blocks of each input file into a ring of PINNED blocks           (async.c's reader, per block)
-//                    -- a gzip file, a FIFO or a terminal-less stdin-like path has one reader instead, which inflates / reads it
-//                    in order through zlib, as the reference opens every input (fileio.c:86-96); its size is known when it ends
+//                    -- a gzip or bzip2 file, or an input that is not a regular file (a FIFO), has ONE reader instead, which
+//                    reads it in order through zlib / libbz2, as the reference opens every input (fileio.c:70-96); its size is
+//                    known when it ends
 //   copier threads   one per input: hipMemcpyAsync of each block into a device ring, on a stream of its own
 //   the pump         (the calling thread) gathers a chunk's text from the two device rings behind the previous chunk's
 //                    unconsumed tail (device-to-device: records straddle blocks and the two files' records differ in size),
