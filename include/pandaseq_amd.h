@@ -30,6 +30,7 @@ extern "C" {
 #endif
 
 #define PAMD_MAX_LEN 450	/* PANDA_MAX_LEN / configure.ac:8 */
+#define PAMD_MAX_NUM_KMERS 64	/* panda_assembler_new_kmer: "no more than 10" (pandaseq-assembler.h:58); 2 (the default) runs on the device, others on the host path */
 #define PAMD_MAX_MODULES 8
 #define PAMD_NUM_COUNTERS (8 + PAMD_MAX_MODULES + 2 * PAMD_MAX_LEN)
 
@@ -38,7 +39,7 @@ enum {
 	PAMD_EINVAL = -1,	/* bad argument / value outside the device domain */
 	PAMD_ENODEVICE = -2,	/* no HIP device, or HIP runtime error */
 	PAMD_ENOMEM = -3,
-	PAMD_EUNSUPPORTED = -4	/* e.g. num_kmers != 2: not on the device path */
+	PAMD_EUNSUPPORTED = -4	/* e.g. an algorithm class without a device form */
 };
 
 /* One base.  Byte-identical to panda_qual (pandaseq-common.h:210-219): nt is the one-hot

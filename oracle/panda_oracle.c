@@ -430,13 +430,17 @@ int po_result_phred(const po_tables *t, double p) {
 
 /* ------------------------------------------------------------------ align (assembler.c:48-250) */
 
+/* The reference's table is KMERSEEN_SIZE(num_kmers) = 65536 * num_kmers entries (assembler_support.c:82, misc.h:34).  The oracle keeps
+ * room for PO_MAX_NUM_KMERS of them per k-mer ("no more than 10", pandaseq-assembler.h:58) and bounds every index by the size the
+ * reference would have allocated. */
+#define PO_MAX_NUM_KMERS 16
 struct po_scratch {
-	uint16_t *seen;		/* 65536 * 2, zero when idle (assembler_support.c:82,94) */
+	uint16_t *seen;		/* 65536 * PO_MAX_NUM_KMERS, zero when idle (assembler_support.c:82,94) */
 };
 
 po_scratch *po_scratch_new(void) {
 	po_scratch *s = malloc(sizeof *s);
-	s->seen = calloc(65536 * 2, sizeof(uint16_t));
+	s->seen = calloc(65536 * PO_MAX_NUM_KMERS, sizeof(uint16_t));
 	return s;
 }
 
@@ -472,31 +476,39 @@ static int align(const po_config *c, const po_tables *t, po_scratch *sc, const p
 	size_t words = size / 32 + 1;
 	memset(bits, 0, words * sizeof(uint32_t));
 
-	/* :92-101 forward k-mers: keep the first two positions per k-mer (num_kmers == 2) */
+	/* :92-101 forward k-mers.  The free slot is LOOKED FOR at kmerseen[(kmer << 1) + j] (:94) and the position WRITTEN to
+	 * kmerseen[kmer * num_kmers + j] (:99): the same entry only for num_kmers == 2.  For any other value the test reads entries
+	 * that belong to other k-mers (k-mer k's own are [k * n, k * n + n)); the oracle does exactly that on one flat array.  With
+	 * num_kmers == 1 the test's index reaches 2 * 65535 in an array of 65536 entries: the reference reads beyond its allocation
+	 * there (undefined); defined here as "reads 0" (the slot is free).  num_kmers == 0: every k-mer is lost (j == num_kmers at once). */
+	const size_t nk = c->num_kmers < 0 ? 0 : (c->num_kmers > PO_MAX_NUM_KMERS ? PO_MAX_NUM_KMERS : (size_t) c->num_kmers);
+	const size_t table = nk << 16;	/* entries the reference allocates */
 	size_t nf = po_kmers_forward(F, flen, kf, pf);
 	for (size_t a = 0; a < nf; a++) {
-		uint16_t *slot = &sc->seen[(size_t) kf[a] << 1];
-		if (slot[0] == 0)
-			slot[0] = pf[a];
-		else if (slot[1] == 0)
-			slot[1] = pf[a];
-		/* else: lost k-mer */
+		size_t j;
+		for (j = 0; j < nk; j++) {
+			const size_t probe = ((size_t) kf[a] << 1) + j;
+			if (probe >= table || sc->seen[probe] == 0)
+				break;
+		}
+		if (j < nk)
+			sc->seen[(size_t) kf[a] * nk + j] = pf[a];
+		/* else: lost k-mer (:95-97) */
 	}
 	/* :104-110 reverse k-mers flag candidate overlaps */
 	size_t nr = po_kmers_reverse(R, rlen, kr, prv);
 	for (size_t a = 0; a < nr; a++) {
-		const uint16_t *slot = &sc->seen[(size_t) kr[a] << 1];
-		for (int j = 0; j < 2 && slot[j] != 0; j++) {
+		const uint16_t *slot = &sc->seen[(size_t) kr[a] * nk];
+		for (size_t j = 0; j < nk && slot[j] != 0; j++) {
 			int index = (int) (flen + rlen - prv[a] - slot[j] - minov - 1);
 			if (index >= 0 && (size_t) index < size)
 				bits[index / 32] |= 1u << (index % 32);
 		}
 	}
 	/* :113-116 reset */
-	for (size_t a = 0; a < nf; a++) {
-		sc->seen[((size_t) kf[a] << 1)] = 0;
-		sc->seen[((size_t) kf[a] << 1) + 1] = 0;
-	}
+	for (size_t a = 0; a < nf; a++)
+		for (size_t j = 0; j < nk; j++)
+			sc->seen[(size_t) kf[a] * nk + j] = 0;
 	/* :118 ALL_BITS_IF_NONE */
 	{
 		uint32_t any = 0;

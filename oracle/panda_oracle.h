@@ -99,7 +99,7 @@ typedef struct {
 	double threshold;			/* stored as log, assembler_support.c:76,391-397 */
 	int minoverlap;				/* default 2 */
 	int maxoverlap;				/* default 0 = min(flen, rlen) */
-	int num_kmers;				/* only 2 is meaningful (assembler.c:94 vs :99) */
+	int num_kmers;				/* default 2; any other value probes at (kmer << 1) + j and stores at kmer * n + j, as assembler.c:94 vs :99 do */
 	uint8_t fprimer[PO_MAX_LEN];
 	int fprimer_len;
 	uint8_t rprimer[PO_MAX_LEN];

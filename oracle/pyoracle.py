@@ -136,7 +136,7 @@ def tables_np():
 
 
 def make_config(algo="simple_bayesian", q=None, pear_random_base_log=None, threshold=None, minoverlap=None,
-                maxoverlap=None, fprimer=None, rprimer=None, ftrim=0, rtrim=0, primer_penalty=0.0, modules=(), primers_after=False):
+                maxoverlap=None, fprimer=None, rprimer=None, ftrim=0, rtrim=0, primer_penalty=0.0, modules=(), primers_after=False, num_kmers=None):
     """Mirror of the flag -> setter mapping of args_assembler.c:26-368 for the in-scope knobs.
     fprimer / rprimer are sequences of nt codes as the assembler stores them (the -q primer is
     already complemented, args_assembler.c:222)."""
@@ -171,6 +171,8 @@ def make_config(algo="simple_bayesian", q=None, pear_random_base_log=None, thres
     if 0 <= primer_penalty < 1:
         c.primer_penalty = primer_penalty
     c.post_primers = 1 if primers_after else 0  # `-a`, args_assembler.c
+    if num_kmers is not None:  # panda_assembler_new_kmer (assembler_support.c:80), args.c:384
+        c.num_kmers = int(num_kmers)
     c.n_modules = len(modules)
     for i, (kind, val) in enumerate(modules):
         if kind == "min_phred":

@@ -715,6 +715,12 @@ int device_algo_of(PandaAlgorithm algorithm, double *param_out = nullptr) {
 	return algo;
 }
 
+// pairs of this assembler are assembled one by one on the caller's thread (host_assemble): an algorithm class of the caller's, or
+// a k-mer table of other than two positions per k-mer (the kernels' seeding is the default's, num_kmers == 2)
+bool host_routed(PandaAssembler a) {
+	return device_algo_of(a->algo) < 0 || a->num_kmers != 2;
+}
+
 int push_config(PandaAssembler a) {
 	if (a->dev == nullptr) {	// (pamd_compat_host_only_assembler_new: a test hook; nothing but the per-pair host path works on it)
 		pamd_set_error("this assembler has no device: only panda_assembler_assemble() runs on it");
@@ -931,8 +937,9 @@ size_t host_primer_offset(double threshold, double penalty, size_t n, Base base,
 }
 
 struct host_scratch {
-	// first two forward positions per k-mer (assembler.c:94-99), each entry tagged with the pair it was written for
+	// the forward positions kept per k-mer (assembler.c:94-99), each entry tagged with the pair it was written for
 	// (tag << 16 | position; a stale tag reads as "none"), so the table is cleared once per 65 535 pairs and not per pair
+	// (65 536 x num_kmers entries, assembler_support.c:82; sized for the largest num_kmers this thread has seen)
 	std::vector<uint32_t> seen = std::vector<uint32_t>(2u << 16, 0);
 	uint32_t tag = 0;
 	std::vector<uint8_t> bits;
@@ -940,7 +947,12 @@ struct host_scratch {
 
 // align(), assembler.c:48-250
 bool host_align(PandaAssembler a, panda_result_seq &res, host_scratch &sc) {
-	assert(a->num_kmers == 2);	// two slots per k-mer below (panda_assembler_new_kmer admits nothing else)
+	// num_kmers (panda_assembler_new_kmer, assembler_support.c:80): the reference LOOKS FOR a free slot at kmerseen[(kmer << 1) + j]
+	// (assembler.c:94) and WRITES to kmerseen[kmer * num_kmers + j] (:99) -- one and the same entry only for 2, the default.  For any
+	// other value the test reads entries of other k-mers; reproduced as written, on one flat table.  (1: the test's index runs to
+	// 2 x 65 535 in a table of 65 536 entries -- the reference reads past its allocation; read here as "free".  0: every k-mer is lost.)
+	const size_t nk = a->num_kmers;
+	const size_t table = nk << 16;
 	const PamdTables &T = host_tables();
 	const struct panda_algorithm_class *cls = panda_algorithm_class(a->algo);
 	void *data = panda_algorithm_data(a->algo);
@@ -955,6 +967,10 @@ bool host_align(PandaAssembler a, panda_result_seq &res, host_scratch &sc) {
 		maxov = (size_t) a->maxoverlap;
 	const size_t size = minov <= maxov ? maxov - minov + 1 : 1;
 	sc.bits.assign(size, 0);
+	if (sc.seen.size() < table) {
+		sc.seen.assign(table, 0u);
+		sc.tag = 0;
+	}
 	if (++sc.tag == 0x10000u) {
 		std::fill(sc.seen.begin(), sc.seen.end(), 0u);
 		sc.tag = 1;
@@ -962,16 +978,19 @@ bool host_align(PandaAssembler a, panda_result_seq &res, host_scratch &sc) {
 	const uint32_t tag = sc.tag << 16;
 	// (a k-mer ends at position >= 8, so a stored position is never 0 and a zeroed entry never carries a live tag)
 	host_kmers(res.forward, flen, false, [&](size_t k, size_t p) {
-		uint32_t *slot = &sc.seen[2 * k];
-		if ((slot[0] ^ tag) >= 0x10000u)
-			slot[0] = tag | (uint32_t) p;
-		else if ((slot[1] ^ tag) >= 0x10000u)
-			slot[1] = tag | (uint32_t) p;
+		size_t j = 0;
+		for (; j < nk; j++) {
+			const size_t probe = (k << 1) + j;
+			if (probe >= table || (sc.seen[probe] ^ tag) >= 0x10000u)
+				break;
+		}
+		if (j < nk)
+			sc.seen[k * nk + j] = tag | (uint32_t) p;
 	});
 	bool any = false;
 	host_kmers(res.reverse, rlen, true, [&](size_t k, size_t p) {
-		for (int j = 0; j < 2 && (sc.seen[2 * k + j] ^ tag) < 0x10000u; j++) {
-			const ptrdiff_t index = (ptrdiff_t) (flen + rlen) - (ptrdiff_t) p - (ptrdiff_t) (sc.seen[2 * k + j] & 0xFFFFu) - (ptrdiff_t) minov - 1;
+		for (size_t j = 0; j < nk && (sc.seen[k * nk + j] ^ tag) < 0x10000u; j++) {
+			const ptrdiff_t index = (ptrdiff_t) (flen + rlen) - (ptrdiff_t) p - (ptrdiff_t) (sc.seen[k * nk + j] & 0xFFFFu) - (ptrdiff_t) minov - 1;
 			if (index >= 0 && (size_t) index < size) {
 				sc.bits[(size_t) index] = 1;
 				any = true;
@@ -2335,9 +2354,10 @@ PandaAssembler panda_assembler_new(PandaNextSeq next, void *next_data, PandaDest
 PandaAssembler panda_assembler_new_kmer(PandaNextSeq next, void *next_data, PandaDestroy next_destroy, PandaLogProxy logger, size_t num_kmers) {
 	pamd_assembler *dev = nullptr;
 	const int device = pick_device();
-	if (num_kmers != 2) {
-		// the reference's own table indexing only works for 2 (assembler.c:94 vs :99)
-		pamd_set_error("num_kmers = %zu is not supported on the device path (only 2)", num_kmers);
+	// num_kmers != 2 (assembler_support.c:80): the reference's table indexing is consistent only for 2 (assembler.c:94 vs :99); what it
+	// does for other values is reproduced pair by pair on the host path (host_align; host_routed() below), the kernels seed with 2
+	if (num_kmers > PAMD_MAX_NUM_KMERS) {
+		pamd_set_error("num_kmers = %zu: at most %d (the reference asks for \"no more than 10\", pandaseq-assembler.h:58)", num_kmers, PAMD_MAX_NUM_KMERS);
 	} else {
 		dev = pamd_assembler_create(device);
 	}
@@ -2373,6 +2393,14 @@ PandaAssembler pamd_compat_host_only_assembler_new(void) {
 	a->algo = panda_algorithm_simple_bayes_new();
 	memset(&a->result, 0, sizeof a->result);
 	a->result.sequence = a->result_seq;
+	return a;
+}
+// ... and one with a given num_kmers (panda_assembler_new_kmer, assembler_support.c:36-100)
+PandaAssembler pamd_compat_host_only_assembler_new_kmer(size_t num_kmers) {
+	if (num_kmers > PAMD_MAX_NUM_KMERS)
+		return nullptr;
+	PandaAssembler a = pamd_compat_host_only_assembler_new();
+	a->num_kmers = num_kmers;
 	return a;
 }
 
@@ -2444,7 +2472,7 @@ const panda_result_seq *panda_assembler_assemble(PandaAssembler a, panda_seq_ide
 	// class's two functions, as assembler.c:368-383 does: an upload, two launches and a download per pair cost 40 us, the pair
 	// itself 3.  Arrays (pamd_compat_assemble_many) and streams (panda_assembler_next) of pairs go to the kernels.
 	// PAMD_COMPAT_PER_PAIR=device / pamd_compat_set_per_pair_device(1) sends single pairs there too (tests compare the two).
-	if (device_algo_of(a->algo) < 0 || !compat_per_pair_device() || a->dev == nullptr)
+	if (host_routed(a) || !compat_per_pair_device() || a->dev == nullptr)
 		return host_assemble(a, id, forward, forward_length, reverse, reverse_length);
 	ensure_staging(a, 1);
 	stage_pair(a, 0, id, forward, forward_length, reverse, reverse_length);
@@ -2508,7 +2536,7 @@ size_t pamd_compat_assemble_many(PandaAssembler a, const panda_seq_identifier *i
 			return 0;
 		}
 	size_t assembled = 0;
-	if (device_algo_of(a->algo) < 0) {	// a class of the caller's: pair by pair through its own functions
+	if (host_routed(a)) {	// a class of the caller's, or num_kmers != 2: pair by pair on this thread
 		for (size_t i = 0; i < n; i++) {
 			if (forward_length[i] > PAMD_MAX_LEN || reverse_length[i] > PAMD_MAX_LEN) {	// the reference asserts (assembler.c:375-376)
 				fprintf(stderr, "pandaseq_amd: read longer than PANDA_MAX_LEN\n");
@@ -2579,7 +2607,7 @@ size_t pamd_compat_assemble_many(PandaAssembler a, const panda_seq_identifier *i
 const panda_result_seq *panda_assembler_next(PandaAssembler a) {
 	if (a->next == nullptr)
 		return nullptr;
-	if (device_algo_of(a->algo) < 0 && !a->primed) {	// a class of the caller's: pair by pair on this thread (assembler.c:350-371)
+	if (host_routed(a) && !a->primed) {	// a class of the caller's, or num_kmers != 2: pair by pair on this thread (assembler.c:350-371)
 		for (;;) {
 			const panda_qual *f = nullptr, *r = nullptr;
 			size_t fl = 0, rl = 0;

@@ -11,6 +11,7 @@
  *          many   pamd_compat_assemble_many() over all pairs at once (the device)
  *   options: -p <forward primer> -q <reverse primer> (one hex digit per base: the panda_nt code) -a (primers after assembly)
  *            -t <threshold> -o <minimum overlap> -O <maximum overlap> -T <primer penalty> -m <module spec, e.g. min_phred:4>
+ *            -k <num_kmers> (first option if given: the assembler is made by panda_assembler_new_kmer, assembler_support.c:36-100)
  *            -r <passes> (host / pair: that many untimed-output passes over the pairs first, every base read; prints pairs/s to stderr)
  *   out.bin: per pair: u32 returned?, then (if returned) u32 index, overlap, seq_len, mism, degen, fo, ro, examined, f64 quality,
  *            f64 est, seq_len nt bytes, seq_len f64 -- test_compat.c's record; then 10 i64: count, ok, noalgn, lowq, badr, slow,
@@ -25,6 +26,7 @@
 #include "pandaseq_amd_compat.h"
 
 PandaAssembler pamd_compat_host_only_assembler_new(void);	/* test hook of libpandaseq_amd (pamd_compat.cpp) */
+PandaAssembler pamd_compat_host_only_assembler_new_kmer(size_t num_kmers);
 
 static FILE *out;
 
@@ -76,9 +78,17 @@ int main(int argc, char **argv) {
 		return 3;
 	fclose(in);
 	const char *path = argv[4];
-	PandaAssembler a = strcmp(path, "host") == 0 ? pamd_compat_host_only_assembler_new() : panda_assembler_new(NULL, NULL, NULL, NULL);
+	size_t num_kmers = PANDA_DEFAULT_NUM_KMERS;
+	int first_option = 5;
+	if (argc >= 7 && strcmp(argv[5], "-k") == 0) {
+		num_kmers = (size_t) atol(argv[6]);
+		first_option = 7;
+	}
+	PandaAssembler a = strcmp(path, "host") == 0 ? pamd_compat_host_only_assembler_new_kmer(num_kmers) : panda_assembler_new_kmer(NULL, NULL, NULL, NULL, num_kmers);
 	if (a == NULL)
 		return 4;
+	if (panda_assembler_get_num_kmer(a) != num_kmers)
+		return 6;
 	PandaAlgorithm algo = NULL;
 	if (strcmp(argv[3], "pear") == 0)
 		algo = panda_algorithm_pear_new();
@@ -97,7 +107,7 @@ int main(int argc, char **argv) {
 	panda_assembler_set_algorithm(a, algo);
 	panda_algorithm_unref(algo);
 	int passes = 0;
-	for (int i = 5; i < argc; i++) {
+	for (int i = first_option; i < argc; i++) {
 		const char *o = argv[i];
 		if (strcmp(o, "-a") == 0) {
 			panda_assembler_set_primers_after(a, true);

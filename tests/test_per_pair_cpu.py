@@ -84,6 +84,42 @@ def test_host_path_with_overlap_bounds_and_threshold(client, tmp_path, algo):
     _check(client, tmp_path, algo, fwd, rev, flen, rlen, ["-o", "9", "-O", "120", "-t", "0.9"], dict(minoverlap=9, maxoverlap=120, threshold=0.9))
 
 
+def _repeats_and_strays(n, seed):
+    """config-1 pairs, a third of them tandem repeats (k-mers that occur dozens of times: what num_kmers decides), a third unrelated reads"""
+    from pandaseq_amd import synth
+    spec = synth.config_spec(1)
+    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
+    rng = np.random.default_rng(seed)
+    L = spec.read_len
+    for i in range(0, n, 3):
+        unit = rng.choice(np.array([1, 2, 4, 8], np.uint8), size=int(rng.integers(1, 14)))
+        rep = np.tile(unit, L // len(unit) + 2)
+        off = int(rng.integers(0, len(unit)))
+        fwd[i, :L, 0] = rep[:L]
+        rev[i, :L, 0] = rep[off:off + L]
+        if i % 9 == 0:
+            fwd[i, 40:52, 0] = 15
+    for i in range(1, n, 3):
+        rev[i, :L, 0] = rng.choice(np.array([1, 2, 4, 8], np.uint8), size=L)
+    return fwd, rev, flen, rlen
+
+
+@pytest.mark.parametrize("k", [0, 1, 3, 5, 10])
+def test_host_path_with_other_num_kmers(client, tmp_path, k):
+    """panda_assembler_new_kmer(k != 2) (assembler_support.c:36-100): the reference looks for a free slot at kmerseen[(kmer << 1) + j]
+    and writes to kmerseen[kmer * k + j] (assembler.c:94 vs :99); the host path reproduces that as written -- against the oracle's
+    flat table, on pairs whose k-mers repeat (where the number of kept positions decides which overlaps are examined)."""
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    fwd, rev, flen, rlen = _repeats_and_strays(450, seed=60 + k)
+    o = _check(client, tmp_path, "simple_bayesian", fwd, rev, flen, rlen, ["-k", str(k)], dict(num_kmers=k))
+    o2 = po.assemble_batch(po.make_config("simple_bayesian"), fwd, rev, flen, rlen)
+    # the setting is not a no-op: some pair examines another number of overlaps than with the default two positions per k-mer
+    assert (o[0]["examined"] != o2[0]["examined"]).any()
+    fwd, rev, flen, rlen = adversarial_pairs(synth.config_spec(1), 300, seed=70 + k)
+    _check(client, tmp_path, "pear", fwd, rev, flen, rlen, ["-k", str(k)], dict(num_kmers=k))
+
+
 def test_every_class_object_is_complete(built):
     """pandaseq-common.h:594-605 is public: each of the seven class objects carries both functions, and
     panda_algorithm_quality_compare (algo.c:27-32) answers through them -- checked against the oracle's tables."""

@@ -110,3 +110,19 @@ def test_array_form_on_few_pairs(client, tmp_path, n):
     pp.run_client(client, pairs, tmp_path / "many.bin", "simple_bayesian", "many", env=env)
     pp.run_client(client, pairs, tmp_path / "host.bin", "simple_bayesian", "pair", env=env)
     assert (tmp_path / "many.bin").read_bytes() == (tmp_path / "host.bin").read_bytes()
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_other_num_kmers_on_an_ordinary_assembler(client, tmp_path, k):
+    """panda_assembler_new_kmer(k != 2) on an assembler that has its GPU: the per-pair entry point and the array form both give the
+    oracle's output for that k (assembler.c:94 vs :99) -- pairs of such an assembler are assembled on the host path, the kernels'
+    seeding being the default's."""
+    from oracle import pyoracle as po
+    from test_per_pair_cpu import _repeats_and_strays
+    fwd, rev, flen, rlen = _repeats_and_strays(600, seed=80 + k)
+    pairs = tmp_path / "pairs.bin"
+    pp.write_pairs(pairs, fwd, rev, flen, rlen)
+    o = po.assemble_batch(po.make_config("simple_bayesian", num_kmers=k), fwd, rev, flen, rlen)
+    for path in ("pair", "many"):
+        got = pp.run_client(client, pairs, tmp_path / (path + ".bin"), "simple_bayesian", path, ["-k", str(k)])
+        pp.compare_with_oracle(*got, *o)
