@@ -39,7 +39,8 @@ enum {
 	PAMD_EINVAL = -1,	/* bad argument / value outside the device domain */
 	PAMD_ENODEVICE = -2,	/* no HIP device, or HIP runtime error */
 	PAMD_ENOMEM = -3,
-	PAMD_EUNSUPPORTED = -4	/* e.g. an algorithm class without a device form */
+	PAMD_EUNSUPPORTED = -4,	/* e.g. an algorithm class without a device form */
+	PAMD_EIO = -5		/* a file could not be read or written (pamd_pipe_run: pread / pwrite / inflate failed) */
 };
 
 /* One base.  Byte-identical to panda_qual (pandaseq-common.h:210-219): nt is the one-hot

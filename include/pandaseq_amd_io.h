@@ -161,6 +161,29 @@ typedef struct {
 } pamd_pipe_stats;
 int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_options *options, pamd_pipe_stats *stats);
 
+/* The same run over N devices: what panda_run_pool (pool.c:110-181) is to the reference -- a worker per thread there, each with
+ * an assembler of its own configured alike (pool.c:142-150), all fed by one mux and writing through one writer -- with a device
+ * for a worker and a chunk of `pairs_per_chunk` records for a pair.  The two files are cut at record boundaries (a record is four
+ * lines of either file, fastq.c:46-197) found by counting line ends on the host; chunk k goes to devices[k mod n_devices], whose
+ * own reader and copier threads bring exactly its bytes up over THAT device's link; every device runs parse -> assemble ->
+ * format on its chunks; the text of chunk k is written behind the text of chunks 0 .. k-1, so the output file is byte for byte
+ * pamd_pipe_run()'s, and stats->counters is the sum of the chunks' counter blocks (the STAT all-reduce, done on the host because
+ * the devices share a process).  A chunk in which the reader gives up ends the run as it ends pamd_pipe_run(): later chunks,
+ * already dealt, are dropped.  stats->chunks counts the chunks dealt.
+ *   assemblers   n_devices configured assemblers, assemblers[i] created on devices[i] (a device may be named twice: two
+ *                workers on one GPU, each with its own assembler)
+ * Inputs that are read in order by one thread (gzip / bzip2 text, FIFOs) gain nothing from more devices: such a run is handed to
+ * pamd_pipe_run(assemblers[0], devices[0], ...). */
+int pamd_pipe_run_multi(pamd_assembler *const *assemblers, const int *devices, int n_devices, const pamd_pipe_options *options, pamd_pipe_stats *stats);
+
+/* The STAT block a reference worker prints when its input ends (pool.c:86-104; OVERLAPS as proxy.c:175-190 prints it), from a
+ * counter block -- one assembler's, one run's (pamd_pipe_stats::counters) or a sum over devices:
+ *     STAT\tREADS\t<count>  [NOFP] [NORP]  NOALGN  LOWQ  BADR  SLOW  <module>\t<rejected> (module.c:208-216: only if > 0)  OK  OVERLAPS\t<n0> <n1> ...
+ * NOFP / NORP only when that primer is set; every line prefixed "<name>\t" when name is not NULL (proxy.c:165-172); TIME and
+ * ELAPSED (pool.c:60-65) are the caller's clock and not printed.  Returns the length written (the text is NUL-terminated) or
+ * PAMD_EINVAL when `cap` is too small. */
+int pamd_stat_block(const int64_t *counters, int has_forward_primer, int has_reverse_primer, const char *const *module_names, int n_modules, const char *name, char *buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

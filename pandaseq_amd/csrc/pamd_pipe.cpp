@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -49,11 +50,20 @@ struct Shared {	// what every thread of one run looks at
 	std::atomic<bool> failed{false};
 	std::mutex msg_lock;
 	std::string msg;
+	int code = PAMD_OK;	// what the run returns: PAMD_EIO for a file that could not be read or written, PAMD_ENODEVICE for the HIP runtime
 	int device = 0;
-	void fail(const char *what, const char *why) {
-		std::lock_guard<std::mutex> g(msg_lock);
-		if (!failed.exchange(true))
-			msg = std::string(what) + ": " + why;
+	std::function<void()> wake;	// notifies every condition variable of the run, each under its mutex: a waiter that has just looked at
+					// `failed` and not yet gone to sleep holds that mutex, so it cannot miss the notification
+	void fail(int rc, const char *what, const char *why) {
+		{
+			std::lock_guard<std::mutex> g(msg_lock);
+			if (!failed.exchange(true)) {
+				msg = std::string(what) + ": " + why;
+				code = rc;
+			}
+		}
+		if (wake)
+			wake();
 	}
 };
 
@@ -94,7 +104,7 @@ struct Input {
 			const int r = pamd_bz2()->bzRead(&e, bz, dst, (int) ask);
 			bz_ended = e == PAMD_BZ_STREAM_END;
 			if (e != PAMD_BZ_OK && e != PAMD_BZ_STREAM_END) {
-				sh->fail("BZ2_bzRead", ("libbz2 error " + std::to_string(e)).c_str());
+				sh->fail(PAMD_EIO, "BZ2_bzRead", ("libbz2 error " + std::to_string(e)).c_str());
 				return -1;
 			}
 			return r;
@@ -103,7 +113,7 @@ struct Input {
 		if (r < 0) {
 			int e = 0;
 			const char *why = gzerror(gz, &e);
-			sh->fail("gzread", e == Z_ERRNO ? strerror(errno) : why);
+			sh->fail(PAMD_EIO, "gzread", e == Z_ERRNO ? strerror(errno) : why);
 		}
 		return r;
 	}
@@ -173,7 +183,7 @@ struct Input {
 			while (got < len) {
 				const ssize_t r = pread(fd, dst + got, len - got, (off_t) (b * block + got));
 				if (r <= 0) {
-					sh->fail("pread", r == 0 ? "the file shrank" : strerror(errno));
+					sh->fail(PAMD_EIO, "pread", r == 0 ? "the file shrank" : strerror(errno));
 					cv.notify_all();
 					return;
 				}
@@ -188,7 +198,7 @@ struct Input {
 	}
 	void copier_main() {
 		if (hipSetDevice(sh->device) != hipSuccess) {
-			sh->fail("hipSetDevice", "copier thread");
+			sh->fail(PAMD_ENODEVICE, "hipSetDevice", "copier thread");
 			cv.notify_all();
 			return;
 		}
@@ -203,13 +213,13 @@ struct Input {
 				issue = b < limit;
 			}
 			if (issue && (hipMemcpyAsync(ring + (b % (uint64_t) nr) * block, pin[b % NB], block_len(b), hipMemcpyHostToDevice, s_in) != hipSuccess || hipEventRecord(ev[b & 1], s_in) != hipSuccess)) {
-				sh->fail("hipMemcpyAsync", "host to device");
+				sh->fail(PAMD_ENODEVICE, "hipMemcpyAsync", "host to device");
 				cv.notify_all();
 				return;
 			}
 			if (b > 0) {
 				if (hipEventSynchronize(ev[(b - 1) & 1]) != hipSuccess) {
-					sh->fail("hipEventSynchronize", "host to device");
+					sh->fail(PAMD_ENODEVICE, "hipEventSynchronize", "host to device");
 					cv.notify_all();
 					return;
 				}
@@ -290,7 +300,7 @@ struct Output {
 	}
 	void writer_main() {
 		if (hipSetDevice(sh->device) != hipSuccess) {
-			sh->fail("hipSetDevice", "writer thread");
+			sh->fail(PAMD_ENODEVICE, "hipSetDevice", "writer thread");
 			return;
 		}
 		for (;;) {
@@ -304,7 +314,7 @@ struct Output {
 				jobs.pop_front();
 			}
 			if (hipEventSynchronize(ev[j.slot]) != hipSuccess)
-				sh->fail("hipEventSynchronize", "device to host");
+				sh->fail(PAMD_ENODEVICE, "hipEventSynchronize", "device to host");
 			// (pwrite, and by default from ONE thread: write() holds the inode's lock for the whole copy, so threads writing one file
 			// take turns, and on a memory-backed file system -- where making the file's pages is the cost -- one thread's 6.5 GB/s is
 			// what the file takes however it is written: shared mappings filled by 1-12 threads, with or without MADV_POPULATE_WRITE,
@@ -315,7 +325,7 @@ struct Output {
 				// pieces in the order they were queued: plain write())
 				const ssize_t w = seekable ? pwrite(fd, pin[j.slot] + put, j.len - put, (off_t) (j.off + put)) : write(fd, pin[j.slot] + put, j.len - put);
 				if (w <= 0) {
-					sh->fail(seekable ? "pwrite" : "write", strerror(errno));
+					sh->fail(PAMD_EIO, seekable ? "pwrite" : "write", strerror(errno));
 					break;
 				}
 				put += (uint64_t) w;
@@ -403,6 +413,14 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 	Input in[2];
 	Output out;
 	out.sh = &sh;
+	sh.wake = [&in, &out]() {
+		for (Input &s : in) {
+			std::lock_guard<std::mutex> g(s.m);
+			s.cv.notify_all();
+		}
+		std::lock_guard<std::mutex> g(out.m);
+		out.cv.notify_all();
+	};
 	DeviceBuffers mem;
 	const char *paths[2] = { o->forward_path, o->reverse_path };
 	auto close_all = [&]() {
@@ -545,7 +563,7 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 	uint64_t pos[2] = { 0, 0 };		// file bytes gathered out of each ring so far
 	uint64_t tail_off[2] = { 0, 0 }, tail_len[2] = { 0, 0 };	// the previous chunk's unconsumed text, in d_text[s][(k - 1) & 1]
 	double bytes_per_record[2] = { 600.0, 600.0 };
-	uint64_t out_off = 0, records = 0, dropped = 0, chunk = 0;
+	uint64_t out_off = 0, records = 0, dropped = 0, chunk = 0, parsed = 0;
 	int stop = PAMD_FQ_END, rc = PAMD_OK;
 	uint64_t stop_record = 0;
 	bool grow = false;
@@ -565,9 +583,9 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 				break;
 			// this chunk's text: the tail of the previous one, then `take` new bytes of the file
 			if (tail_len[s] > 0 && hipMemcpyAsync(d_text[s][cur], d_text[s][prev] + tail_off[s], tail_len[s], hipMemcpyDeviceToDevice, s_cmp) != hipSuccess)
-				sh.fail("hipMemcpyAsync", "tail");
+				sh.fail(PAMD_ENODEVICE, "hipMemcpyAsync", "tail");
 			if (!gather(in[s], pos[s], take, d_text[s][cur] + tail_len[s], s_cmp))
-				sh.fail("hipMemcpyAsync", "gather");
+				sh.fail(PAMD_ENODEVICE, "hipMemcpyAsync", "gather");
 			pos[s] += take;
 			have[s] = tail_len[s] + take;
 			more_input |= pos[s] < in[s].size_now();
@@ -581,6 +599,7 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 		rc = pamd_fastq_parse_device(fq, d_text[0][cur], have[0], d_text[1][cur], have[1], chunk_pairs, d_fwd, stride, d_rev, stride, d_flen, d_rlen, d_ids, &st, s_cmp);
 		if (rc != PAMD_OK)
 			break;
+		parsed++;
 		// (the parse synchronised its stream: the gathers are done, their ring bytes may be overwritten)
 		for (int s = 0; s < 2; s++)
 			in[s].publish_consumed(pos[s]);
@@ -603,14 +622,14 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 			b.seq_cursor = reinterpret_cast<uint64_t *>(d_cursor);
 			b.counters = reinterpret_cast<int64_t *>(d_ctr);
 			if (hipMemsetAsync(d_cursor, 0, 8, s_cmp) != hipSuccess) {
-				sh.fail("hipMemsetAsync", "cursor");
+				sh.fail(PAMD_ENODEVICE, "hipMemsetAsync", "cursor");
 				break;
 			}
 			if ((rc = pamd_assemble_device(a, &b, s_cmp)) != PAMD_OK)
 				break;
 			// this text buffer's previous contents (two chunks ago) have left for the host
 			if (hipStreamWaitEvent(s_cmp, ev_out_done[cur], 0) != hipSuccess) {
-				sh.fail("hipStreamWaitEvent", "output buffer");
+				sh.fail(PAMD_ENODEVICE, "hipStreamWaitEvent", "output buffer");
 				break;
 			}
 			size_t text_bytes = 0, n_fix = 0;
@@ -621,12 +640,12 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 				pamd_pair_result one;
 				char tmp[32];
 				if (hipMemcpy(&one, d_res + fix[2 * k + 1], sizeof one, hipMemcpyDeviceToHost) != hipSuccess) {
-					sh.fail("hipMemcpy", "fixup");
+					sh.fail(PAMD_ENODEVICE, "hipMemcpy", "fixup");
 					break;
 				}
 				snprintf(tmp, sizeof tmp, "%f", exp(one.quality));
 				if (hipMemcpy(d_out[cur] + fix[2 * k], tmp, 8, hipMemcpyHostToDevice) != hipSuccess)
-					sh.fail("hipMemcpy", "fixup");
+					sh.fail(PAMD_ENODEVICE, "hipMemcpy", "fixup");
 			}
 			c3 = now_s();
 			// (the format synchronised its stream: the text is there) -- back in pieces, each written as soon as it has landed
@@ -636,13 +655,13 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 				if (slot < 0)
 					break;
 				if (hipMemcpyAsync(out.pin[slot], d_out[cur] + at, len, hipMemcpyDeviceToHost, s_out) != hipSuccess || hipEventRecord(out.ev[slot], s_out) != hipSuccess) {
-					sh.fail("hipMemcpyAsync", "device to host");
+					sh.fail(PAMD_ENODEVICE, "hipMemcpyAsync", "device to host");
 					break;
 				}
 				out.submit(slot, out_off + at, len);
 			}
 			if (hipEventRecord(ev_out_done[cur], s_out) != hipSuccess)
-				sh.fail("hipEventRecord", "output buffer");
+				sh.fail(PAMD_ENODEVICE, "hipEventRecord", "output buffer");
 			out_off += text_bytes;
 		}
 		if (trace)
@@ -656,9 +675,17 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 		}
 		if (st.n_records == 0) {
 			// not one whole record pair in this text: more of the files if there is more (a chunk's first guess may be short of a
-			// long record), else only a partial record is left (PANDA_CODE_PREMATURE_EOF in the reference when any bytes remain)
-			if (!more_input || grow)
+			// long record); else both files end inside a record -- the headers are read and read_seq() runs out of lines:
+			// PANDA_CODE_PREMATURE_EOF (fastq.c:58-60,69-71,84-86)
+			if (!more_input) {
+				stop = PAMD_FQ_EOF;
+				stop_record = records;
 				break;
+			}
+			if (grow) {
+				sh.fail(PAMD_EINVAL, "input", "a record of more text than a chunk holds");
+				break;
+			}
 			grow = true;
 		} else {
 			grow = false;
@@ -692,13 +719,13 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 	long long ctr[PAMD_NUM_COUNTERS];
 	memset(ctr, 0, sizeof ctr);
 	if (hipMemcpy(ctr, d_ctr, sizeof ctr, hipMemcpyDeviceToHost) != hipSuccess)
-		sh.fail("hipMemcpy", "counters");
+		sh.fail(PAMD_ENODEVICE, "hipMemcpy", "counters");
 	const double t_end = now_s();
 	for (unsigned k = 0; k < PAMD_NUM_COUNTERS; k++)
 		stats->counters[k] = ctr[k];
 	stats->pairs = records;
 	stats->dropped = dropped;
-	stats->chunks = chunk + 1;
+	stats->chunks = parsed;
 	stats->in_bytes = pos[0] + pos[1];
 	stats->out_bytes = out_off;
 	stats->stop_code = stop;
@@ -708,7 +735,7 @@ extern "C" int pamd_pipe_run(pamd_assembler *a, int device, const pamd_pipe_opti
 	destroy_all();
 	if (sh.failed.load()) {
 		pamd_set_error("pamd_pipe_run: %s", sh.msg.c_str());
-		return PAMD_ENODEVICE;
+		return sh.code != PAMD_OK ? sh.code : PAMD_ENODEVICE;
 	}
 	return rc;
 }

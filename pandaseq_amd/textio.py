@@ -32,7 +32,7 @@ assert SEQID_DTYPE.itemsize == 48
 # every symbol include/pandaseq_amd_io.h declares
 SYMBOLS = [
     "pamd_fastq_parser_create", "pamd_fastq_parser_destroy", "pamd_fastq_parse_device", "pamd_fastq_last_kernel_ms",
-    "pamd_formatter_create", "pamd_formatter_destroy", "pamd_format_device", "pamd_format_last_kernel_ms", "pamd_pipe_run",
+    "pamd_formatter_create", "pamd_formatter_destroy", "pamd_format_device", "pamd_format_last_kernel_ms", "pamd_pipe_run", "pamd_pipe_run_multi", "pamd_stat_block",
 ]
 
 

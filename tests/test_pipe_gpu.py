@@ -316,3 +316,118 @@ def test_reader_stops_early_in_streamed_inputs(pipe, tmp_path):
     want, ctr, st = _oracle_text(bad, rt, "simple_bayesian", "fasta")
     assert st.n_records == 3100 and (int(stop[0]), int(stop[1])) == (st.stop_code, 3100)
     assert o.read_bytes() == want
+
+
+# ---- pamd_pipe_run_multi(): the same run dealt to N devices (pool.c:110-181's shape, a device per worker) ------------------
+def _run_full(pipe, tmp_path, ft, rt, algo, fmt, chunk, devices=None, extra=(), out_name="out.txt"):
+    """The client's output file and everything it prints but the timings and the number of chunks."""
+    f, r, o = tmp_path / "f.fastq", tmp_path / "r.fastq", tmp_path / out_name
+    f.write_bytes(ft)
+    r.write_bytes(rt)
+    env = dict(os.environ)
+    env.pop("PAMD_PIPE_DEVICES", None)
+    if devices is not None:
+        env["PAMD_PIPE_DEVICES"] = devices
+    out = subprocess.check_output([pipe, str(f), str(r), str(o), str(po.ALGO[algo]), fmt, str(chunk), *extra], timeout=300, env=env).decode()
+    lines = [line for line in out.splitlines() if not line.startswith("PIPE")]
+    pipe_line = [line for line in out.splitlines() if line.startswith("PIPE")][0].split("\t")
+    return o.read_bytes(), lines, dict(zip(pipe_line[1::2], pipe_line[2::2]))
+
+
+@pytest.mark.parametrize("devices", ["0", "0,0", "0,0,0"])
+@pytest.mark.parametrize("algo,fmt", [("simple_bayesian", "fasta"), ("pear", "fastq")])
+def test_multi_device_run_equals_the_single_device_run(pipe, tmp_path, devices, algo, fmt):
+    """Output bytes, STAT lines, the reference-format STAT block and all 916 counters of pamd_pipe_run_multi() over devices
+    {0}, {0, 0}, {0, 0, 0} (workers that share the one GPU of this pool, each with its own assembler, streams and buffers)
+    equal pamd_pipe_run()'s -- and the oracle chain's.  Chunks of 700 of 5 000 pairs: eight chunks dealt round robin."""
+    ft, rt = util.random_fastq(5000, 61)
+    want_bytes, want_lines, _ = _run_full(pipe, tmp_path, ft, rt, algo, fmt, 700)
+    got_bytes, got_lines, info = _run_full(pipe, tmp_path, ft, rt, algo, fmt, 700, devices=devices, out_name="multi.txt")
+    assert got_bytes == want_bytes and got_lines == want_lines
+    assert int(info["chunks"]) == 8 and int(info["pairs"]) == 5000
+    oracle_bytes, ctr, st = _oracle_text(ft, rt, algo, fmt)
+    assert got_bytes == oracle_bytes
+    block = [line for line in got_lines if line.startswith("pamd\tSTAT")]
+    assert block[0] == "pamd\tSTAT\tREADS\t%d" % int(ctr["count"]) and block[-1].startswith("pamd\tSTAT\tOVERLAPS\t")
+    assert [int(x) for x in block[-1].split("\t")[3].split(" ")] == [int(x) for x in ctr["overlapcount"][:int(ctr["longest_overlap"]) + 1]]
+
+
+def test_multi_device_run_with_primers_and_unequal_records(pipe, tmp_path):
+    """config 2 (primers before and after assembly), then records of very different sizes in the two files (the chunk boundaries
+    are found per file by counting lines) and a forward file with more records than the reverse one."""
+    spec = synth.config_spec(2)
+    f, r, fl, rl = synth.generate_numpy(spec, 0, 3000)
+    ft, rt = synth.render_fastq(f, r, fl, rl)
+    for after in (0, 1):
+        extra = (str(after), spec.fprimer, spec.rprimer)
+        want = _run_full(pipe, tmp_path, ft, rt, "pear", "fasta", 1000, extra=extra)
+        got = _run_full(pipe, tmp_path, ft, rt, "pear", "fasta", 1000, devices="0,0", extra=extra, out_name="multi.txt")
+        assert got[0] == want[0] and got[1] == want[1] and len(got[0]) > 100_000
+    rng = np.random.default_rng(12)
+    n = 6000
+    fo, ro = [], []
+    for i in range(n):
+        h = f"@M1:7:FC:1:{1101 + i % 40}:{i}:{7 * i % 9973}"
+        lf, lr = int(rng.integers(280, 301)), int(rng.integers(40, 80))
+        for hh, ln, dst in ((h + " 1:N:0:ACGT", lf, fo), (h + " 2:N:0:ACGT", lr, ro)):
+            seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=ln).tobytes()
+            dst.append(hh.encode() + b"\n" + seq + b"\n+\n" + bytes([int(q) for q in rng.integers(35, 74, size=ln)]) + b"\n")
+    ft, rt = b"".join(fo), b"".join(ro)
+    for rev in (rt, b"".join(ro[:n - 500]), b"".join(ro[:n - 500])[:-30], b""):
+        want = _run_full(pipe, tmp_path, ft, rev, "simple_bayesian", "fasta", 900)
+        got = _run_full(pipe, tmp_path, ft, rev, "simple_bayesian", "fasta", 900, devices="0,0,0", out_name="multi.txt")
+        assert got[0] == want[0] and got[1] == want[1], len(rev)
+    # both files end inside a record: the reader runs out of lines in read_seq(): PANDA_CODE_PREMATURE_EOF (8), either way
+    for devices in (None, "0,0"):
+        got = _run_full(pipe, tmp_path, ft[:-40], rt[:-25], "simple_bayesian", "fasta", 900, devices=devices)
+        assert "STOP\t8\t%d" % (n - 1) in got[1], got[1][:9]
+
+
+def test_multi_device_run_stops_where_the_reader_stops(pipe, tmp_path):
+    """A record the reader gives up at, in the third of eight chunks: the chunks dealt beyond it (some of them assembled before the
+    bad one was parsed) leave nothing behind -- neither text nor counts."""
+    ft, rt = util.random_fastq(4000, 67)
+    lines = ft.split(b"\n")
+    k = 4 * 1300 + 1
+    lines[k] = (b"1" + lines[k][1:]) if lines[k] else b"1"
+    bad = b"\n".join(lines)
+    want = _run_full(pipe, tmp_path, bad, rt, "simple_bayesian", "fasta", 500)
+    for devices in ("0,0", "0,0,0"):
+        got = _run_full(pipe, tmp_path, bad, rt, "simple_bayesian", "fasta", 500, devices=devices, out_name="multi.txt")
+        assert got[0] == want[0] and got[1] == want[1], devices
+    assert [line for line in want[1] if line.startswith("STOP")][0].split("\t")[2] == "1300"
+    oracle_bytes, ctr, st = _oracle_text(bad, rt, "simple_bayesian", "fasta")
+    assert want[0] == oracle_bytes and st.n_records == 1300
+
+
+def test_multi_device_run_into_a_pipe_and_from_gzip(pipe, tmp_path):
+    """An output that cannot seek takes the pieces of all devices in offset order from one writer; inputs that are read in order
+    (gzip) go to the first device's pamd_pipe_run()."""
+    import gzip
+    ft, rt = util.random_fastq(3000, 71)
+    want = _run_full(pipe, tmp_path, ft, rt, "simple_bayesian", "fastq", 400)
+    f, r = tmp_path / "f.fastq", tmp_path / "r.fastq"
+    env = dict(os.environ, PAMD_PIPE_DEVICES="0,0")
+    fifo = tmp_path / "out.fifo"
+    os.mkfifo(fifo)
+    reader = subprocess.Popen(["cat", str(fifo)], stdout=subprocess.PIPE)
+    subprocess.check_call([pipe, str(f), str(r), str(fifo), "0", "fastq", "400"], timeout=300, env=env, stdout=subprocess.DEVNULL)
+    text, _ = reader.communicate(timeout=60)
+    assert text == want[0]
+    (tmp_path / "f.gz").write_bytes(gzip.compress(ft, 1))
+    (tmp_path / "r.gz").write_bytes(gzip.compress(rt, 1))
+    subprocess.check_call([pipe, str(tmp_path / "f.gz"), str(tmp_path / "r.gz"), str(tmp_path / "gz.txt"), "0", "fastq", "400"], timeout=300, env=env, stdout=subprocess.DEVNULL)
+    assert (tmp_path / "gz.txt").read_bytes() == want[0]
+
+
+def test_multi_device_run_fails_cleanly(pipe, tmp_path):
+    ft, rt = util.random_fastq(200, 3)
+    f, r = tmp_path / "f.fastq", tmp_path / "r.fastq"
+    f.write_bytes(ft)
+    r.write_bytes(rt)
+    env = dict(os.environ, PAMD_PIPE_DEVICES="0,0")
+    for args in ((str(tmp_path / "missing.fastq"), str(r), str(tmp_path / "o.txt")), (str(f), str(r), str(tmp_path / "no_such_dir" / "o.txt"))):
+        out = subprocess.run([pipe, *args, "0", "fasta", "1000"], capture_output=True, text=True, timeout=120, env=env)
+        assert out.returncode == 3 and "cannot" in out.stderr, (args, out.returncode, out.stderr[-300:])
+    out = subprocess.run([pipe, str(f), str(r), str(tmp_path / "o.txt"), "0", "fasta", "1000"], capture_output=True, text=True, timeout=120, env=dict(os.environ, PAMD_PIPE_DEVICES="0,99"))
+    assert out.returncode == 3, out.stderr[-300:]    # no device 99

@@ -147,6 +147,77 @@ DEFK64(ds_read_b64, F_DSR64("%0", "0"), F_DSR64("%1", "1024"), F_DSR64("%2", "20
 #define F_DSG64(r) "ds_read_b64 " r ", %10"
 DEFK64(ds_read_b64_gather, F_DSG64("%0"), F_DSG64("%1"), F_DSG64("%2"), F_DSG64("%3"), F_DSG64("%4"), F_DSG64("%5"), F_DSG64("%6"), F_DSG64("%7") "\n s_waitcnt lgkmcnt(0)")
 
+// more one- and two-operand classes: which of them issue at the doubled rate v_add_u32 does?
+#define F_MOV(r) "v_mov_b32 " r ", %8"
+DEFK32(v_mov_b32, SAME8(F_MOV))
+#define F_AND(r) "v_and_b32 " r ", " r ", %8"
+DEFK32(v_and_b32, SAME8(F_AND))
+#define F_OR(r) "v_or_b32 " r ", " r ", %8"
+DEFK32(v_or_b32, SAME8(F_OR))
+#define F_XOR(r) "v_xor_b32 " r ", " r ", %8"
+DEFK32(v_xor_b32, SAME8(F_XOR))
+#define F_LSHL(r) "v_lshlrev_b32 " r ", 3, " r
+DEFK32(v_lshlrev_b32, SAME8(F_LSHL))
+#define F_LSHR(r) "v_lshrrev_b32 " r ", 3, " r
+DEFK32(v_lshrrev_b32, SAME8(F_LSHR))
+#define F_LSHRV(r) "v_lshrrev_b32 " r ", %8, " r
+DEFK32(v_lshrrev_b32_by_vgpr, SAME8(F_LSHRV))
+#define F_SUB(r) "v_sub_u32 " r ", " r ", %8"
+DEFK32(v_sub_u32, SAME8(F_SUB))
+#define F_SUBREV(r) "v_subrev_u32 " r ", " r ", %8"
+DEFK32(v_subrev_u32, SAME8(F_SUBREV))
+#define F_MAX(r) "v_max_u32 " r ", " r ", %8"
+DEFK32(v_max_u32, SAME8(F_MAX))
+#define F_ADDLIT(r) "v_add_u32 " r ", 0x12345, " r
+DEFK32(v_add_u32_literal, SAME8(F_ADDLIT))
+#define F_ANDLIT(r) "v_and_b32 " r ", 0x7F7F7F7F, " r
+DEFK32(v_and_b32_literal, SAME8(F_ANDLIT))
+#define F_ADDINL(r) "v_add_u32 " r ", 5, " r
+DEFK32(v_add_u32_inline, SAME8(F_ADDINL))
+#define F_ADDS(r) "v_add_u32 " r ", s40, " r
+DEFK32(v_add_u32_sgpr, SAME8(F_ADDS))
+#define F_ADDE64(r) "v_add_u32_e64 " r ", " r ", %8"
+DEFK32(v_add_u32_e64, SAME8(F_ADDE64))
+#define F_ADDCO(r) "v_add_co_u32 " r ", vcc, " r ", %8"
+DEFK32(v_add_co_u32, SAME8(F_ADDCO))
+#define F_MUL24(r) "v_mul_u32_u24 " r ", " r ", %8"
+DEFK32(v_mul_u32_u24, SAME8(F_MUL24))
+#define F_CNDV(r) "v_cndmask_b32 " r ", " r ", %8, vcc"
+DEFK32(v_cndmask_vcc, SAME8(F_CNDV))
+#define F_BFI(r) "v_bfi_b32 " r ", " r ", %8, %8"
+DEFK32(v_bfi_b32, SAME8(F_BFI))
+#define F_ADD3(r) "v_add3_u32 " r ", " r ", %8, %8"
+DEFK32(v_add3_u32, SAME8(F_ADD3))
+#define F_OR3(r) "v_or3_b32 " r ", " r ", %8, %8"
+DEFK32(v_or3_b32, SAME8(F_OR3))
+#define F_BFREV(r) "v_bfrev_b32 " r ", " r
+DEFK32(v_bfrev_b32, SAME8(F_BFREV))
+#define F_BCNT(r) "v_bcnt_u32_b32 " r ", " r ", %8"
+DEFK32(v_bcnt_u32_b32, SAME8(F_BCNT))
+#define F_FFBH(r) "v_ffbh_u32 " r ", " r
+DEFK32(v_ffbh_u32, SAME8(F_FFBH))
+#define F_ADDF32(r) "v_add_f32 " r ", " r ", %8"
+DEFK32(v_add_f32, SAME8(F_ADDF32))
+#define F_MULF32(r) "v_mul_f32 " r ", " r ", %8"
+DEFK32(v_mul_f32, SAME8(F_MULF32))
+#define F_FMAF32(r) "v_fma_f32 " r ", " r ", %8, %8"
+DEFK32(v_fma_f32, SAME8(F_FMAF32))
+#define F_FMACF32(r) "v_fmac_f32 " r ", %8, %8"
+DEFK32(v_fmac_f32, SAME8(F_FMACF32))
+#define F_CVT(r) "v_cvt_f32_u32 " r ", " r
+DEFK32(v_cvt_f32_u32, SAME8(F_CVT))
+#define F_RCP(r) "v_rcp_f32 " r ", " r
+DEFK32(v_rcp_f32, SAME8(F_RCP))
+#define F_CMPVCC(r) "v_cmp_lt_u32 vcc, " r ", %8"
+DEFK32(v_cmp_vcc_only, SAME8(F_CMPVCC))
+#define F_WRLANE(r) "v_writelane_b32 " r ", s40, 5"
+DEFK32(v_writelane, SAME8(F_WRLANE))
+#define F_MBCNT(r) "v_mbcnt_lo_u32_b32 " r ", %8, " r
+DEFK32(v_mbcnt_lo, SAME8(F_MBCNT))
+// one fast and one slow class interleaved 1 : 1 -- do they share one issue budget?
+DEFK32(v_add_u32_plus_v_perm_1to1, F_ADD("%0"), F_PERM("%1"), F_ADD("%2"), F_PERM("%3"), F_ADD("%4"), F_PERM("%5"), F_ADD("%6"), F_PERM("%7"))
+DEFK32(v_add_u32_plus_v_add_f64_like_min, F_ADD("%0"), F_MIN("%1"), F_ADD("%2"), F_MIN("%3"), F_ADD("%4"), F_MIN("%5"), F_ADD("%6"), F_MIN("%7"))
+
 typedef void (*kern_t)(Rec *, unsigned *, int);
 struct Class {
 	const char *name;
@@ -160,6 +231,10 @@ static const Class classes[] = {
 	C(v_add_sdwa, 64), C(v_cmp_to_sgpr, 64), C(v_cmp_vcc_cndmask, 64), C(v_cndmask_sgpr, 64), C(v_readlane, 64), C(v_readfirstlane, 64), C(ds_bpermute, 64),
 	C(s_add_u32, 64), C(v_add_plus_s_add_1to1, 64), C(v_add_x3_plus_s_add, 64), C(v_add_x4_plus_branch, 64),
 	C(v_add_f64, 64), C(v_mul_f64, 64), C(v_fma_f64, 64), C(v_cmp_f64_to_sgpr, 64), C(v_lshlrev_b64, 64), C(v_pk_add_f32, 64),
+	C(v_mov_b32, 64), C(v_and_b32, 64), C(v_or_b32, 64), C(v_xor_b32, 64), C(v_lshlrev_b32, 64), C(v_lshrrev_b32, 64), C(v_lshrrev_b32_by_vgpr, 64), C(v_sub_u32, 64), C(v_subrev_u32, 64), C(v_max_u32, 64),
+	C(v_add_u32_literal, 64), C(v_and_b32_literal, 64), C(v_add_u32_inline, 64), C(v_add_u32_sgpr, 64), C(v_add_u32_e64, 64), C(v_add_co_u32, 64), C(v_mul_u32_u24, 64), C(v_cndmask_vcc, 64), C(v_bfi_b32, 64), C(v_add3_u32, 64),
+	C(v_or3_b32, 64), C(v_bfrev_b32, 64), C(v_bcnt_u32_b32, 64), C(v_ffbh_u32, 64), C(v_add_f32, 64), C(v_mul_f32, 64), C(v_fma_f32, 64), C(v_fmac_f32, 64), C(v_cvt_f32_u32, 64), C(v_rcp_f32, 64), C(v_cmp_vcc_only, 64),
+	C(v_writelane, 64), C(v_mbcnt_lo, 64), C(v_add_u32_plus_v_perm_1to1, 64), C(v_add_u32_plus_v_add_f64_like_min, 64),
 	C(ds_read_b32, 64), C(ds_read_u16, 64), C(ds_read_b64, 64), C(ds_read_b64_gather, 64), C(ds_write_b32, 64), C(ds_min_rtn_u32, 64), C(v_add_x6_plus_ds_read_x2, 64),
 };
 
@@ -222,12 +297,15 @@ int main(int argc, char **argv) {
 				lo = std::min(lo, r.t0);
 				hi = std::max(hi, r.t1);
 			}
-			std::vector<double> rates;
+			std::vector<double> rates, spans;
 			for (auto &kv : simds)
-				if (kv.second.n == w)
+				if (kv.second.n == w) {
 					rates.push_back((double) w * iters * c.instr_per_trip / (double) (kv.second.last - kv.second.first));
+					spans.push_back((double) (kv.second.last - kv.second.first));
+				}
 			const double r = median(rates);
-			printf("%-28s %5d %12.4f %12.3f %10.1f %7zu\n", c.name, w, r, r > 0 ? 1.0 / r : 0.0, (double) (hi - lo) / (ms * 1e3), rates.size());
+			// (the XCDs' counters are not in step with each other: the clock is taken from one SIMD's span -- all SIMDs run the whole launch -- against the launch's event time)
+			printf("%-28s %5d %12.4f %12.3f %10.1f %7zu\n", c.name, w, r, r > 0 ? 1.0 / r : 0.0, median(spans) / ((double) ms * 1e3), rates.size());
 			fflush(stdout);
 		}
 	}
