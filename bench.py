@@ -419,7 +419,7 @@ def main():
                 others[f"config{oc}"] = {"error": str(exc)[:300]}
             torch.cuda.empty_cache()
         others["note"] = ("each: the configuration's single-GPU shard resident in HBM, 1 warmup + 3 timed steps by the same code as the headline line "
-                          "(run_config), any-order sums; frac = algorithmic bytes / HIP-event kernel time / 8 TB/s")
+                          "(run_config), " + ("sums in the reference's order" if args.sums == "exact" else "any-order sums") + "; frac = algorithmic bytes / HIP-event kernel time / 8 TB/s")
         out["other_configs"] = others
     # ---- end to end through the drop-in API (never `value`): the reference's loop, PCIe both ways, plain C ----
     if rank == 0 and world == 1 and not args.no_e2e and cfg_index in (1, 3, 4):

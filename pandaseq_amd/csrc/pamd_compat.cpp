@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <future>
+#include <list>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -2120,20 +2121,34 @@ struct panda_writer {
 	PandaDestroy write_destroy = nullptr;
 	PandaWriter commit_slave = nullptr;
 	std::mutex lock;
-	unsigned long serial = 0;	// (a thread's pending text is kept under this, not under the address: a new writer at an old one's address starts empty)
+	unsigned long serial = 0;	// (a thread finds its pending text under this, not under the address: a new writer at an old one's address starts empty)
+	// what each thread has appended and not committed (writer.c:40-52's buffer_list: the writer owns the buffers, a thread finds
+	// its own through a thread-local key); the last unref writes what is left in them (writer.c:186-193)
+	std::list<std::pair<std::thread::id, std::string>> buffers;
 };
 extern "C++" {
 namespace {
 std::atomic<unsigned long> g_writer_serial{1};
 std::string &pending_of(PandaWriter w) {
-	static thread_local std::vector<std::pair<unsigned long, std::string>> mine;
+	static thread_local std::vector<std::pair<unsigned long, std::string *>> mine;	// this thread's buffers, by writer (a cache: the text is the writer's)
 	for (auto &e : mine)
 		if (e.first == w->serial)
-			return e.second;
-	if (mine.size() >= 64)	// (writers come and go: the oldest entry makes room)
+			return *e.second;
+	std::string *text = nullptr;
+	{
+		std::lock_guard<std::mutex> g(w->lock);
+		for (auto &b : w->buffers)
+			if (b.first == std::this_thread::get_id())
+				text = &b.second;
+		if (text == nullptr) {
+			w->buffers.emplace_back(std::this_thread::get_id(), std::string());
+			text = &w->buffers.back().second;
+		}
+	}
+	if (mine.size() >= 64)	// (writers come and go: the oldest cache entry makes room; its text stays with its writer)
 		mine.erase(mine.begin());
-	mine.emplace_back(w->serial, std::string());
-	return mine.back().second;
+	mine.emplace_back(w->serial, text);
+	return *text;
 }
 void file_write(const char *buffer, size_t buffer_length, void *file) {
 	if (fwrite(buffer, 1, buffer_length, static_cast<FILE *>(file)) != buffer_length)
@@ -2261,6 +2276,9 @@ void panda_writer_unref(PandaWriter writer) {
 		left = --writer->refcnt;
 	}
 	if (left == 0) {
+		for (auto &b : writer->buffers)	// writer.c:186-193: what any thread appended and never committed is written now
+			if (!b.second.empty())
+				writer->write(b.second.data(), b.second.size(), writer->write_data);
 		if (writer->commit_slave != nullptr)
 			panda_writer_unref(writer->commit_slave);
 		if (writer->write_destroy != nullptr && writer->write_data != nullptr)

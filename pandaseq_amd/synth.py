@@ -205,6 +205,26 @@ def generate_device(spec: SynthSpec, start: int, n: int, device="cuda:0", stream
     return fwd, rev, flen, rlen
 
 
+def generate_host(spec: SynthSpec, start: int, n: int):
+    """generate_numpy's arrays (the same values, padding zeroed), made by the HIP generator where a GPU is present and copied
+    back: 300 000 pairs take a second instead of a minute.  tests/test_parity_gpu.py::test_synth_device_matches_numpy holds the
+    two generators to each other; without a GPU (the CPU suite) this IS generate_numpy."""
+    try:
+        import torch
+        gpu = torch.cuda.is_available()
+    except Exception:
+        gpu = False
+    if not gpu or n < 256:
+        return generate_numpy(spec, start, n)
+    f, r, fl, rl = generate_device(spec, start, n)
+    torch.cuda.synchronize()
+    L = spec.read_len
+    f, r = f.cpu().numpy(), r.cpu().numpy()
+    f[:, L:] = 0
+    r[:, L:] = 0
+    return f, r, fl.cpu().numpy().view(np.uint16).copy(), rl.cpu().numpy().view(np.uint16).copy()
+
+
 # ---- FASTQ rendering of synthetic pairs (input of the ingest path, SURVEY.md 8f row 1) --------------
 _NT_ASCII = np.frombuffer(b"NACMGRSVTWYHKDBN", dtype=np.uint8)  # ntchar, nt.c:25
 _NT_COMP = np.array([((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3) for v in range(16)], dtype=np.uint8)

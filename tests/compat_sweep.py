@@ -40,7 +40,7 @@ def run(rounds=10, first=0, log=print):
             if rnd % 2:
                 fwd, rev, flen, rlen = adversarial_pairs(spec, n, seed=int(rng.integers(1, 1 << 30)))
             else:
-                fwd, rev, flen, rlen = synth.generate_numpy(spec, int(rng.integers(0, 1_000_000)), n)
+                fwd, rev, flen, rlen = synth.generate_host(spec, int(rng.integers(0, 1_000_000)), n)
             algo = ALGOS[rnd % 7]
             if algo == "pear":
                 rlen = np.minimum(rlen, flen)

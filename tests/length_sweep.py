@@ -33,7 +33,7 @@ def run(rounds=10, first=0, n=1500, log=print):
         tmin = int(rng.integers(max(12, L // 2), L + 1))                    # fragments shorter than a read: the overlap runs past its ends
         tmax = int(rng.integers(max(tmin, L + 1), min(2 * L - 2, 1024) + 1))
         spec = synth.SynthSpec(0x5EED1000 + rnd, L, tmin, tmax, qhi=int(rng.integers(30, 42)))
-        f, r, fl, rl = synth.generate_numpy(spec, int(rng.integers(0, 1_000_000)), n)
+        f, r, fl, rl = synth.generate_host(spec, int(rng.integers(0, 1_000_000)), n)
         if rnd % 3 == 0:    # a third of the rounds: a quarter of the pairs cut to ragged lengths
             cut = rng.random(n) < 0.25
             fl = np.where(cut, rng.integers(1, L + 1, n), fl).astype(fl.dtype)

@@ -34,7 +34,7 @@ def run(rounds=5, wide=False, first=0, n=3000, log=print):
             spec = synth.config_spec(cfg)
             start = int(rng.integers(0, 40_000_000))
             if rnd % 2 == 0:
-                f, r, fl, rl = synth.generate_numpy(spec, start, n)
+                f, r, fl, rl = synth.generate_host(spec, start, n)
             else:
                 f, r, fl, rl = adversarial_pairs(spec, n, seed=int(rng.integers(1, 1 << 30)))
             primers = cfg == 2

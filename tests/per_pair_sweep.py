@@ -37,7 +37,7 @@ def run(rounds=10, first=0, log=print):
             n = int(rng.integers(50, 1200))
             if primers:
                 spec = synth.config_spec(2)
-                fwd, rev, flen, rlen = synth.generate_numpy(spec, int(rng.integers(0, 100_000)), n)
+                fwd, rev, flen, rlen = synth.generate_host(spec, int(rng.integers(0, 100_000)), n)
                 fp, rp = synth.nt_codes(spec.fprimer), synth.nt_codes(spec.rprimer, complement=True)
                 options += ["-p", pp.primer_arg(fp), "-q", pp.primer_arg(rp)]
                 kw.update(fprimer=fp, rprimer=rp)
@@ -55,7 +55,7 @@ def run(rounds=10, first=0, log=print):
                 if rnd % 2:
                     fwd, rev, flen, rlen = adversarial_pairs(spec, n, seed=int(rng.integers(1, 1 << 30)))
                 else:
-                    fwd, rev, flen, rlen = synth.generate_numpy(spec, int(rng.integers(0, 100_000)), n)
+                    fwd, rev, flen, rlen = synth.generate_host(spec, int(rng.integers(0, 100_000)), n)
             if algo == "pear":
                 rlen = np.minimum(rlen, flen)
             if rng.random() < 0.4:

@@ -19,7 +19,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 bad = 0
 for cfg, algo in ((0, "simple_bayesian"), (1, "simple_bayesian"), (4, "simple_bayesian"), (1, "pear"), (1, "rdp_mle"), (0, "pear")):
     spec = synth.config_spec(cfg)
-    f, r, fl, rl = adversarial_pairs(spec, 6000, seed=cfg + 3) if cfg == 1 else synth.generate_numpy(spec, 0, 6000)
+    f, r, fl, rl = adversarial_pairs(spec, 6000, seed=cfg + 3) if cfg == 1 else synth.generate_host(spec, 0, 6000)
     if algo == "pear":
         rl = np.minimum(rl, fl)
     o = po.assemble_batch(po.make_config(algo), f, r, fl, rl)

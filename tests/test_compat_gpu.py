@@ -155,7 +155,7 @@ def test_reference_plugin_that_calls_back_into_the_library(built, tmp_path):
         pytest.skip("oracle/_ref was not built (needs /root/reference at build time: make -C oracle ref)")
     spec = synth.config_spec(2)     # reads that begin with the forward primer, a tenth of them after 1-3 stray bases
     n = 2000
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 4000, n)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 4000, n)
     rng = np.random.default_rng(5)
     wipe = rng.random(n) < 0.4      # the primer destroyed in four reads of ten: those pass the filter
     fwd[wipe, :24, 0] = rng.choice(np.array([1, 2, 4, 8], np.uint8), (int(wipe.sum()), 24))
@@ -302,7 +302,7 @@ def test_one_assembler_per_thread(built, tmp_path):
     from pandaseq_amd import synth
     from oracle import pyoracle as po
     spec = synth.config_spec(1)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 20000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 20000)
     pin = tmp_path / "pairs.bin"
     _write_pairs(pin, fwd, rev, flen, rlen)
     exe = str(tmp_path / "test_threads")
@@ -327,7 +327,7 @@ def test_fused_modules_after_a_host_module(built, tmp_path):
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
     n = 3000
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, n)
     pin, pout = tmp_path / "pairs.bin", tmp_path / "out.bin"
     _write_pairs(pin, fwd, rev, flen, rlen)
     subprocess.check_call([_build_client(str(tmp_path)), str(pin), str(pout), "rdp_mle", "4"], timeout=300)
@@ -359,7 +359,7 @@ def test_algorithm_class_registered_by_the_caller(built, tmp_path, primers):
     from util import adversarial_pairs
     spec = synth.config_spec(2 if primers else 1)
     if primers:
-        fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 600)
+        fwd, rev, flen, rlen = synth.generate_host(spec, 0, 600)
     else:
         fwd, rev, flen, rlen = adversarial_pairs(spec, 600, seed=31)
     pairs = tmp_path / "pairs.bin"
@@ -376,7 +376,7 @@ def test_reference_api_default_sums(built, tmp_path):
     from oracle import pyoracle as po
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 500, 700)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 500, 700)
     pin, pout = tmp_path / "pairs.bin", tmp_path / "out.bin"
     _write_pairs(pin, fwd, rev, flen, rlen)
     env = dict(os.environ)
@@ -399,7 +399,7 @@ def test_rows_built_on_the_callers_thread(built, tmp_path):
     caller's thread instead of ahead of it -- the same records, bit for bit."""
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 900, 1500)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 900, 1500)
     pin = tmp_path / "pairs.bin"
     _write_pairs(pin, fwd, rev, flen, rlen)
     exe = _build_client(str(tmp_path))
@@ -419,7 +419,7 @@ def test_one_assembler_per_thread_consumers(built, tmp_path):
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
     distinct, total, threads = 3000, 50_000, 4
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, distinct)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, distinct)
     pin = tmp_path / "pairs.bin"
     _write_pairs(pin, fwd, rev, flen, rlen)
     exe = _build_c(str(tmp_path), "bench_pool")

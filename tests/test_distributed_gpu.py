@@ -78,7 +78,7 @@ def test_two_ranks_on_one_gpu_reduce_to_a_single_run(built):
     assert text == format_stat_block(single, module_names=names)
     # ... and from the oracle's, on a prefix the host finishes in seconds
     m = 20_000
-    f, r, fl, rl = synth.generate_numpy(synth.config_spec(CFG), 0, m)
+    f, r, fl, rl = synth.generate_host(synth.config_spec(CFG), 0, m)
     ctr = po.assemble_batch(bench.oracle_config(po, synth, CFG), f, r, fl, rl, want_seq=False)[3]
     d = counters_to_dict(_shard_counters(0, m).cpu().numpy())
     for k in ("count", "badr", "nofp", "norp", "noalgn", "lowq", "ok", "slow"):

@@ -54,7 +54,7 @@ def test_long_geometry_all_scorers(built, algo, sums):
             if algo == "pear":
                 rlen = np.minimum(rlen, flen)   # algo_pear.c:52 reads the forward read at the reverse index
         else:
-            fwd, rev, flen, rlen = synth.generate_numpy(spec, 200, n)
+            fwd, rev, flen, rlen = synth.generate_host(spec, 200, n)
         asm = pa.Assembler(0)
         asm.set_algorithm(algo)
         asm.set_exact_sums(sums == "exact")
@@ -87,7 +87,7 @@ def test_primer_scan_inside_the_lean_kernel(built, plen, algo, sums):
     rng = np.random.default_rng(300 + plen)
     spec = synth.config_spec(2 if plen % 2 else 1)     # 2x300 and 2x250 reads
     L = spec.read_len
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 52000, 2500)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 52000, 2500)
     fwd[:, :, 0] = np.where(np.arange(fwd.shape[1])[None, :] < L, fwd[:, :, 0], 0)
     n = len(flen)
     codes = np.array([1, 2, 4, 8, 1, 2, 4, 8, 3, 5, 10, 12, 7, 14, 15], np.uint8)   # mostly plain bases, some ambiguity codes, N
@@ -123,7 +123,7 @@ def sweep_case(rnd):
     spec = synth.config_spec(2 if rnd % 3 else 1)
     L = spec.read_len
     n = 3000
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, int(rng.integers(0, 40_000_000)), n)
+    fwd, rev, flen, rlen = synth.generate_host(spec, int(rng.integers(0, 40_000_000)), n)
     fwd[:, :, 0] = np.where(np.arange(fwd.shape[1])[None, :] < L, fwd[:, :, 0], 0)
     fplen, rplen = int(rng.integers(1, 25)), int(rng.integers(1, 25))
     fp = rng.choice(codes if rnd % 2 else codes[:4], fplen)
@@ -169,7 +169,7 @@ def test_primers_the_lean_kernel_does_not_serve(built):
     import pandaseq_amd as pa
     from pandaseq_amd import synth
     spec = synth.config_spec(2)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 1200)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 1200)
     fp = np.concatenate([synth.nt_codes(spec.fprimer), np.array([1, 2, 4, 8, 1, 2, 4, 8], np.uint8)])
     rp = synth.nt_codes(spec.rprimer, complement=True)
     fwd[:, 17:25, 0] = fp[17:]
@@ -194,7 +194,7 @@ def test_trims_inside_the_lean_kernel(built, ftrim, rtrim, sums):
     import pandaseq_amd as pa
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 9000, 3000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 9000, 3000)
     rng = np.random.default_rng(ftrim * 7 + rtrim)
     flen[::7] = rng.integers(2, 251, len(flen[::7]))
     rlen[::5] = rng.integers(2, 251, len(rlen[::5]))
@@ -214,7 +214,7 @@ def test_one_primer_only_and_offsets_of_deferred_pairs(built):
     from pandaseq_amd import synth
     spec = synth.config_spec(2)
     n = 3000
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 77000, n)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 77000, n)
     rng = np.random.default_rng(9)
     L = spec.read_len
     for i in range(0, n, 6):    # tandem repeats behind intact primers

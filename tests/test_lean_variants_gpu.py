@@ -89,7 +89,7 @@ def test_every_instantiation_of_the_lean_kernel(built, algo, geometry):
     cfg, want, extra = GEOMETRIES[geometry]
     spec = synth.config_spec(cfg)
     n = 3000
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 4242, n)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 4242, n)
     if algo == "pear":
         rlen = np.minimum(rlen, flen)
     fp = rp = None

@@ -22,7 +22,7 @@ def test_maximum_overlap_in_the_lean_kernel(built, algo, cfg, maxov, sums):
     if maxov in (249, 40):     # ragged reads: the maximum lies beyond the shorter read of some pairs (deferred), within it for others
         fwd, rev, flen, rlen = adversarial_pairs(spec, n, seed=maxov, iupac=False, weird_quals=False)
     else:
-        fwd, rev, flen, rlen = synth.generate_numpy(spec, 7_000_000 + maxov, n)
+        fwd, rev, flen, rlen = synth.generate_host(spec, 7_000_000 + maxov, n)
     if algo == "pear":
         rlen = np.minimum(rlen, flen)
     kw = dict(maxoverlap=maxov)

@@ -440,6 +440,25 @@ def test_writer_and_output_functions(built, tmp_path):
     L.panda_writer_unref(fw)                 # (the master still holds it)
     L.panda_writer_unref(w)                  # closes the file through the slave's destroy
     assert path.read_bytes() == b"#42\n"
+    # text appended and never committed is written when the last reference goes (writer.c:186-193), from whichever thread appended
+    # it; and more writers than a thread's cache of buffers holds (64) lose nothing
+    import threading
+    late = []
+    cb2 = WRITE(lambda buf, n, data: late.append(C.string_at(buf, n)))
+    w2 = L.panda_writer_new(cb2, None, None)
+    L.panda_writer_append(w2, b"main %d;", 1)
+    t = threading.Thread(target=lambda: L.panda_writer_append(w2, b"other %d;", 2))
+    t.start()
+    t.join()
+    many = [L.panda_writer_new(cb2, None, None) for _ in range(70)]
+    for k, m in enumerate(many):
+        L.panda_writer_append(m, b"w%d;", k)
+    assert late == []
+    L.panda_writer_unref(w2)
+    assert sorted(late) == [b"main 1;", b"other 2;"]
+    for m in many:
+        L.panda_writer_unref(m)
+    assert sorted(late[2:]) == sorted(b"w%d;" % k for k in range(70))
 
 
 def test_bzip2_in_and_out(lib, tmp_path):

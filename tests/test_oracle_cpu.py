@@ -458,6 +458,35 @@ def test_the_bench_kernels_do_not_spill(built, tmp_path):
     assert len(cold) == 1 and int(cold[0][1]) <= 80, cold     # (56 when this was written, 65 since the uniform regions are no longer structurized)
 
 
+def test_the_build_refuses_a_hazardous_listing(built, tmp_path):
+    """tools/isa_hazards.py is a step of the BUILD (pandaseq_amd/csrc/Makefile: the lean kernel's object is moved into place only
+    after the listing of the same compilation has passed the scan), not only of this suite: `make isa-check` passes on the listing
+    the library was built from and fails on a copy with a planted hazard -- a register move that reads the destination of a bare
+    LDS read before its wait, and a compiler-side use of M0."""
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, "pandaseq_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert "$(ISA_CHECK) $(FAST_LISTING)" in mk and "mv $(OBJDIR)/fast/pamd_fast.o $@" in mk
+    listings = glob.glob(os.path.join(ROOT, "pandaseq_amd", "libpandaseq_amd.so.obj", "*", "fast", "pamd_fast-hip-amdgcn-amd-amdhsa-gfx950.s"))
+    if not listings:
+        pytest.skip("the library was not built in this tree (no listing kept)")
+    listing = max(listings, key=os.path.getmtime)
+    assert subprocess.run(["make", "-s", "-C", csrc, "isa-check", "ISA_LISTING=" + listing], capture_output=True).returncode == 0
+    lines = open(listing).read().splitlines()
+    at = next(i for i, t in enumerate(lines) if t.strip().startswith("ds_read_u16 v") and lines[i - 1].strip().startswith(";;#ASMSTART"))
+    reg = lines[at].strip().split()[1].rstrip(",")
+    end = next(i for i in range(at, len(lines)) if lines[i].strip().startswith(";;#ASMEND"))
+    planted = lines[:end + 1] + ["\tv_mov_b32_e32 v0, " + reg] + lines[end + 1:]
+    (tmp_path / "planted.s").write_text("\n".join(planted))
+    out = subprocess.run(["make", "-s", "-C", csrc, "isa-check", "ISA_LISTING=" + str(tmp_path / "planted.s")], capture_output=True, text=True)
+    assert out.returncode != 0 and "1 uses of a pending register" in out.stdout, out.stdout[-500:]
+    planted = lines[:end + 1] + ["\ts_movrels_b32 s0, s1", "\ts_mov_b32 m0, s2"] + lines[end + 1:]
+    (tmp_path / "planted_m0.s").write_text("\n".join(planted))
+    out = subprocess.run(["make", "-s", "-C", csrc, "isa-check", "ISA_LISTING=" + str(tmp_path / "planted_m0.s")], capture_output=True, text=True)
+    assert out.returncode != 0 and "1 compiler-emitted uses of m0" in out.stdout, out.stdout[-500:]
+
+
 def test_row_checksums_two_ways(built):
     """bench.py's at-scale row parity rests on two implementations of the same per-row checksums -- the oracle's
     (po_row_checksums_mt, C, on the host) and the product's (pandaseq_amd.row_checksums, torch, where the rows lie) --: here both

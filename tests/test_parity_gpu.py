@@ -35,7 +35,7 @@ def test_synthetic_configs(built, algo, cfg, sums):
     from pandaseq_amd import synth
     spec = synth.config_spec(cfg)
     n = 6000
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, n)
     asm = pa.Assembler(0)
     asm.set_algorithm(algo)
     asm.set_exact_sums(sums == "exact")
@@ -73,7 +73,7 @@ def _at_scale_against_the_oracle(algo, cfg, after, exact, n):
     from oracle import pyoracle as po
     from pandaseq_amd import synth
     spec = synth.config_spec(cfg)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 31_000_000, n)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 31_000_000, n)
     if algo == "pear":
         rlen = np.minimum(rlen, flen)
     okw = {}
@@ -168,7 +168,7 @@ def test_config2_primers_pear(built, sums):
     """BASELINE configs[2]: 2x300 with embedded primers, -p/-q, pear."""
     from pandaseq_amd import synth
     spec = synth.config_spec(2)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 5000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 5000)
     # a few pairs whose primers are damaged or missing, and a read shorter than the primer
     rng = np.random.default_rng(3)
     for i in range(0, 200, 7):
@@ -188,7 +188,7 @@ def test_config2_primers_pear(built, sums):
 def test_primers_all_algorithms_with_penalty(built, penalty):
     from pandaseq_amd import synth
     spec = synth.config_spec(2)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 7000, 1500)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 7000, 1500)
     for algo in ("simple_bayesian", "rdp_mle"):
         asm = _asm_for(algo, spec, primers=True, primer_penalty=penalty)
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=608)
@@ -202,7 +202,7 @@ def test_config3_rdp_with_modules(built, sums):
     """BASELINE configs[3]: rdp_mle + min_phred + min_overlapbits, modules applied in order."""
     from pandaseq_amd import synth
     spec = synth.config_spec(3)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 6000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 6000)
     for mods in ([("min_phred", 2), ("min_overlapbits", 15)], [("min_overlapbits", 40), ("min_phred", 1)], [("min_phred", 10)]):
         asm = _asm_for("rdp_mle", modules=[f"{k}:{v}" for k, v in mods], exact=sums == "exact")
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
@@ -220,7 +220,7 @@ def test_min_phred_one_on_rows_with_both_kinds_of_low_p(built, algo, sums):
     from oracle import pyoracle as po
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 9000, 3000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 9000, 3000)
     plain = _oracle(algo, fwd, rev, flen, rlen)
     # two disagreeing positions planted in every second pair's overlap: qualities (3, 7) give a log-p between qual_score[0] and
     # [1] under simple_bayesian and (5, 4) under uparse, qualities (4, 30) / (0, 1) one at or below qual_score[0]
@@ -300,7 +300,7 @@ def test_algorithm_parameters(built):
     from pandaseq_amd import synth
     import pandaseq_amd as pa
     spec = synth.config_spec(0)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 3000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 3000)
     asm = pa.Assembler(0)
     asm.set_algorithm("simple_bayesian", 0.2)
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
@@ -316,7 +316,7 @@ def test_max_length_reads(built, sums):
     """PANDA_MAX_LEN = 450 reads: the widest rows, the longest merges (899) and the smallest launch geometry."""
     from pandaseq_amd import synth
     spec = synth.SynthSpec(seed=77, read_len=450, tmin=450, tmax=899, qhi=40)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 1500)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 1500)
     for algo in ("simple_bayesian", "pear", "rdp_mle"):
         asm = _asm_for(algo, exact=sums == "exact")
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
@@ -331,7 +331,7 @@ def test_host_buffer_entry_point(built):
     from pandaseq_amd import synth
     import pandaseq_amd as pa
     spec = synth.config_spec(1)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 500, 2000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 500, 2000)
     asm = pa.Assembler(0)
     for stride in (512, 0):
         res, nt, p, ctr = asm.assemble_host(fwd, rev, flen, rlen, seq_stride=stride)
@@ -346,11 +346,11 @@ def test_empty_and_tiny_batches(built):
     spec = synth.config_spec(0)
     asm = pa.Assembler(0)
     for n in (1, 2, 17):
-        fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
+        fwd, rev, flen, rlen = synth.generate_host(spec, 0, n)
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
         o = _oracle("simple_bayesian", fwd, rev, flen, rlen)
         compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 4)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 4)
     res, nt, p, ctr = asm.assemble_host(fwd[:0], rev[:0], flen[:0], rlen[:0])
     assert len(res) == 0 and ctr["count"] == 0
 
@@ -509,7 +509,7 @@ def test_unequal_strides_and_api_validation(built):
     import pandaseq_amd as pa
     from pandaseq_amd import _lib, synth
     spec = synth.config_spec(1)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 1500)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 1500)
     # reverse reads truncated to 180 bases in a narrower row
     rev2 = np.ascontiguousarray(rev[:, :184])
     rlen2 = np.minimum(rlen, 180).astype(np.uint16)
@@ -535,7 +535,7 @@ def test_arena_overflow_is_reported(built):
     import pandaseq_amd as pa
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 4000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 4000)
     asm = pa.Assembler(0)
     with pytest.raises(pa.PamdError, match="arena too small"):
         asm.assemble_host(fwd, rev, flen, rlen, seq_stride=0, capacity=200_000)
@@ -585,7 +585,7 @@ def test_primer_scan_when_exp_collapses_two_alignments(built):
             break
     assert sum(1 for c in cases if c[2] == "tie") >= 2, "the search must produce ties for the test to mean anything"
     n = len(cases)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, n)
     other = {1: 2, 2: 4, 4: 8, 8: 1}
     for i, (qa, qb, _kind) in enumerate(cases):
         fwd[i, 0:P, 0] = primer
@@ -633,7 +633,7 @@ def test_primer_kernel_on_planted_primers(built, plen, penalty):
     import pandaseq_amd as pa
     rng = np.random.default_rng(100 + plen)
     spec = synth.config_spec(1)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 31000, 3000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 31000, 3000)
     n = len(flen)
     codes = np.array([1, 2, 4, 8, 1, 2, 4, 8, 3, 5, 10, 12, 7, 14, 15], np.uint8)   # mostly plain bases, some ambiguity codes, N
     fp = rng.choice(codes, plen)
@@ -708,7 +708,7 @@ def test_batch_sizes_around_the_work_queues_grain(built, cfg, algo, sums):
     64 at a time: batches just below, at and above those grains, against the oracle."""
     from pandaseq_amd import synth
     spec = synth.config_spec(cfg)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 123456, 1100)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 123456, 1100)
     kw = dict(fprimer=synth.nt_codes(spec.fprimer), rprimer=synth.nt_codes(spec.rprimer, complement=True)) if cfg == 2 else {}
     for n in (1, 2, 15, 16, 17, 31, 63, 64, 65, 127, 129, 255, 1024, 1025, 1100):
         asm = _asm_for(algo, spec, primers=cfg == 2, exact=sums == "exact")

@@ -53,7 +53,7 @@ def test_per_pair_equals_batches_on_adversarial_pairs(client, tmp_path, algo):
 @pytest.mark.parametrize("algo,cfg", [("simple_bayesian", 0), ("simple_bayesian", 4), ("pear", 4), ("rdp_mle", 1), ("uparse", 1)])
 def test_per_pair_equals_batches_on_synthetic_configs(client, tmp_path, algo, cfg):
     from pandaseq_amd import synth
-    fwd, rev, flen, rlen = synth.generate_numpy(synth.config_spec(cfg), 77_000, 1500)
+    fwd, rev, flen, rlen = synth.generate_host(synth.config_spec(cfg), 77_000, 1500)
     _three_ways(client, tmp_path, algo, fwd, rev, flen, rlen)
 
 
@@ -61,7 +61,7 @@ def test_per_pair_equals_batches_on_synthetic_configs(client, tmp_path, algo, cf
 def test_per_pair_equals_batches_with_primers(client, tmp_path, algo, how):
     from pandaseq_amd import synth
     spec = synth.config_spec(2)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 3000, 800)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 3000, 800)
     fp, rp = synth.nt_codes(spec.fprimer), synth.nt_codes(spec.rprimer, complement=True)
     options = ["-p", pp.primer_arg(fp), "-q", pp.primer_arg(rp)]
     kw = dict(fprimer=fp, rprimer=rp)
@@ -77,7 +77,7 @@ def test_per_pair_equals_batches_with_primers(client, tmp_path, algo, how):
 @pytest.mark.parametrize("algo,module,value", [("rdp_mle", "min_phred", 4), ("rdp_mle", "min_overlapbits", 15), ("pear", "min_overlapbits", 30)])
 def test_per_pair_equals_batches_with_a_fused_module(client, tmp_path, algo, module, value):
     from pandaseq_amd import synth
-    fwd, rev, flen, rlen = synth.generate_numpy(synth.config_spec(1), 9000, 1200)
+    fwd, rev, flen, rlen = synth.generate_host(synth.config_spec(1), 9000, 1200)
     _three_ways(client, tmp_path, algo, fwd, rev, flen, rlen, ["-m", "%s:%d" % (module, value)], modules=[(module, value)])
 
 
@@ -88,7 +88,7 @@ def test_array_form_across_more_batches_than_slots(client, tmp_path):
     import filecmp
     from pandaseq_amd import synth
     spec = synth.SynthSpec(0x5EED7700, 40, 46, 70, qhi=36)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 300_000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 300_000)
     pairs = tmp_path / "pairs.bin"
     pp.write_pairs(pairs, fwd, rev, flen, rlen)
     env = dict(os.environ, PAMD_COMPAT_SUMS="exact")
@@ -102,7 +102,7 @@ def test_array_form_across_more_batches_than_slots(client, tmp_path):
 def test_array_form_on_few_pairs(client, tmp_path, n):
     """... and arrays shorter than one piece of a batch (one slot filled, three idle), or empty"""
     from pandaseq_amd import synth
-    fwd, rev, flen, rlen = synth.generate_numpy(synth.config_spec(4), 500, max(n, 1))
+    fwd, rev, flen, rlen = synth.generate_host(synth.config_spec(4), 500, max(n, 1))
     fwd, rev, flen, rlen = fwd[:n], rev[:n], flen[:n], rlen[:n]
     pairs = tmp_path / "pairs.bin"
     pp.write_pairs(pairs, fwd, rev, flen, rlen)

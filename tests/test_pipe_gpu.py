@@ -61,7 +61,7 @@ def test_files_to_fasta_every_scorer(pipe, tmp_path, algo):
 
 def test_files_to_fastq_config1(pipe, tmp_path):
     spec = synth.config_spec(1)
-    f, r, fl, rl = synth.generate_numpy(spec, 0, 6000)
+    f, r, fl, rl = synth.generate_host(spec, 0, 6000)
     ft, rt = synth.render_fastq(f, r, fl, rl, tag="TTAGGC")
     got, stat, stop = _run(pipe, tmp_path, ft, rt, "simple_bayesian", "fastq", 2048)
     want, ctr, st = _oracle_text(ft, rt, "simple_bayesian", "fastq")
@@ -71,7 +71,7 @@ def test_files_to_fastq_config1(pipe, tmp_path):
 @pytest.mark.parametrize("after", [0, 1])
 def test_files_with_primers(pipe, tmp_path, after):
     spec = synth.config_spec(2)
-    f, r, fl, rl = synth.generate_numpy(spec, 0, 3000)
+    f, r, fl, rl = synth.generate_host(spec, 0, 3000)
     ft, rt = synth.render_fastq(f, r, fl, rl)
     got, stat, stop = _run(pipe, tmp_path, ft, rt, "pear", "fasta", 1000, extra=(str(after), spec.fprimer, spec.rprimer))
     want, ctr, st = _oracle_text(ft, rt, "pear", "fasta", fprimer=synth.nt_codes(spec.fprimer),
@@ -186,7 +186,7 @@ def test_reference_file_api(open_client, tmp_path, algo, gz):
 def test_reference_file_api_many_chunks_and_stop(open_client, tmp_path):
     """More pairs than one refill holds (65 536), and a record the reader must stop at."""
     spec = synth.config_spec(0)
-    f, r, fl, rl = synth.generate_numpy(spec, 0, 150_000)
+    f, r, fl, rl = synth.generate_host(spec, 0, 150_000)
     ft, rt = synth.render_fastq(f, r, fl, rl)
     lines = rt.split(b"\n")
     lines[4 * 140_000 + 3] = lines[4 * 140_000 + 3][:-1]  # one quality too few in the reverse read of record 140000
@@ -356,7 +356,7 @@ def test_multi_device_run_with_primers_and_unequal_records(pipe, tmp_path):
     """config 2 (primers before and after assembly), then records of very different sizes in the two files (the chunk boundaries
     are found per file by counting lines) and a forward file with more records than the reverse one."""
     spec = synth.config_spec(2)
-    f, r, fl, rl = synth.generate_numpy(spec, 0, 3000)
+    f, r, fl, rl = synth.generate_host(spec, 0, 3000)
     ft, rt = synth.render_fastq(f, r, fl, rl)
     for after in (0, 1):
         extra = (str(after), spec.fprimer, spec.rprimer)
@@ -410,10 +410,13 @@ def test_multi_device_run_into_a_pipe_and_from_gzip(pipe, tmp_path):
     env = dict(os.environ, PAMD_PIPE_DEVICES="0,0")
     fifo = tmp_path / "out.fifo"
     os.mkfifo(fifo)
-    reader = subprocess.Popen(["cat", str(fifo)], stdout=subprocess.PIPE)
+    import threading
+    got = []
+    reader = threading.Thread(target=lambda: got.append(open(fifo, "rb").read()))
+    reader.start()
     subprocess.check_call([pipe, str(f), str(r), str(fifo), "0", "fastq", "400"], timeout=300, env=env, stdout=subprocess.DEVNULL)
-    text, _ = reader.communicate(timeout=60)
-    assert text == want[0]
+    reader.join()
+    assert got[0] == want[0]
     (tmp_path / "f.gz").write_bytes(gzip.compress(ft, 1))
     (tmp_path / "r.gz").write_bytes(gzip.compress(rt, 1))
     subprocess.check_call([pipe, str(tmp_path / "f.gz"), str(tmp_path / "r.gz"), str(tmp_path / "gz.txt"), "0", "fastq", "400"], timeout=300, env=env, stdout=subprocess.DEVNULL)

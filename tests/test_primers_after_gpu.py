@@ -51,7 +51,7 @@ def _pair(algo, fwd, rev, flen, rlen, exact=True, seq_stride=0, est_rel_tol=0.0,
 def test_config2_primers_after(built, algo, exact):
     from pandaseq_amd import synth
     spec = synth.config_spec(2)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 4000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 4000)
     o_res, o_ctr = _pair(algo, fwd, rev, flen, rlen, exact=exact,
                          fprimer=synth.nt_codes(spec.fprimer), rprimer=synth.nt_codes(spec.rprimer, complement=True))
     ok = o_res["status"] == 0
@@ -81,7 +81,7 @@ def test_primers_after_one_primer_and_trims(built, exact):
     (exact: the general kernel's `-a`; any-order sums: the lean kernel's, DESIGN.md 3.1, docs/NOTEBOOK.md 3.1e)"""
     from pandaseq_amd import synth
     spec = synth.config_spec(2)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 3000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 3000)
     _pair("simple_bayesian", fwd, rev, flen, rlen, exact=exact, fprimer=synth.nt_codes(spec.fprimer), rtrim=9)
     _pair("simple_bayesian", fwd, rev, flen, rlen, exact=exact, rprimer=synth.nt_codes(spec.rprimer, complement=True), ftrim=5)
     _pair("pear", fwd, rev, flen, rlen, exact=exact, ftrim=20, rtrim=31)
@@ -94,7 +94,7 @@ def test_primers_after_one_primer_and_trims(built, exact):
 def test_primers_after_short_reads_and_counting_scorers(built, exact):
     from pandaseq_amd import synth
     spec = synth.config_spec(0)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 2500)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 2500)
     fp = synth.nt_codes("ACGTTGCA")
     for algo, tol in (("flash", 0.0), ("ea_util", 0.0), ("stitch", 0.0), ("uparse", 0.0)):
         _pair(algo, fwd, rev, flen, rlen, exact=exact, fprimer=fp, rprimer=fp, est_rel_tol=tol)
@@ -106,7 +106,7 @@ def test_primers_after_ambiguity_codes_in_the_primer_and_long_primers(built):
     (the general kernel's), planted at the start of the merged sequence; any-order sums."""
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 2000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 2000)
     rng = np.random.default_rng(5)
     for plen in (12, 24, 30):
         f2 = fwd.copy()

@@ -39,7 +39,7 @@ def test_synthetic_configs(built, algo, cfg, sums):
     import pandaseq_amd as pa
     from pandaseq_amd import synth
     spec = synth.config_spec(cfg)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 5000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 5000)
     asm = pa.Assembler(0)
     asm.set_algorithm(algo)
     asm.set_exact_sums(sums == "exact")
@@ -73,7 +73,7 @@ def test_uparse_error_estimation_and_modules(built):
     import pandaseq_amd as pa
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 4000)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 4000)
     asm = pa.Assembler(0)
     asm.set_algorithm("uparse", 0.25)
     asm.add_module("min_phred:3")
@@ -88,9 +88,9 @@ def test_long_reads_and_primers(built):
     import pandaseq_amd as pa
     from pandaseq_amd import synth
     spec = synth.SynthSpec(seed=91, read_len=450, tmin=450, tmax=899, qhi=40)
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, 1200)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, 1200)
     spec2 = synth.config_spec(2)
-    f2, r2, fl2, rl2 = synth.generate_numpy(spec2, 0, 1500)
+    f2, r2, fl2, rl2 = synth.generate_host(spec2, 0, 1500)
     for algo in SCORERS:
         asm = pa.Assembler(0)
         asm.set_algorithm(algo)

@@ -68,7 +68,7 @@ def check_parse(textio, ft, rt, qualmin=33, policy=2, stride=456, parser=None):
 def test_parse_synthetic_config1(io, crlf):
     pa, textio, parser, _ = io
     spec = synth.config_spec(1)
-    f, r, fl, rl = synth.generate_numpy(spec, 0, 20000)
+    f, r, fl, rl = synth.generate_host(spec, 0, 20000)
     ft, rt = synth.render_fastq(f, r, fl, rl, crlf=crlf)
     out, st = check_parse(textio, ft, rt, stride=spec.row_stride(), parser=parser)
     assert st.n_good == 20000 and st.fwd_consumed == len(ft) and st.rev_consumed == len(rt)
@@ -118,7 +118,7 @@ def test_parse_in_chunks(io):
 def test_parse_row_overflow_and_validation(io):
     pa, textio, parser, _ = io
     spec = synth.config_spec(1)
-    f, r, fl, rl = synth.generate_numpy(spec, 0, 64)
+    f, r, fl, rl = synth.generate_host(spec, 0, 64)
     ft, rt = synth.render_fastq(f, r, fl, rl)
     out, st = parser.parse(textio.text_to_device(ft), textio.text_to_device(rt), 100, stride=128)
     assert textio.FQ_STOP[st.stop_code] == "ROW_OVERFLOW" and st.n_good == 0
@@ -190,7 +190,7 @@ def test_format_with_rejections_and_fastq_phred_range(io):
     """rdp_mle + both check modules: rejected pairs print nothing; phred bytes span the table."""
     pa, textio, parser, formatter = io
     spec = synth.config_spec(3)
-    f, r, fl, rl = synth.generate_numpy(spec, 0, 3000)
+    f, r, fl, rl = synth.generate_host(spec, 0, 3000)
     ft, rt = synth.render_fastq(f, r, fl, rl)
     ftd = textio.text_to_device(ft)
     rows, st = parser.parse(ftd, textio.text_to_device(rt), 3001, spec.row_stride())
@@ -216,7 +216,7 @@ def test_fastq_phred_of_every_kind_of_value(io):
     pa, textio, parser, formatter = io
     spec = synth.config_spec(1)
     n = 600
-    f, r, fl, rl = synth.generate_numpy(spec, 100, n)
+    f, r, fl, rl = synth.generate_host(spec, 100, n)
     ft, rt = synth.render_fastq(f, r, fl, rl)
     ftd = textio.text_to_device(ft)
     rows, st = parser.parse(ftd, textio.text_to_device(rt), n + 1, spec.row_stride())
@@ -288,7 +288,7 @@ def test_parse_max_pairs_and_resume(io):
 def test_format_capacity_and_empty(io):
     pa, textio, parser, formatter = io
     spec = synth.config_spec(1)
-    f, r, fl, rl = synth.generate_numpy(spec, 0, 512)
+    f, r, fl, rl = synth.generate_host(spec, 0, 512)
     ft, rt = synth.render_fastq(f, r, fl, rl)
     ftd = textio.text_to_device(ft)
     rows, st = parser.parse(ftd, textio.text_to_device(rt), 512, spec.row_stride())

@@ -37,7 +37,7 @@ def test_lean_kernel_matches_oracle_and_general(built, algo, exact):
         if weird:
             fwd, rev, flen, rlen = adversarial_pairs(spec, n, seed=21)
         else:
-            fwd, rev, flen, rlen = synth.generate_numpy(spec, 100, n)
+            fwd, rev, flen, rlen = synth.generate_host(spec, 100, n)
         o_res, o_nt, o_p, o_ctr = _oracle(algo, fwd, rev, flen, rlen)
         deferred = None
         for fast_path in (True, False):
@@ -68,7 +68,7 @@ def test_lean_kernel_many_candidates_and_repeats(built):
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
     n = 3000
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, n)
     rng = np.random.default_rng(5)
     L = spec.read_len
     for i in range(0, n, 3):   # tandem repeats of every unit length, and a few poly-N stretches inside them
@@ -102,7 +102,7 @@ def test_arena_overflow_through_the_device_path(built):
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
     n = 5000
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, n)
     o_res, o_nt, o_p, o_ctr = _oracle("simple_bayesian", fwd, rev, flen, rlen)
     for fast_path in (True, False):
         for exact in (True, False):
@@ -139,7 +139,7 @@ def test_streaming_a_shard_in_chunks(built, exact):
     from pandaseq_amd import synth
     spec = synth.config_spec(1)
     n, chunk = 30_000, 11_000
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, n)
     asm = pa.Assembler(0)
     asm.set_exact_sums(exact)
     whole = pa.upload_batch(fwd, rev, flen, rlen, device="cuda:0", seq_stride=0)

@@ -9,7 +9,7 @@ P_TOL = 1e-6  # north_star: per-base log-probabilities within 1e-6 (we expect ex
 def adversarial_pairs(spec, n, seed=1, ragged=True, weird_quals=True, iupac=True):
     """Synthetic pairs plus the edge cases the hot path has: Ns, IUPAC ambiguity codes, Q2 tails
     (B-cliff), ragged and too-short reads, qualities outside 0..46, identical-quality mismatches."""
-    fwd, rev, flen, rlen = synth.generate_numpy(spec, 0, n)
+    fwd, rev, flen, rlen = synth.generate_host(spec, 0, n)
     rng = np.random.default_rng(seed)
     L = spec.read_len
     if iupac:
@@ -106,15 +106,24 @@ def compare_results(dev_res, dev_nt, dev_p, ora_res, ora_nt, ora_p, seq_stride=N
         return
     ok = np.nonzero(st_o == 0)[0]
     max_dp = 0.0
-    for i in ok:
-        m = int(ora_res["seq_len"][i])
-        off = int(dev_res["seq_offset"][i])
-        assert off != 0xFFFFFFFFFFFFFFFF
+    # every merged base and log-p of every accepted pair, a few thousand rows at a time (the rows gathered into one matrix)
+    for lo in range(0, ok.size, 4096):
+        rows = ok[lo:lo + 4096]
+        m = ora_res["seq_len"][rows].astype(np.int64)
+        assert not (dev_res["seq_offset"][rows] == np.uint64(0xFFFFFFFFFFFFFFFF)).any()
+        off = dev_res["seq_offset"][rows].astype(np.int64)
         if seq_stride:
-            assert off == i * seq_stride
-        assert np.array_equal(dev_nt[off:off + m], ora_nt[i, :m]), f"merged nt differs at pair {i}"
-        d = np.abs(dev_p[off:off + m] - ora_p[i, :m])
+            assert np.array_equal(off, rows.astype(np.int64) * seq_stride)
+        width = int(m.max()) if m.size else 0
+        j = np.arange(width, dtype=np.int64)
+        inside = j[None, :] < m[:, None]
+        assert (off + m <= dev_nt.size).all(), "a row runs past the end of the arena"
+        at = np.where(inside, off[:, None] + j[None, :], 0)
+        wrong = (dev_nt[at] != ora_nt[rows][:, :width]) & inside
+        assert not wrong.any(), f"merged nt differs at pair {rows[np.nonzero(wrong.any(axis=1))[0][0]]}"
+        d = np.where(inside, np.abs(dev_p[at] - ora_p[rows][:, :width]), 0.0)
         if d.size:
+            assert not np.isnan(d).any(), f"per-base log-p is NaN on one side only at pair {rows[np.nonzero(np.isnan(d).any(axis=1))[0][0]]}"
             max_dp = max(max_dp, float(d.max()))
     assert max_dp <= P_TOL, f"per-base log-p differs by {max_dp}"
     assert max_dp == 0.0, f"per-base log-p not bit-exact (max diff {max_dp}, within tolerance)"

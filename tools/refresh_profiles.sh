@@ -2,7 +2,7 @@
 # Everything profiles/ holds for one build, in one go on the GPU box (writes gpurun_out/<tag>/; copy what is to be
 # kept into profiles/):   bash tools/refresh_profiles.sh r02
 # bench lines of configs 1 (fast sums with the CPU baseline and the end-to-end leg; exact sums), 2, 3, 4; rocprofv3
-# --kernel-trace --stats of the default bench command; SQ counters and the per-phase ablation of the lean kernel, SQ counters of
+# --kernel-trace --stats of the bench command without its `other_configs` leg (config 1 alone: the kernels of configs 2-4 have their own lines); SQ counters and the per-phase ablation of the lean kernel, SQ counters of
 # config 2's two kernels; the HBM
 # traffic passes of tools/traffic_probe.py (FETCH_SIZE and WRITE_SIZE in separate passes, calibrated on a 1 GiB copy);
 # the other scorers, `-a`, and the data-format rows (bench.py --io, rocprofv3 of tools/bench_io.py).
@@ -16,13 +16,13 @@ cd "$ROOT"
 # (git rev-parse --short HEAD > .build_id)
 export PAMD_BUILD=$(cat .build_id 2>/dev/null || git rev-parse --short HEAD 2>/dev/null || echo unknown)
 python3 bench.py --steps 5 --warmup 1 2> "$OUT/bench_config1_fast.err" | tail -1 > "$OUT/bench_config1_fast.json"
-python3 bench.py --steps 5 --warmup 1 --sums exact --no-cpu --no-e2e 2> /dev/null | tail -1 > "$OUT/bench_config1_exact.json"
+python3 bench.py --steps 5 --warmup 1 --sums exact --no-cpu --no-e2e --no-other-configs 2> /dev/null | tail -1 > "$OUT/bench_config1_exact.json"
 for c in 2 3 4; do python3 bench.py --steps 3 --warmup 1 --config $c --no-cpu --no-e2e 2> /dev/null | tail -1 > "$OUT/bench_config$c.json"; done
 for c in 2 3 4; do python3 bench.py --steps 3 --warmup 1 --config $c --sums exact --no-cpu --no-e2e 2> /dev/null | tail -1 > "$OUT/bench_config${c}_exact.json"; done
 python3 bench.py --steps 3 --warmup 1 --config 2 --primers-after --sums exact --no-cpu --no-e2e 2> /dev/null | tail -1 > "$OUT/bench_config2_primers_after_exact.json"
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o t -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu --no-e2e > "$OUT/prof.log" 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o t -- python3 "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu --no-e2e --no-other-configs > "$OUT/prof.log" 2>&1)
 python3 profiles/summarize_rocprof.py --like '%pamd_%' $(find "$OUT/prof" -name '*_results.db' | head -1) > "$OUT/rocprof.txt"
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof2" -o t -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --config 2 --no-cpu --no-e2e > "$OUT/prof2.log" 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof2" -o t -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --config 2 --no-cpu --no-e2e --no-other-configs > "$OUT/prof2.log" 2>&1)
 python3 profiles/summarize_rocprof.py --like '%pamd_%' $(find "$OUT/prof2" -name '*_results.db' | head -1) > "$OUT/rocprof_config2.txt"
 traffic() {	# config sums pairs [tag]
 	export PAMD_CONFIG=$1 PAMD_SUMS=$2 PAMD_PAIRS=$3
