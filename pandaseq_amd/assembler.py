@@ -46,6 +46,15 @@ class DeviceBatch:
     def counters_dict(self):
         return counters_to_dict(self.counters.cpu().numpy())
 
+    def rows_numpy(self):
+        """(seq_nt, seq_p) on the host.  Of a compact arena only the part the launch's waves reserved (everything below the
+        cursor: the rows lie there) -- the arena of a 2 000-pair test batch is sized for its chunks, a gigabyte, and its rows are
+        a megabyte."""
+        used = self.capacity
+        if self.seq_stride == 0:
+            used = max(0, min(used, int(self.cursor.item())))
+        return self.seq_nt[:used].cpu().numpy(), self.seq_p[:used].cpu().numpy()
+
 
 def counters_to_dict(c):
     c = np.asarray(c)

@@ -85,7 +85,6 @@ struct pamd_assembler {
 	bool primers_dirty = true;
 	unsigned long long *d_error = nullptr;
 	bool notp_never_finite = false;	// of the table image on the device (upload_tables)
-	bool tables_symmetric = false;	// matrices A and B of that image, bit for bit
 	unsigned long long *d_phase = nullptr;
 	void *hb_ptr[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };	// pamd_assemble_host staging
 	size_t hb_cap[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -436,11 +435,6 @@ static int upload_tables(pamd_assembler *a, hipStream_t st) {
 		for (size_t i = 0; i < img.size(); i++)
 			notp[i] = (img[i] > M_LN2) ? std::log1p(-std::exp(-img[i])) : std::log(-std::expm1(-img[i]));
 		HIP_TRY(hipMemcpy(a->d_notp, notp.data(), sizeof(double) * notp.size(), hipMemcpyHostToDevice));
-		a->tables_symmetric = true;
-		for (int qa = 0; qa < PAMD_NQ; qa++)
-			for (int qb = 0; qb < qa; qb++)
-				if (memcmp(&A[qa * PAMD_NQ + qb], &A[qb * PAMD_NQ + qa], 8) != 0 || memcmp(&B[qa * PAMD_NQ + qb], &B[qb * PAMD_NQ + qa], 8) != 0)
-					a->tables_symmetric = false;
 		a->notp_never_finite = true;
 		for (size_t i = 0; i < (a->algo == PAMD_ALGO_RDP_MLE ? img.size() : (size_t) PAMD_LT_C); i++)
 			if (i != (size_t) PAMD_LT_ZERO && std::isfinite(notp[i]))	// (the spare slot holds 0.0 and is no base's log-p)
@@ -627,7 +621,6 @@ static int assemble_device_impl(pamd_assembler *a, const pamd_batch *b, void *st
 		}
 	}
 	p.notp_never_finite = a->notp_never_finite ? 1 : 0;
-	p.tables_symmetric = a->tables_symmetric ? 1 : 0;
 	p.primer_qthr = 22;
 	p.primer_err_t = a->tabs.score_err[22];
 	p.primer_inv_err_t = 1.0 / p.primer_err_t;

@@ -86,44 +86,16 @@ static_assert(Lay<true>::PIDX % 16 == 0 && Lay<true>::MC % 16 == 0 && Lay<true>:
 __device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) {
 	return (unsigned) __umul24(a, b);	// (this ROCm's __umul24 yields a SIGNED value: a plain >> on it is an arithmetic shift)
 }
-// DENSE (round 5): five waves per SIMD instead of four.  One 16-wave workgroup per CU is what 36 KB of tables + 7.6 KB per
-// wave allow; the short geometry's kernels of the scorers whose matrices are symmetric (every one but uparse's; rdp_mle has
-// three of them and stays as it was) instead run TWO workgroups of ten waves per CU: the two matrices staged as lower
-// triangles (2 x 9 KB instead of 2 x 17.7 KB: tri_index()), a 512-slot first k-mer table (5.6 KB per wave), and a kernel
-// compiled for 96 vector registers -- 2 x (18.4 + 3.6 + 54.8) KB = 153.5 of 160 KB.  -DFK_DENSE=0 builds the round-4 geometry (A/B).
-#ifndef FK_DENSE
-#define FK_DENSE 0
-#endif
-template <int ALGO, bool LONG>
-__device__ __host__ constexpr bool dense_geo() {
-	return FK_DENSE != 0 && !LONG && ALGO != PAMD_ALGO_UPARSE && ALGO != PAMD_ALGO_RDP_MLE;
-}
-#ifndef FK_OPAQUE_NARROW
-#define FK_OPAQUE_NARROW 0
-#endif
-#ifndef FK_DENSE_WPE
-#define FK_DENSE_WPE 6
-#endif
-#ifndef FK_DENSE_NW
-#define FK_DENSE_NW 10
-#endif
-constexpr int FK_DENSE_WAVES = FK_DENSE_NW;	// per workgroup, two workgroups per CU
-constexpr unsigned FK_TRI = PAMD_NQ * (PAMD_NQ + 1) / 2;	// entries of a lower triangle
-constexpr unsigned FK_DLT_A = PAMD_LT_A, FK_DLT_B = PAMD_LT_A + FK_TRI, FK_DLT_END = FK_DLT_B + FK_TRI;	// the dense table image (doubles): score, err, A, B
+// (Round 5 built a geometry of two ten-wave workgroups per CU -- the two matrices staged as lower triangles, a 512-slot first k-mer
+// table, 96 and then 80 vector registers -- and measured it: a SIMD's throughput is the same with 3, 4, 5 or 6 waves, the kernel is
+// bound by vector issue (profiles/r05_dense_geometry_ab.txt).  It shipped compiled out and was removed in
+// round 6; `git log -S FK_DENSE` has it.)
 template <int ALGO, bool LONG = false>
 __device__ __host__ constexpr int t1_bits() {
-	return (ALGO == PAMD_ALGO_RDP_MLE || dense_geo<ALGO, LONG>()) ? 9 : 10;	// (512 slots for every scorer in the 16-wave geometry: measured 2 % slower on config 1; for reads of at most 192 bases only, round 4: 1 % slower on config 4)
-}
-// entry (a, b) of a symmetric 47 x 47 matrix stored as its lower triangle: row max(a, b), column min(a, b)
-__device__ __forceinline__ unsigned tri_index(unsigned a, unsigned b) {
-	const unsigned hi = a > b ? a : b, lo = a > b ? b : a;
-	return (mul24(hi, hi + 1u) >> 1) + lo;
+	return ALGO == PAMD_ALGO_RDP_MLE ? 9 : 10;	// (512 slots for every scorer: measured 2 % slower on config 1; for reads of at most 192 bases only, round 4: 1 % slower on config 4)
 }
 // the index, in the staged table image, of entry (a, b) of the "match" (A) or "mismatch" (B) matrix
-template <bool DENSE>
 __device__ __forceinline__ unsigned mat_index(bool match, unsigned a, unsigned b) {
-	if (DENSE)
-		return (match ? FK_DLT_A : FK_DLT_B) + tri_index(a, b);
 	return (match ? (unsigned) PAMD_LT_A : (unsigned) PAMD_LT_B) + a * PAMD_NQ + b;
 }
 
@@ -232,6 +204,27 @@ __device__ __forceinline__ unsigned lshl_add(unsigned x, unsigned y) {
 __device__ __forceinline__ unsigned lds_read_u32(unsigned addr) {
 	return *reinterpret_cast<__attribute__((address_space(3))) const unsigned *>(addr);
 }
+__device__ __forceinline__ unsigned lds_read_u32_early(unsigned addr) {	// (volatile: see lds_read_u16_early)
+	return *reinterpret_cast<volatile __attribute__((address_space(3))) const unsigned *>(addr);
+}
+#ifndef FK_DEEP_BATCH
+#define FK_DEEP_BATCH 1
+#endif
+#ifndef FK_LAZY_FLAGS
+#define FK_LAZY_FLAGS 1
+#endif
+#ifndef FK_KARGS
+#define FK_KARGS 1
+#endif
+// FK_EPOCH (short geometry): the k-mer tables are cleared every 127th pair instead of every pair.  A table word is
+// epoch (7 bits) | k-mer (16) | position (9); a wave's epoch counts DOWN from 126, so the words of the pair at hand are smaller
+// than everything earlier pairs left behind: a stale word loses every ds_min (it is displaced like an empty slot's 0xFFFFFFFF, and
+// what is displaced is dropped: "live" is one compare against the epoch's upper limit, where it was one against EMPTY), and it
+// never reads as a match (its epoch bits differ).  After epoch 0, or after something else was laid over the tables, they are
+// cleared and the count starts over.
+#ifndef FK_EPOCH
+#define FK_EPOCH 1
+#endif
 
 // ---- stage one read: four bases per lane -------------------------------------------------------------------
 // Writes the row, its 2-bit codes and its N map to LDS; returns the B-cliff length (read length minus the trailing
@@ -943,14 +936,13 @@ __device__ __forceinline__ double score_share(const unsigned char *wb, const dou
 			const unsigned ef = lds_read_u16(lF + 2u * (unsigned) fi), er = lds_read_u16(lR + 2u * (unsigned) ri);
 			const unsigned a = ef & 0xFFu, b = er & 0xFFu, qa = ef >> 8;
 			const bool agree = (a & b) != 0;
-			constexpr bool DENSE = dense_geo<ALGO, std::is_same<L, Lay<true>>::value>();
 			if (ALGO == PAMD_ALGO_PEAR) {
 				// the second index is the FORWARD read's quality at the reverse index (algo_pear.c:52,54, sic); past the forward
 				// read the reference reads beyond the array: defined as quality 0 here
 				const unsigned qb = ri < flen ? lds_read_u16(lF + 2u * (unsigned) ri) >> 8 : 0u;
-				part += (a == 15u || b == 15u) ? nrb : lds_read_f64(lT + 8u * mat_index<DENSE>(agree, qa, qb));
+				part += (a == 15u || b == 15u) ? nrb : lds_read_f64(lT + 8u * mat_index(agree, qa, qb));
 			} else {
-				part += lds_read_f64(lT + 8u * mat_index<DENSE>(agree, qa, er >> 8)) - nn;
+				part += lds_read_f64(lT + 8u * mat_index(agree, qa, er >> 8)) - nn;
 			}
 		}
 	}
@@ -1348,8 +1340,8 @@ __device__ __forceinline__ void load_pair(Carry<LONG> &c, const PamdKernelParams
 // one level of the forward insert: the smaller of (slot, carry) stays in the slot, the larger one moves on
 // (EMPTY = nothing moves on).  The order of the words is irrelevant; ds_min only makes "who stays" independent of the
 // order in which lanes and instructions reach a slot, so no lane ever has to retry.
-__device__ __forceinline__ unsigned insert_level(unsigned *table, unsigned slot, unsigned carry) {
-	if (carry != EMPTY) {	// lanes with nothing to insert stay out of the LDS (they would all meet on one slot)
+__device__ __forceinline__ unsigned insert_level(unsigned *table, unsigned slot, unsigned carry, unsigned limit = EMPTY) {
+	if (carry < limit) {	// lanes with nothing to insert stay out of the LDS (they would all meet on one slot)
 		const unsigned old = atomicMin(&table[slot], carry);
 		carry = old > carry ? old : carry;
 	}
@@ -1393,6 +1385,31 @@ __device__ __forceinline__ void insert_all(const unsigned (&addr)[BPL], unsigned
 		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") FK_INS("%[w3]", "%[a3]", "%[c3]") FK_INS("%[w4]", "%[a4]", "%[c4]") "s_waitcnt lgkmcnt(0)"
 			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [w3] "+v"(was[3]), [w4] "+v"(was[4]), [sv] "=&s"(sv)
 			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [a3] "v"(addr[3]), [a4] "v"(addr[4]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [c3] "v"(carry[3]), [c4] "v"(carry[4])
+			     : "vcc", "scc", "memory");
+#pragma unroll
+	for (int j = 0; j < BPL; j++)
+		carry[j] = was[j] > carry[j] ? was[j] : carry[j];
+}
+#undef FK_INS
+// (FK_EPOCH: a word is live -- this pair's, not EMPTY, not a stale one just displaced -- when it lies below the epoch's upper limit)
+#define FK_INS(W, A, C) "v_cmp_gt_u32_e32 vcc, %[lim], " C "\n\ts_and_saveexec_b64 %[sv], vcc\n\tds_min_rtn_u32 " W ", " A ", " C "\n\ts_mov_b64 exec, %[sv]\n\t"
+template <int BPL>
+__device__ __forceinline__ void insert_all_live(const unsigned (&addr)[BPL], unsigned (&carry)[BPL], unsigned limit) {
+	unsigned was[BPL];
+#pragma unroll
+	for (int j = 0; j < BPL; j++)
+		was[j] = 0;
+	u64 sv;
+	static_assert(BPL == 3 || BPL == 4, "the short geometry's three or four words per lane");
+	if constexpr (BPL == 3)
+		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") "s_waitcnt lgkmcnt(0)"
+			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [sv] "=&s"(sv)
+			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [lim] "s"(limit)
+			     : "vcc", "scc", "memory");
+	else
+		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") FK_INS("%[w3]", "%[a3]", "%[c3]") "s_waitcnt lgkmcnt(0)"
+			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [w3] "+v"(was[3]), [sv] "=&s"(sv)
+			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [a3] "v"(addr[3]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [c3] "v"(carry[3]), [lim] "s"(limit)
 			     : "vcc", "scc", "memory");
 #pragma unroll
 	for (int j = 0; j < BPL; j++)
@@ -1445,12 +1462,22 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 #define DEBUG_DUMP(...)
 #endif
 
+// launch parameters every pair needs, read ONCE per wave into scalar registers (FK_KARGS): left as kernel arguments, the compiler
+// re-reads them from the argument segment inside the pair loop -- three of the five scalar loads per pair with their wait right
+// behind them (the counter is shared with the LDS reads that follow: the wait cannot be put off)
+struct HotArgs {
+	double qual_nn, pmatch, pmismatch, threshold;
+	u64 stride, capacity;
+	uint8_t *nt;
+	double *p;
+};
+
 // LONG: the geometry (Lay<LONG>).  PRIM (LONG only): primers (`-p` / `-q`, found by primer_quick) or trims are configured.
 // NARROW (short geometry only): reads of at most 192 bases seed three bases per lane, on windows of the code streams
 // POST (LONG only): `-a`, the primers are looked for in the merged sequence and cut off it (reference-order sums since round 5:
 // `quality` is the whole merge's, assembler.c:244 precedes the clipping, and comes from the group walk like any other row's)
 template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW, bool POST>
-__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, const unsigned char *places, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases, uint16_t *xs) {
+__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, const unsigned char *places, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases, uint16_t *xs, const HotArgs &H, bool &flags_dirty, unsigned &epoch) {
 	typedef Lay<LONG> L;
 	constexpr int BPL = NARROW ? 3 : L::BPL;
 	constexpr bool WINDOWS = BPL != 4;	// k-mers from unaligned words of the code streams (else from the neighbouring lanes' registers)
@@ -1469,7 +1496,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	bool slow = false;
 	const int minov = P.minoverlap;
 	constexpr int T1B = t1_bits<ALGO, LONG>();
-	constexpr bool DENSE = dense_geo<ALGO, LONG>();
+	constexpr bool EP = FK_EPOCH != 0 && !LONG;	// (the LONG geometry lays its primer scan and its merged row over the first table: cleared per pair as ever)
+	constexpr unsigned KSH = EP ? 9u : 16u, POS_END = EP ? 0x200u : 0x10000u;	// a table word is key << KSH | position; an entry of the k-mer looked for reads as its bare position, below POS_END
 	typedef Geo<LONG, T1B> G;
 	unsigned *const t1 = reinterpret_cast<unsigned *>(wb + L::T1), *const t2 = reinterpret_cast<unsigned *>(wb + G::T2);
 	unsigned *const t3 = reinterpret_cast<unsigned *>(wb + G::T3), *const t4 = reinterpret_cast<unsigned *>(wb + G::T4);
@@ -1599,20 +1627,26 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			// (the first two tables are whole kilobytes: straight-line stores, no loop counter; the last two, 384 bytes, only
 			// when the previous pair used them)
 			static_assert((G::T3 - L::T1) % 1024u == 0 && (G::WAVE_BYTES - G::T3) / 16u <= 64u, "whole rounds of 64 lanes x 16 bytes");
-			uint4 *h = reinterpret_cast<uint4 *>(wb + L::T1) + lane;
-			unsigned e = EMPTY;
-			asm volatile("" : "+v"(e));	// (made here: hoisted out of the pair loop the four registers of the constant are spilled and reloaded per pair)
-			const uint4 e4 = make_uint4(e, e, e, e);
+			const bool clear_now = !EP || epoch == 0u || deep_dirty;	// (EP: deep_dirty = something was laid over the tables)
+			if (clear_now) {
+				uint4 *h = reinterpret_cast<uint4 *>(wb + L::T1) + lane;
+				unsigned e = EMPTY;
+				asm volatile("" : "+v"(e));	// (made here: hoisted out of the pair loop the four registers of the constant are spilled and reloaded per pair)
+				const uint4 e4 = make_uint4(e, e, e, e);
 #pragma unroll
-			for (unsigned i = 0; i < (G::T3 - L::T1) / 1024u; i++)
-				h[64u * i] = e4;
-			if (deep_dirty && lane < (int) ((G::WAVE_BYTES - G::T3) / 16u))
-				reinterpret_cast<uint4 *>(wb + G::T3)[lane] = e4;
-			if (lane < (LONG ? 24 : 16)) {
+				for (unsigned i = 0; i < (G::T3 - L::T1) / 1024u; i++)
+					h[64u * i] = e4;
+				if ((EP || deep_dirty) && lane < (int) ((G::WAVE_BYTES - G::T3) / 16u))
+					reinterpret_cast<uint4 *>(wb + G::T3)[lane] = e4;
+			}
+			if (EP)
+				epoch = clear_now ? 126u : epoch - 1u;
+			if ((!FK_LAZY_FLAGS || flags_dirty) && lane < (LONG ? 24 : 16)) {	// (FK_LAZY_FLAGS: only a pair whose candidates went through the flag bytes leaves any set)
 				unsigned z = 0u;
 				asm volatile("" : "+v"(z));	// (likewise)
 				reinterpret_cast<uint4 *>(flags)[lane] = make_uint4(z, z, z, z);
 			}
+			flags_dirty = false;
 			deep_dirty = false;
 		}
 		wave_sync();
@@ -1651,14 +1685,33 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				nw = ((x2 >> 8) & 0xFFu) | (x1 & 0xFF00u) | ((x0 & 0xFF00u) << 8);
 			}
 			unsigned carry[BPL];
-#pragma unroll
-			for (int j = 0; j < BPL; j++) {
-				// the k-mer's eight codes are bits 2+2j .. 17+2j of w: shifted to the top half of the table word
-				const unsigned word = ((w << (14 - 2 * j)) & 0xFFFF0000u) | (unsigned) (BPL * lane + j);
-				carry[j] = (nw & (0x15555u << (2 * j))) == 0 ? word : EMPTY;
-			}
+			const unsigned limit = EP ? (epoch + 1u) << 25 : EMPTY;	// a word below it is live: this pair's (EP), not EMPTY
 			const unsigned l1 = lds_addr(t1), l2 = lds_addr(t2);
-			{
+			if constexpr (EP) {
+				unsigned key[BPL];
+#pragma unroll
+				for (int j = 0; j < BPL; j++) {
+					// the k-mer's eight codes are bits 2+2j .. 17+2j of w; the key is epoch | k-mer, the word key | position
+					key[j] = __builtin_amdgcn_alignbit(epoch, w << (14 - 2 * j), 16);
+					const unsigned word = (key[j] << 9) | (unsigned) (BPL * lane + j);
+					carry[j] = (nw & (0x15555u << (2 * j))) == 0 ? word : EMPTY;
+				}
+				unsigned addr[BPL];
+#pragma unroll
+				for (int j = 0; j < BPL; j++)
+					addr[j] = lshl_add<2>(mul24(key[j], HASH_C) >> (32 - T1B), l1);
+				insert_all_live<BPL>(addr, carry, limit);
+#pragma unroll
+				for (int j = 0; j < BPL; j++)
+					addr[j] = lshl_add<2>(__builtin_amdgcn_ubfe(mul24(carry[j] >> 9, HASH_C), 14, 8), l2);
+				insert_all_live<BPL>(addr, carry, limit);
+			} else {
+#pragma unroll
+				for (int j = 0; j < BPL; j++) {
+					// the k-mer's eight codes are bits 2+2j .. 17+2j of w: shifted to the top half of the table word
+					const unsigned word = ((w << (14 - 2 * j)) & 0xFFFF0000u) | (unsigned) (BPL * lane + j);
+					carry[j] = (nw & (0x15555u << (2 * j))) == 0 ? word : EMPTY;
+				}
 				unsigned addr[BPL];
 #pragma unroll
 				for (int j = 0; j < BPL; j++)
@@ -1674,21 +1727,21 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			for (int j = 0; j < BPL; j++) {
 				// (measured and not kept, round 4: all of a lane's words sent through the last two tables under one test, one
 				// round trip per level -- every pair that needs them for one word then pays the issue for four: -2.5 %)
-				if (ballot(carry[j] != EMPTY) != 0) {	// rare from here on: one or two words per pair
+				if (ballot(carry[j] < limit) != 0) {	// rare from here on: one or two words per pair
 					deep = true;
-					carry[j] = insert_level(t3, slot3(carry[j] >> 16), carry[j]);
-					carry[j] = insert_level(t4, slot4(carry[j] >> 16), carry[j]);
-					if (ballot(carry[j] != EMPTY) != 0) {
+					carry[j] = insert_level(t3, slot3(carry[j] >> KSH), carry[j], limit);
+					carry[j] = insert_level(t4, slot4(carry[j] >> KSH), carry[j], limit);
+					if (ballot(carry[j] < limit) != 0) {
 						// A word found no slot.  The words of one k-mer that did are always its smallest positions (a slot
 						// keeps its minimum), so a k-mer with two of them in the tables loses nothing the reference keeps
 						// (assembler.c:94-99 drops a third position as well): tandem repeats pass here.
-						const unsigned k = carry[j] >> 16, kk = carry[j] & 0xFFFF0000u;
-						const int kept = (int) ((t1[slot1<T1B>(k)] ^ kk) < 0x10000u) + (int) ((t2[slot2(k)] ^ kk) < 0x10000u) + (int) ((t3[slot3(k)] ^ kk) < 0x10000u) + (int) ((t4[slot4(k)] ^ kk) < 0x10000u);
-						lost |= ballot(carry[j] != EMPTY && kept < 2) != 0;
+						const unsigned k = carry[j] >> KSH, kk = carry[j] & ~(POS_END - 1u);
+						const int kept = (int) ((t1[slot1<T1B>(k)] ^ kk) < POS_END) + (int) ((t2[slot2(k)] ^ kk) < POS_END) + (int) ((t3[slot3(k)] ^ kk) < POS_END) + (int) ((t4[slot4(k)] ^ kk) < POS_END);
+						lost |= ballot(carry[j] < limit && kept < 2) != 0;
 					}
 				}
 			}
-			deep_dirty = deep;
+			deep_dirty = EP ? false : deep;
 			DEBUG_DUMP(P, wb, pair, lane, 0, uf, ur, (int) deep, (int) lost, (int) carry[0], (int) carry[1]);
 #ifdef PAMD_FK_DEBUG
 			if (deep)
@@ -1712,10 +1765,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		{
 			unsigned w, nw;	// base BPL*l + b at bits 2b..2b+1 of w, its N flag at bit 2b+1 of nw
 			if constexpr (WINDOWS) {
-				int ln = lane;
-				if constexpr (DENSE)
-					asm volatile("" : "+v"(ln));	// (the window's address is the same for every pair: hoisted out of the pair loop it is spilled at 80 registers, and its reload waits for the next pair's rows)
-				const int rb = 2 * BPL * ln;
+				const int rb = 2 * BPL * lane;
 				const unsigned *cw = reinterpret_cast<const unsigned *>(wb + L::RC) + (rb >> 5), *nwp = reinterpret_cast<const unsigned *>(wb + L::RN) + (rb >> 5);
 				const unsigned c0 = cw[0], c1 = cw[1], n0 = nwp[0], n1 = nwp[1];
 				w = __builtin_amdgcn_alignbit(c1, c0, (unsigned) rb & 31u);
@@ -1737,7 +1787,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			for (int j = 0; j < BPL; j++) {
 				xk[j] = br << (2 * j);	// this k-mer in the top half
 				ok[j] = (nw & (0x2AAAAu << (2 * j))) == 0;
-				const unsigned prod = mul24(xk[j] >> 16, HASH_C), kk = xk[j] & 0xFFFF0000u;
+				if constexpr (EP)
+					xk[j] = __builtin_amdgcn_alignbit(epoch, xk[j], 16);	// the key, epoch | k-mer: what this pair's words of the k-mer carry above their position
+				const unsigned prod = mul24(EP ? xk[j] : xk[j] >> 16, HASH_C), kk = EP ? xk[j] << 9 : xk[j] & 0xFFFF0000u;
 				const unsigned e1 = lds_read_u32(lshl_add<2>(prod >> (32 - T1B), l1)) ^ kk;
 				const unsigned e2 = lds_read_u32(lshl_add<2>(__builtin_amdgcn_ubfe(prod, 14, 8), l2)) ^ kk;
 				// an entry of this k-mer reads as its bare position (< 0x10000), anything else as >= 0x10000
@@ -1745,10 +1797,25 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				m2[j] = e1 < e2 ? e2 : e1;
 			}
 			if (deep) {	// wave-uniform: the last two tables hold something
+#if FK_DEEP_BATCH
+				// (all 2 BPL reads under way before the first is used: left to itself the compiler reads k-mer by k-mer, BPL exposed round trips)
+				unsigned r3[BPL], r4[BPL];
 #pragma unroll
 				for (int j = 0; j < BPL; j++) {
-					const unsigned kmer = xk[j] >> 16, kk = xk[j] & 0xFFFF0000u;
+					const unsigned kmer = EP ? xk[j] : xk[j] >> 16;
+					r3[j] = lds_read_u32_early(lshl_add<2>(slot3(kmer), lds_addr(t3)));
+					r4[j] = lds_read_u32_early(lshl_add<2>(slot4(kmer), lds_addr(t4)));
+				}
+#endif
+#pragma unroll
+				for (int j = 0; j < BPL; j++) {
+					const unsigned kmer = EP ? xk[j] : xk[j] >> 16, kk = EP ? xk[j] << 9 : xk[j] & 0xFFFF0000u;
+#if FK_DEEP_BATCH
+					const unsigned e3 = r3[j] ^ kk, e4 = r4[j] ^ kk;
+					(void) kmer;
+#else
 					const unsigned e3 = t3[slot3(kmer)] ^ kk, e4 = t4[slot4(kmer)] ^ kk;
+#endif
 					const unsigned l34 = e3 < e4 ? e3 : e4, h34 = e3 < e4 ? e4 : e3;
 					const unsigned hi = m1[j] < l34 ? l34 : m1[j];
 					m1[j] = m1[j] < l34 ? m1[j] : l34;
@@ -1762,7 +1829,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			for (int j = 0; j < BPL; j++) {
 				const unsigned idx = top - (unsigned) j - m1[j];	// no match: m1 >= 0x10000 wraps far beyond size
 				idx1[j] = ok[j] && idx < (unsigned) size ? idx : EMPTY;
-				second |= ballot(ok[j]) & ballot(m2[j] < 0xFFFFu);	// (an empty slot reads as 0xFFFF for the k-mer 0xFFFF.  Two compares and scalar logic: the ballot of a conjunction goes through a vector register)
+				second |= ballot(ok[j]) & ballot(m2[j] < (EP ? POS_END : 0xFFFFu));	// (an empty slot reads as 0xFFFF for the k-mer 0xFFFF.  Two compares and scalar logic: the ballot of a conjunction goes through a vector register)
 			}
 			const bool twice = second != 0;	// a k-mer that occurs twice in the forward read
 			// Nearly every pair's k-mers vote for one overlap, or for that and a stray one: settled here in registers, the
@@ -1800,6 +1867,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				}
 			}
 			if (__builtin_expect(!quick, 0)) {
+				flags_dirty = true;
 #pragma unroll
 				for (int j = 0; j < BPL; j++)
 					if (idx1[j] != EMPTY)
@@ -1858,7 +1926,11 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 #undef FK_TAKE
 		}
 		MARK("scan");
+#if FK_KARGS
+		best = H.qual_nn * (double) (flen + rlen);	// assembler.c:60
+#else
 		best = P.qual_nn * (double) (flen + rlen);	// assembler.c:60
+#endif
 		if (!counting_algo<ALGO>()) {
 			// ---- pear / rdp_mle: an overlap's score is a sum of per-base table values (algo_pear.c:32-59,
 			// algo_rdp_mle.c:43-74).  Lanes produce the terms.  Exact sums: lane 0 adds them in the reference's order.
@@ -1902,9 +1974,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 							// the second index is the FORWARD read's quality at the reverse index (algo_pear.c:52,54, sic);
 							// past the forward read the reference reads beyond the array: defined as quality 0 here
 							const unsigned qb = ri < flen ? lds_read_u16(lF + 2u * (unsigned) ri) >> 8 : 0u;
-							term = (a == 15u || b == 15u) ? nrb : lds_read_f64(lT + 8u * mat_index<DENSE>(agree, qa, qb));
+							term = (a == 15u || b == 15u) ? nrb : lds_read_f64(lT + 8u * mat_index(agree, qa, qb));
 						} else {
-							term = lds_read_f64(lT + 8u * mat_index<DENSE>(agree, qa, er >> 8)) - nn;
+							term = lds_read_f64(lT + 8u * mat_index(agree, qa, er >> 8)) - nn;
 						}
 						part += term;
 					}
@@ -1947,9 +2019,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 						unsigned entry;
 						if (ALGO == PAMD_ALGO_PEAR) {
 							const unsigned qb = ri < flen ? lds_read_u16(lF + 2u * (unsigned) ri) >> 8 : 0u;
-							entry = (a == 15u || b == 15u) ? (unsigned) PAMD_LT_C : mat_index<DENSE>(agree, qa, qb);	// (the slot behind the matrices holds -random_base: the kernel's prologue)
+							entry = (a == 15u || b == 15u) ? (unsigned) PAMD_LT_C : mat_index(agree, qa, qb);	// (the slot behind the matrices holds -random_base: the kernel's prologue)
 						} else {
-							entry = mat_index<DENSE>(agree, qa, er >> 8);
+							entry = mat_index(agree, qa, er >> 8);
 						}
 						sc[64 * r] = (uint16_t) (8u * entry);
 					}
@@ -1981,7 +2053,11 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x122, 0xF, 0xF, false);	// row_ror:2
 			packed += (unsigned) __builtin_amdgcn_mov_dpp((int) packed, 0x121, 0xF, 0xF, false);	// row_ror:1
 			const int unknowns = (int) (packed & 1023u), matches = (int) (packed >> 10);
+#if FK_KARGS
+			const double sc = count_score<ALGO, true>(H.qual_nn, H.pmatch, H.pmismatch, P.count_table, flen, rlen, myov, unknowns, matches, myov);
+#else
 			const double sc = count_score<ALGO, true>(P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.count_table, flen, rlen, myov, unknowns, matches, myov);
+#endif
 			if (__builtin_expect(ncand == 1, 1)) {	// (nine pairs in ten: one compare, no walk over the rows)
 				const double pr = lane_f64(sc, 0);
 				if (pr > best) {
@@ -2027,10 +2103,16 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		// (the launch parameters the allocation below needs, read together and FIRST: scalar loads and LDS reads share a counter,
 		// so a wait for these after the reads below would wait for those as well; and the compiler otherwise re-reads each
 		// from the kernel argument segment, one exposed scalar-memory round trip per use, in whichever branch it is used)
+#if FK_KARGS
+		const u64 k_stride = H.stride, k_capacity = H.capacity;
+		uint8_t *const k_nt = H.nt;
+		double *const k_p = H.p;
+#else
 		u64 k_stride = P.seq_stride, k_capacity = P.seq_capacity;
 		uint8_t *k_nt = P.seq_nt;
 		double *k_p = P.seq_p;
 		asm volatile("" : "+s"(k_stride), "+s"(k_capacity), "+s"(k_nt), "+s"(k_p));
+#endif
 		// The staged bases of all rounds of the merge (below), requested before the register rotation and the row's allocation:
 		// sixty scalar instructions that need nothing from the LDS run while the reads are under way.
 		// (NARROW: reads of at most 192 bases: a row spans six rounds, a forward base lies in the first three)
@@ -2155,10 +2237,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				const unsigned d = fq > rq ? fq - rq : rq - fq;
 				qi = PAMD_LT_SCORE + (match ? (fq > rq ? fq : rq) : (d < 2 ? 2 : d));
 			} else if (ALGO == PAMD_ALGO_RDP_MLE) {	// algo_rdp_mle.c:29-41
-				static_assert(ALGO != PAMD_ALGO_RDP_MLE || !DENSE, "rdp_mle's third matrix has no place in the dense image");
 				qi = match ? PAMD_LT_SCORE + (fq > rq ? fq : rq) : PAMD_LT_C + fq * PAMD_NQ + rq;
 			} else {	// algo_simple_bayes.c:68-75, algo_pear.c:61-68, algo_uparse.c:68-75, algo_stitch.c:59-67
-				qi = mat_index<DENSE>(match, fq, rq);
+				qi = mat_index(match, fq, rq);
 			}
 			if (cliff) {
 				asm volatile("; B-cliff");	// (keeps this a branch: as selects it would cost every pair six instructions a round)
@@ -2382,7 +2463,12 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			qsum = wave_sum_any_order(qacc);	// divided by len in finish64() ...
 			// ... unless the quotient could land within 1e-9 of the LOWQ threshold (tested without dividing): the general
 			// kernel then makes the three sums in reference order (assembler.c:171,226,236,244,334)
-			if (__builtin_expect(fabs(qsum - P.threshold * (double) (seqlen + 1)) <= 1e-9 * (double) (seqlen + 1), 0)) {
+#if FK_KARGS
+			const double k_thr = H.threshold;
+#else
+			const double k_thr = P.threshold;
+#endif
+			if (__builtin_expect(fabs(qsum - k_thr * (double) (seqlen + 1)) <= 1e-9 * (double) (seqlen + 1), 0)) {
 				note(P, 4, lane);
 				status = PAMD_ST_DEFER;	// (its row stays behind in the arena as a hole)
 				break;
@@ -2441,9 +2527,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 // PHRED: a min_phred module is loaded, the merge tracks the row's smallest log-p (plugin_min_phred.c:8-22)
 // (one 16-wave workgroup fills a CU's LDS: four waves per SIMD whatever the registers allow, so the compiler is told to
 // spend all 128 vector registers on scheduling instead of saving them for waves that cannot come -- 1 % on a 16 M-pair
-// launch, nothing measurable at 50 M.  DENSE: two workgroups of ten waves, five waves per SIMD, 96 registers.)
+// launch, nothing measurable at 50 M.)
 template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW, bool POST = false>
-__global__ __launch_bounds__((dense_geo<ALGO, LONG>() ? 64 * FK_DENSE_WAVES : 1024)) __attribute__((amdgpu_waves_per_eu((dense_geo<ALGO, LONG>() ? FK_DENSE_WPE : 4), (dense_geo<ALGO, LONG>() ? FK_DENSE_WPE : 4))))
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void pamd_fast_kernel(const PamdKernelParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	double *ltab = reinterpret_cast<double *>(lds);
@@ -2453,19 +2539,8 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 	const int wave = uni(tid >> 6);
 	const int nwaves = blockDim.x >> 6;
 
-	if constexpr (dense_geo<ALGO, LONG>()) {
-		// the two matrices as lower triangles (the host has checked that they are symmetric: pamd_launch_fast)
-		for (unsigned i = tid; i < PAMD_LT_A; i += blockDim.x)
-			ltab[i] = P.tables[i];
-		for (unsigned i = tid; i < 2u * PAMD_TAB; i += blockDim.x) {
-			const unsigned m = i >= PAMD_TAB ? 1u : 0u, e = i - m * PAMD_TAB, a = e / PAMD_NQ, b = e - a * PAMD_NQ;
-			if (a >= b)
-				ltab[(m ? FK_DLT_B : FK_DLT_A) + ((a * (a + 1u)) >> 1) + b] = P.tables[PAMD_LT_A + i];
-		}
-	} else {
-		for (unsigned i = tid; i < P.lds_table_doubles; i += blockDim.x)
-			ltab[i] = P.tables[i];
-	}
+	for (unsigned i = tid; i < P.lds_table_doubles; i += blockDim.x)
+		ltab[i] = P.tables[i];
 	for (unsigned i = tid; i < PAMD_NUM_COUNTERS; i += blockDim.x)
 		lctr[i] = 0;
 	unsigned char *wb = lds + P.lds_primer_off + (size_t) wave * Geo<LONG, t1_bits<ALGO, LONG>()>::WAVE_BYTES;	// (the per-wave regions start where the general kernel keeps its primers)
@@ -2524,6 +2599,12 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 	constexpr bool XSCORE = EXACT && !counting_algo<ALGO>();
 	constexpr int XG = fk_xg<XSCORE>();
 	bool deep_dirty = true;	// the first pair clears all four tables
+	bool flags_dirty = true;	// ... and the candidate flags
+	unsigned epoch = 0;	// FK_EPOCH: the epoch of the words the last pair wrote (0: the next pair clears the tables and starts over at 126)
+	HotArgs H = { P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.threshold, P.seq_stride, P.seq_capacity, P.seq_nt, P.seq_p };
+#if FK_KARGS
+	asm volatile("" : "+s"(H.qual_nn), "+s"(H.pmatch), "+s"(H.pmismatch), "+s"(H.threshold), "+s"(H.stride), "+s"(H.capacity), "+s"(H.nt), "+s"(H.p));
+#endif
 	Pend64 pd = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
 	auto take_group = [&](int base, int count) __attribute__((always_inline)) {
 		const GroupSums g = exact_sums_group<LONG, XSCORE, ALGO == PAMD_ALGO_RDP_MLE>(lds_addr(ltab), xs, pd.len_bo, pd.pid, pd.ro_st, pd.off_lo, pd.off_hi, P.qual_nn, base, count, lane);
@@ -2543,14 +2624,14 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 		load_pair<LONG, EXACT>(nxt, P, q, lane);
 		const int flen = uni(cur.flen_v), rlen = uni(cur.rlen_v);
 		int lane_now = lane;
-		if constexpr (LONG || ALGO == PAMD_ALGO_EA_UTIL || ALGO == PAMD_ALGO_STITCH || !counting_algo<ALGO>() || (dense_geo<ALGO, LONG>() && NARROW && FK_OPAQUE_NARROW)) {	// (the two table-scored counting scorers spill in the short geometry too; so do pear and rdp_mle, whose many-candidate scan is a call the hot path's registers have to survive)
+		if constexpr (LONG || ALGO == PAMD_ALGO_EA_UTIL || ALGO == PAMD_ALGO_STITCH || !counting_algo<ALGO>()) {	// (the two table-scored counting scorers spill in the short geometry too; so do pear and rdp_mle, whose many-candidate scan is a call the hot path's registers have to survive)
 			// The compiler hoists everything that depends on the lane number alone out of this loop -- multiples, shifts,
 			// LDS addresses -- and, out of registers, spills it: a reload from scratch memory then waits, vmcnt being one
 			// in-order queue, for whatever went before it, the rows just requested for the next pair among them.  Made opaque
 			// here, the lane number's derivatives are recomputed where they are used (an instruction or two each).
 			asm volatile("" : "+v"(lane_now));
 		}
-		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST>(P, ltab, places, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases, EXACT ? xs + (unsigned) xg * fk_xstride<LONG, XSCORE>() : nullptr);
+		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST>(P, ltab, places, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases, EXACT ? xs + (unsigned) xg * fk_xstride<LONG, XSCORE>() : nullptr, H, flags_dirty, epoch);
 		MARK("loop");
 		npend++;
 		if (EXACT && ++xg == XG) {	// sums in the reference's order: a group of pairs is complete
@@ -2621,34 +2702,23 @@ int pamd_fast_supports(const PamdKernelParams &p) {
 	return 0;
 }
 
-// does this launch run the DENSE geometry (dense_geo<ALGO, LONG>(), decided per instantiation above)?
-static bool fast_dense(const PamdKernelParams &p) {
-	return FK_DENSE != 0 && pamd_fast_supports(p) == PAMD_FAST_SHORT && p.algo != PAMD_ALGO_UPARSE && p.algo != PAMD_ALGO_RDP_MLE;
-}
-
 // The launch geometry of the lean kernel for this configuration on a device of `cu_count` CUs: workgroups, waves per workgroup,
-// LDS bytes per workgroup -- and the LDS offsets of `p` set to what its kernel expects (the dense geometry's table image is
-// smaller than the one the general kernel's offsets are made for).
+// LDS bytes per workgroup -- and the LDS offsets of `p` set to what its kernel expects.
 void pamd_fast_geometry(PamdKernelParams &p, int cu_count, size_t lds_limit, int max_waves, int *workgroups, int *waves_per_wg, size_t *lds_bytes) {
-	const bool rdp = p.algo == PAMD_ALGO_RDP_MLE, dense = fast_dense(p);
+	const bool rdp = p.algo == PAMD_ALGO_RDP_MLE;
 	const int cus = cu_count > 0 ? cu_count : 256;
 	if (p.algo == PAMD_ALGO_PEAR && p.exact_sums && pamd_fast_supports(p) != 0) {	// (the slot behind the matrices: -random_base, for the score's chain)
 		p.lds_table_doubles = PAMD_LT_C + 1;
 		p.lds_ctr_off = (p.lds_table_doubles * 8u + 15u) & ~15u;
 		p.lds_primer_off = (p.lds_ctr_off + PAMD_NUM_COUNTERS * 4u + 15u) & ~15u;
 	}
-	if (dense) {
-		p.lds_table_doubles = FK_DLT_END;
-		p.lds_ctr_off = (FK_DLT_END * 8u + 15u) & ~15u;
-		p.lds_primer_off = (p.lds_ctr_off + PAMD_NUM_COUNTERS * 4u + 15u) & ~15u;
-	}
-	const size_t wave = pamd_fast_supports(p) == PAMD_FAST_SHORT ? ((rdp || dense) ? Geo<false, 9>::WAVE_BYTES : Geo<false, 10>::WAVE_BYTES) : (rdp ? Geo<true, 9>::WAVE_BYTES : Geo<true, 10>::WAVE_BYTES);
-	int waves = dense ? FK_DENSE_WAVES : max_waves;
-	while (waves > 1 && (size_t) p.lds_primer_off + (size_t) waves * wave + 96u > lds_limit / (dense ? 2 : 1))	// (+ the 96 bytes of fk_phred_places)
+	const size_t wave = pamd_fast_supports(p) == PAMD_FAST_SHORT ? (rdp ? Geo<false, 9>::WAVE_BYTES : Geo<false, 10>::WAVE_BYTES) : (rdp ? Geo<true, 9>::WAVE_BYTES : Geo<true, 10>::WAVE_BYTES);
+	int waves = max_waves;
+	while (waves > 1 && (size_t) p.lds_primer_off + (size_t) waves * wave + 96u > lds_limit)	// (+ the 96 bytes of fk_phred_places)
 		waves--;
 	if (waves > max_waves)
 		waves = max_waves;
-	size_t wgs = (size_t) cus * (dense ? 2 : 1);
+	size_t wgs = (size_t) cus;
 	const size_t want = ((size_t) p.n_pairs + (size_t) waves - 1) / (size_t) waves;
 	if (wgs > want)
 		wgs = want;
@@ -2719,10 +2789,6 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 #undef FK_PICK4
 	if (pamd_fast_scratch_bytes(p, workgroups, waves_per_wg) > 0 && p.score_scratch == nullptr) {
 		pamd_set_error("the lean kernel's ordered sums need their scratch rows");
-		return PAMD_EINVAL;
-	}
-	if (fast_dense(p) && !p.tables_symmetric) {	// (every scorer's matrices but uparse's are: tests/test_oracle_cpu.py holds the generator to it)
-		pamd_set_error("the lean kernel's dense geometry needs symmetric matrices (algorithm %d)", p.algo);
 		return PAMD_EINVAL;
 	}
 	// pairs in blocks (see the kernel): when every wave has FK_BLOCKS_MIN blocks or more, so that the last, uneven round of blocks

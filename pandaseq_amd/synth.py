@@ -216,7 +216,11 @@ def generate_host(spec: SynthSpec, start: int, n: int):
         gpu = False
     if not gpu or n < 256:
         return generate_numpy(spec, start, n)
-    f, r, fl, rl = generate_device(spec, start, n)
+    from ._lib import PamdError
+    try:
+        f, r, fl, rl = generate_device(spec, start, n)
+    except PamdError:   # (a specification the device generator does not take, e.g. a read length of its own: the host generator's pairs)
+        return generate_numpy(spec, start, n)
     torch.cuda.synchronize()
     L = spec.read_len
     f, r = f.cpu().numpy(), r.cpu().numpy()

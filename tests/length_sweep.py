@@ -51,7 +51,7 @@ def run(rounds=10, first=0, n=1500, log=print):
                 done += 1
                 try:
                     asm.check_overflow()
-                    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=exact)
+                    compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=exact)
                     compare_counters(b.counters_dict(), o[3])
                 except AssertionError as e:
                     bad += 1

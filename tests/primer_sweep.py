@@ -63,7 +63,7 @@ def run(rounds=10, first=0, mode="plain", log=print, copies=1):
                     assert np.array_equal(d_nt.cpu().numpy().view(np.uint64), o_sums[1]), "row checksums (nt)"
                     assert np.array_equal(d_p.cpu().numpy().view(np.uint64), o_sums[2]), "row checksums (log-p)"
                 else:
-                    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=exact)
+                    compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=exact)
                 compare_counters(b.counters_dict(), o[3])
             except AssertionError as e:
                 bad += 1

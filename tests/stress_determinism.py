@@ -32,7 +32,7 @@ for cfg, algo in ((0, "simple_bayesian"), (1, "simple_bayesian"), (4, "simple_ba
             asm.assemble_device(b)
             torch.cuda.synchronize()
             try:
-                compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=exact)
+                compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=exact)
                 compare_counters(b.counters_dict(), o[3])
             except AssertionError as e:
                 bad += 1

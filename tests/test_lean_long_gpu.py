@@ -35,7 +35,7 @@ def sums(request):
 
 
 def _check(asm, b, o, n, max_deferred, exact=False):
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=exact)
+    compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=exact)
     compare_counters(b.counters_dict(), o[3])
     d = asm.last_deferred()
     assert 0 <= d <= max_deferred, f"the lean kernel must have served this launch (deferred {d} of {n})"
@@ -160,7 +160,7 @@ def test_primer_sweep_rounds_that_found_something(built, rnd, sums):
     asm.set_reverse_primer(c["rp"])
     b = _run(asm, c["fwd"], c["rev"], c["flen"], c["rlen"])
     o = _oracle(c["algo"], c["fwd"], c["rev"], c["flen"], c["rlen"], fprimer=c["fp"], rprimer=c["rp"], threshold=c["thr"])
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+    compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=sums == "exact")
     compare_counters(b.counters_dict(), o[3])
 
 
@@ -182,7 +182,7 @@ def test_primers_the_lean_kernel_does_not_serve(built):
         asm.set_primer_penalty(penalty)
         b = _run(asm, fwd, rev, flen, rlen)
         o = _oracle("pear", fwd, rev, flen, rlen, fprimer=primer, rprimer=rp, primer_penalty=penalty)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=False)
+        compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=False)
         compare_counters(b.counters_dict(), o[3])
         assert asm.last_deferred() == -1
 

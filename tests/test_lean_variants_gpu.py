@@ -119,5 +119,5 @@ def test_every_instantiation_of_the_lean_kernel(built, algo, geometry):
                 torch.cuda.synchronize()
                 asm.check_overflow()
                 assert asm.last_lean_variant() == (want if fast else "general"), (algo, geometry, exact, phred, asm.last_lean_variant())
-                compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), o_res, o_nt, o_p, exact_sums=exact)
+                compare_results(b.results_numpy(), *b.rows_numpy(), o_res, o_nt, o_p, exact_sums=exact)
                 compare_counters(b.counters_dict(), o_ctr)

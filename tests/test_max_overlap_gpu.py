@@ -40,7 +40,7 @@ def test_maximum_overlap_in_the_lean_kernel(built, algo, cfg, maxov, sums):
     torch.cuda.synchronize()
     asm.check_overflow()
     o = po.assemble_batch(po.make_config(algo, **kw), fwd, rev, flen, rlen)
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+    compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=sums == "exact")
     compare_counters(b.counters_dict(), o[3])
     assert asm.last_lean_variant() != "general", "the launch went to the general kernel whole"
     deferred = asm.last_deferred()

@@ -41,7 +41,7 @@ def test_synthetic_configs(built, algo, cfg, sums):
     asm.set_exact_sums(sums == "exact")
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
     o_res, o_nt, o_p, o_ctr = _oracle(algo, fwd, rev, flen, rlen)
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), o_res, o_nt, o_p, exact_sums=sums == "exact")
+    compare_results(b.results_numpy(), *b.rows_numpy(), o_res, o_nt, o_p, exact_sums=sums == "exact")
     compare_counters(b.counters_dict(), o_ctr)
 
 
@@ -128,7 +128,7 @@ def test_adversarial_strided(built, algo, sums):
     asm.set_exact_sums(sums == "exact")
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=512)
     o_res, o_nt, o_p, o_ctr = _oracle(algo, fwd, rev, flen, rlen)
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), o_res, o_nt, o_p, seq_stride=512, exact_sums=sums == "exact")
+    compare_results(b.results_numpy(), *b.rows_numpy(), o_res, o_nt, o_p, seq_stride=512, exact_sums=sums == "exact")
     compare_counters(b.counters_dict(), o_ctr)
 
 
@@ -179,7 +179,7 @@ def test_config2_primers_pear(built, sums):
     asm = _asm_for("pear", spec, primers=True, exact=sums == "exact")
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
     o = _oracle("pear", fwd, rev, flen, rlen, fprimer=synth.nt_codes(spec.fprimer), rprimer=synth.nt_codes(spec.rprimer, complement=True))
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+    compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=sums == "exact")
     compare_counters(b.counters_dict(), o[3])
     assert o[3]["ok"] > 4000 and (o[0]["fwd_offset"][o[0]["status"] == 0] >= 17).all()
 
@@ -194,7 +194,7 @@ def test_primers_all_algorithms_with_penalty(built, penalty):
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=608)
         o = _oracle(algo, fwd, rev, flen, rlen, fprimer=synth.nt_codes(spec.fprimer),
                     rprimer=synth.nt_codes(spec.rprimer, complement=True), primer_penalty=penalty)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], seq_stride=608)
+        compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], seq_stride=608)
         compare_counters(b.counters_dict(), o[3])
 
 
@@ -207,7 +207,7 @@ def test_config3_rdp_with_modules(built, sums):
         asm = _asm_for("rdp_mle", modules=[f"{k}:{v}" for k, v in mods], exact=sums == "exact")
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
         o = _oracle("rdp_mle", fwd, rev, flen, rlen, modules=mods)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+        compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=sums == "exact")
         compare_counters(b.counters_dict(), o[3])
         assert sum(o[3]["rejected"]) > 0
 
@@ -237,7 +237,7 @@ def test_min_phred_one_on_rows_with_both_kinds_of_low_p(built, algo, sums):
         asm = _asm_for(algo, modules=[f"{k}:{v}" for k, v in mods], exact=sums == "exact")
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
         o = _oracle(algo, fwd, rev, flen, rlen, modules=mods)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+        compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=sums == "exact")
         compare_counters(b.counters_dict(), o[3])
     s0, s1 = po.tables_np()["score"][:2]
     plain = _oracle(algo, fwd, rev, flen, rlen)
@@ -265,7 +265,7 @@ def test_assembler_settings(built, settings, sums):
         asm = _asm_for(algo, exact=sums == "exact", **settings)
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
         o = _oracle(algo, fwd, rev, flen, rlen, **okw)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+        compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=sums == "exact")
         compare_counters(b.counters_dict(), o[3])
 
 
@@ -288,7 +288,7 @@ def test_threshold_on_a_pairs_own_quality(built, sums):
             asm = _asm_for("simple_bayesian", exact=sums == "exact", threshold=t)
             b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
             o = _oracle("simple_bayesian", fwd, rev, flen, rlen, threshold=t)
-            compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+            compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=sums == "exact")
             compare_counters(b.counters_dict(), o[3])
             flips += int(o[0]["status"][k] != 0)
     assert 0 < flips < 12, "the chosen pairs must land on both sides of their threshold for the test to mean anything"
@@ -305,11 +305,11 @@ def test_algorithm_parameters(built):
     asm.set_algorithm("simple_bayesian", 0.2)
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
     o = _oracle("simple_bayesian", fwd, rev, flen, rlen, q=0.2)
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+    compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3])
     asm.set_algorithm("pear", 0.1)
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
     o = _oracle("pear", fwd, rev, flen, rlen, pear_random_base_log=math.log(0.1))
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+    compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3])
 
 
 def test_max_length_reads(built, sums):
@@ -321,7 +321,7 @@ def test_max_length_reads(built, sums):
         asm = _asm_for(algo, exact=sums == "exact")
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
         o = _oracle(algo, fwd, rev, flen, rlen)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+        compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=sums == "exact")
         compare_counters(b.counters_dict(), o[3])
         assert o[0]["seq_len"].max() > 850
 
@@ -349,7 +349,7 @@ def test_empty_and_tiny_batches(built):
         fwd, rev, flen, rlen = synth.generate_host(spec, 0, n)
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
         o = _oracle("simple_bayesian", fwd, rev, flen, rlen)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+        compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3])
     fwd, rev, flen, rlen = synth.generate_host(spec, 0, 4)
     res, nt, p, ctr = asm.assemble_host(fwd[:0], rev[:0], flen[:0], rlen[:0])
     assert len(res) == 0 and ctr["count"] == 0
@@ -516,7 +516,7 @@ def test_unequal_strides_and_api_validation(built):
     asm = pa.Assembler(0)
     b = _run(asm, fwd, rev2, flen, rlen2, seq_stride=0)
     o = _oracle("simple_bayesian", fwd, rev2, flen, rlen2)
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+    compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3])
     compare_counters(b.counters_dict(), o[3])
     # validation: stride not a multiple of 8
     bad = pa.upload_batch(np.ascontiguousarray(fwd[:, :252]), rev, np.minimum(flen, 250), rlen, device="cuda:0", seq_stride=0)
@@ -604,7 +604,7 @@ def test_primer_scan_when_exp_collapses_two_alignments(built):
     for exact in (True, False):
         asm = _asm_for("pear", spec, primers=True, exact=exact)
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=exact)
+        compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=exact)
         compare_counters(b.counters_dict(), o[3])
 
 
@@ -655,7 +655,7 @@ def test_primer_kernel_on_planted_primers(built, plen, penalty):
     asm.set_primer_penalty(penalty)
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
     o = _oracle("simple_bayesian", fwd, rev, flen, rlen, fprimer=fp, rprimer=rp, primer_penalty=penalty)
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+    compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3])
     compare_counters(b.counters_dict(), o[3])
     # (the reference finds "a primer" in nearly every read: offset.c:72 divides by index + 1, so late weak hits pass)
     ok = o[0]["status"] == 0
@@ -697,7 +697,7 @@ def test_pairs_that_scan_every_overlap(built, algo, sums):
     asm = _asm_for(algo, exact=sums == "exact")
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
     o = _oracle(algo, fwd, rev, flen, rlen)
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+    compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=sums == "exact")
     compare_counters(b.counters_dict(), o[3])
     assert (o[0]["slow"] != 0).sum() > n // 3, "the case must hold pairs that scan every overlap"
 
@@ -714,5 +714,5 @@ def test_batch_sizes_around_the_work_queues_grain(built, cfg, algo, sums):
         asm = _asm_for(algo, spec, primers=cfg == 2, exact=sums == "exact")
         b = _run(asm, fwd[:n], rev[:n], flen[:n], rlen[:n], seq_stride=0)
         o = _oracle(algo, fwd[:n], rev[:n], flen[:n], rlen[:n], **kw)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=sums == "exact")
+        compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=sums == "exact")
         compare_counters(b.counters_dict(), o[3])

@@ -40,7 +40,7 @@ def _pair(algo, fwd, rev, flen, rlen, exact=True, seq_stride=0, est_rel_tol=0.0,
         asm.add_module(f"{kind}:{val}")
     b = _run(asm, fwd, rev, flen, rlen, seq_stride)
     o_res, o_nt, o_p, o_ctr = po.assemble_batch(po.make_config(algo, primers_after=True, **kw), fwd, rev, flen, rlen)
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), o_res, o_nt, o_p,
+    compare_results(b.results_numpy(), *b.rows_numpy(), o_res, o_nt, o_p,
                     seq_stride=seq_stride or None, exact_sums=exact, est_rel_tol=est_rel_tol)
     compare_counters(b.counters_dict(), o_ctr)
     return o_res, o_ctr

@@ -45,7 +45,7 @@ def test_synthetic_configs(built, algo, cfg, sums):
     asm.set_exact_sums(sums == "exact")
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
     o_res, o_nt, o_p, o_ctr = _oracle(algo, fwd, rev, flen, rlen)
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), o_res, o_nt, o_p,
+    compare_results(b.results_numpy(), *b.rows_numpy(), o_res, o_nt, o_p,
                     exact_sums=sums == "exact", est_rel_tol=EST_TOL[algo])
     compare_counters(b.counters_dict(), o_ctr)
     if algo in ("uparse", "ea_util"):
@@ -64,7 +64,7 @@ def test_adversarial_strided(built, algo, sums):
     asm.set_exact_sums(sums == "exact")
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=512)
     o_res, o_nt, o_p, o_ctr = _oracle(algo, fwd, rev, flen, rlen)
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), o_res, o_nt, o_p, seq_stride=512,
+    compare_results(b.results_numpy(), *b.rows_numpy(), o_res, o_nt, o_p, seq_stride=512,
                     exact_sums=sums == "exact", est_rel_tol=EST_TOL[algo])
     compare_counters(b.counters_dict(), o_ctr)
 
@@ -79,7 +79,7 @@ def test_uparse_error_estimation_and_modules(built):
     asm.add_module("min_phred:3")
     b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
     o = _oracle("uparse", fwd, rev, flen, rlen, q=0.25, modules=[("min_phred", 3)])
-    compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3])
+    compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3])
     compare_counters(b.counters_dict(), o[3])
 
 
@@ -96,11 +96,11 @@ def test_long_reads_and_primers(built):
         asm.set_algorithm(algo)
         b = _run(asm, fwd, rev, flen, rlen, seq_stride=0)
         o = _oracle(algo, fwd, rev, flen, rlen)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], est_rel_tol=EST_TOL[algo])
+        compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], est_rel_tol=EST_TOL[algo])
         compare_counters(b.counters_dict(), o[3])
         asm.set_forward_primer(synth.nt_codes(spec2.fprimer))
         asm.set_reverse_primer(synth.nt_codes(spec2.rprimer, complement=True))
         b = _run(asm, f2, r2, fl2, rl2, seq_stride=0)
         o = _oracle(algo, f2, r2, fl2, rl2, fprimer=synth.nt_codes(spec2.fprimer), rprimer=synth.nt_codes(spec2.rprimer, complement=True))
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], est_rel_tol=EST_TOL[algo])
+        compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], est_rel_tol=EST_TOL[algo])
         compare_counters(b.counters_dict(), o[3])

@@ -47,7 +47,7 @@ def test_lean_kernel_matches_oracle_and_general(built, algo, exact):
             asm.set_fast_path(fast_path)
             b = _run(asm, fwd, rev, flen, rlen)
             asm.check_overflow()
-            compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), o_res, o_nt, o_p, exact_sums=exact, est_rel_tol=est_tol)
+            compare_results(b.results_numpy(), *b.rows_numpy(), o_res, o_nt, o_p, exact_sums=exact, est_rel_tol=est_tol)
             compare_counters(b.counters_dict(), o_ctr)
             if fast_path:
                 deferred = asm.last_deferred()
@@ -89,7 +89,7 @@ def test_lean_kernel_many_candidates_and_repeats(built):
         asm.set_algorithm(algo)
         asm.set_exact_sums(False)
         b = _run(asm, fwd, rev, flen, rlen)
-        compare_results(b.results_numpy(), b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy(), *o[:3], exact_sums=False, est_rel_tol=0.0)
+        compare_results(b.results_numpy(), *b.rows_numpy(), *o[:3], exact_sums=False, est_rel_tol=0.0)
         compare_counters(b.counters_dict(), o[3])
         assert o[3]["slow"] > n // 4
         assert asm.last_deferred() < n // 50, "these pairs are the lean kernel's own"
@@ -121,7 +121,7 @@ def test_arena_overflow_through_the_device_path(built):
             assert np.array_equal(res["status"][same], o_res["status"][same].astype(np.uint8))
             c = b.counters_dict()
             assert c["count"] == n and c["ok"] == int((res["status"] == 0).sum()) == int(c["overlapcount"].sum())
-            nt, p = b.seq_nt.cpu().numpy(), b.seq_p.cpu().numpy()
+            nt, p = *b.rows_numpy()
             for i in np.nonzero(res["status"] == 0)[0][::7]:
                 off, m = int(res["seq_offset"][i]), int(res["seq_len"][i])
                 assert off + m <= 600_000
