@@ -210,6 +210,9 @@ __device__ __forceinline__ unsigned lds_read_u32_early(unsigned addr) {	// (vola
 #ifndef FK_DEEP_BATCH
 #define FK_DEEP_BATCH 1
 #endif
+#ifndef FK_MAIN_BATCH
+#define FK_MAIN_BATCH 0
+#endif
 #ifndef FK_LAZY_FLAGS
 #define FK_LAZY_FLAGS 1
 #endif
@@ -1789,9 +1792,20 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				ok[j] = (nw & (0x2AAAAu << (2 * j))) == 0;
 				if constexpr (EP)
 					xk[j] = __builtin_amdgcn_alignbit(epoch, xk[j], 16);	// the key, epoch | k-mer: what this pair's words of the k-mer carry above their position
+#if FK_MAIN_BATCH
+				const unsigned prod = mul24(EP ? xk[j] : xk[j] >> 16, HASH_C);
+				m1[j] = lds_read_u32_early(lshl_add<2>(prod >> (32 - T1B), l1));
+				m2[j] = lds_read_u32_early(lshl_add<2>(__builtin_amdgcn_ubfe(prod, 14, 8), l2));
+			}
+#pragma unroll
+			for (int j = 0; j < BPL; j++) {
+				const unsigned kk = EP ? xk[j] << 9 : xk[j] & 0xFFFF0000u;
+				const unsigned e1 = m1[j] ^ kk, e2 = m2[j] ^ kk;
+#else
 				const unsigned prod = mul24(EP ? xk[j] : xk[j] >> 16, HASH_C), kk = EP ? xk[j] << 9 : xk[j] & 0xFFFF0000u;
 				const unsigned e1 = lds_read_u32(lshl_add<2>(prod >> (32 - T1B), l1)) ^ kk;
 				const unsigned e2 = lds_read_u32(lshl_add<2>(__builtin_amdgcn_ubfe(prod, 14, 8), l2)) ^ kk;
+#endif
 				// an entry of this k-mer reads as its bare position (< 0x10000), anything else as >= 0x10000
 				m1[j] = e1 < e2 ? e1 : e2;
 				m2[j] = e1 < e2 ? e2 : e1;

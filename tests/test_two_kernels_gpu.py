@@ -121,7 +121,7 @@ def test_arena_overflow_through_the_device_path(built):
             assert np.array_equal(res["status"][same], o_res["status"][same].astype(np.uint8))
             c = b.counters_dict()
             assert c["count"] == n and c["ok"] == int((res["status"] == 0).sum()) == int(c["overlapcount"].sum())
-            nt, p = *b.rows_numpy()
+            nt, p = b.rows_numpy()
             for i in np.nonzero(res["status"] == 0)[0][::7]:
                 off, m = int(res["seq_offset"][i]), int(res["seq_len"][i])
                 assert off + m <= 600_000
