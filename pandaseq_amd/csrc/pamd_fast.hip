@@ -210,9 +210,6 @@ __device__ __forceinline__ unsigned lds_read_u32_early(unsigned addr) {	// (vola
 #ifndef FK_DEEP_BATCH
 #define FK_DEEP_BATCH 1
 #endif
-#ifndef FK_MAIN_BATCH
-#define FK_MAIN_BATCH 0
-#endif
 #ifndef FK_LAZY_FLAGS
 #define FK_LAZY_FLAGS 1
 #endif
@@ -1785,27 +1782,17 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			bool ok[BPL];
 			const unsigned l1 = lds_addr(t1), l2 = lds_addr(t2);
 			// (the compiler issues these 2 BPL reads k-mer by k-mer, three LDS round trips; all eight under way before the first
-			// use -- bare reads, one wait -- measured: nothing on configs 1, 2 and 4, -1.5 % on config 3.  The other waves cover it.)
+			// use -- bare reads, one wait -- measured in round 4: nothing on configs 1, 2 and 4, -1.5 % on config 3; as volatile
+			// reads in round 6: +-0.5 % on configs 1 and 4.  The other waves cover it.)
 #pragma unroll
 			for (int j = 0; j < BPL; j++) {
 				xk[j] = br << (2 * j);	// this k-mer in the top half
 				ok[j] = (nw & (0x2AAAAu << (2 * j))) == 0;
 				if constexpr (EP)
 					xk[j] = __builtin_amdgcn_alignbit(epoch, xk[j], 16);	// the key, epoch | k-mer: what this pair's words of the k-mer carry above their position
-#if FK_MAIN_BATCH
-				const unsigned prod = mul24(EP ? xk[j] : xk[j] >> 16, HASH_C);
-				m1[j] = lds_read_u32_early(lshl_add<2>(prod >> (32 - T1B), l1));
-				m2[j] = lds_read_u32_early(lshl_add<2>(__builtin_amdgcn_ubfe(prod, 14, 8), l2));
-			}
-#pragma unroll
-			for (int j = 0; j < BPL; j++) {
-				const unsigned kk = EP ? xk[j] << 9 : xk[j] & 0xFFFF0000u;
-				const unsigned e1 = m1[j] ^ kk, e2 = m2[j] ^ kk;
-#else
 				const unsigned prod = mul24(EP ? xk[j] : xk[j] >> 16, HASH_C), kk = EP ? xk[j] << 9 : xk[j] & 0xFFFF0000u;
 				const unsigned e1 = lds_read_u32(lshl_add<2>(prod >> (32 - T1B), l1)) ^ kk;
 				const unsigned e2 = lds_read_u32(lshl_add<2>(__builtin_amdgcn_ubfe(prod, 14, 8), l2)) ^ kk;
-#endif
 				// an entry of this k-mer reads as its bare position (< 0x10000), anything else as >= 0x10000
 				m1[j] = e1 < e2 ? e1 : e2;
 				m2[j] = e1 < e2 ? e2 : e1;

@@ -72,12 +72,12 @@ def main():
             if best is None or dt < best["process_seconds"]:
                 best = runs[-1]
         out_bytes = os.path.getsize(po) if not args.sink else None
-    d = {"what": "tests/c/pamd_pipe.c = pamd_pipe_run(), file -> file (FASTQ x 2 -> FASTA) on %s; `pairs_per_s`: process start to exit (library load, device start-up, "
+    d = {"what": "tests/c/pamd_pipe.c = pamd_pipe_run() -- pamd_pipe_run_multi() over the devices of PAMD_PIPE_DEVICES when that is set --, file -> file (FASTQ x 2 -> FASTA) on %s; `pairs_per_s`: process start to exit (library load, device start-up, "
                  "allocation of the pinned blocks and thread start included); `pump_pairs_per_s`: first block read to last byte written" % args.dir,
          "config": args.config, "pairs": n, "pairs_per_chunk": args.chunk, "seconds": best["process_seconds"], "pairs_per_s": n / best["process_seconds"],
          "pump_seconds": best["pump_seconds"], "pump_pairs_per_s": n / best["pump_seconds"], "setup_seconds": best["setup_seconds"],
          "input_bytes": in_bytes, "output_bytes": out_bytes, "input_GBps": in_bytes / best["process_seconds"] / 1e9, "pump_input_GBps": in_bytes / best["pump_seconds"] / 1e9,
-         "pump_output_GBps": out_bytes / best["pump_seconds"] / 1e9 if out_bytes else None, "sink": args.sink, "gzip_inputs": bool(args.gzip), "reader_threads_per_file": int(os.environ.get("PAMD_PIPE_READERS", 3)), "writer_threads": int(os.environ.get("PAMD_PIPE_WRITERS", 1)), "runs": runs}
+         "pump_output_GBps": out_bytes / best["pump_seconds"] / 1e9 if out_bytes else None, "sink": args.sink, "devices": os.environ.get("PAMD_PIPE_DEVICES", "(pamd_pipe_run on device 0)"), "gzip_inputs": bool(args.gzip), "reader_threads_per_file": int(os.environ.get("PAMD_PIPE_READERS", 3)), "writer_threads": int(os.environ.get("PAMD_PIPE_WRITERS", 1)), "runs": runs}
     print(json.dumps(d))
     if args.out:
         with open(args.out, "w") as fh:

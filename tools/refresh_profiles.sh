@@ -43,6 +43,8 @@ traffic 2 fast 20000000 _after
 bash tools/pmc_fk.sh 8000000 2 > "$OUT/pmc_config2_after_fast.txt" 2>&1
 unset PAMD_PRIMERS_AFTER
 for c in 1 2 3 4; do bash tools/pmc_fk.sh 8000000 $c > "$OUT/pmc_config${c}_fast.txt" 2>&1; done
+# what one SIMD issues per cycle, by instruction class and waves per SIMD (tools/probe/valu_issue.hip; build it before the trip)
+[ -x tools/probe/valu_issue ] && timeout 400 tools/probe/valu_issue 2000 > "$OUT/valu_issue.txt" 2>&1
 # the per-phase ablation wants six more builds of the library: make them BEFORE going to the GPU box (bash tools/fk_phases.sh build);
 # built there only if they did not travel
 ls "$ROOT"/pandaseq_amd/libpandaseq_amd_fkstop5.so > /dev/null 2>&1 || bash tools/fk_phases.sh build > "$OUT/phases_build.log" 2>&1
@@ -58,6 +60,8 @@ python3 bench.py --config 3 --min-phred 3 --no-cpu --no-e2e --steps 3 --warmup 1
 python3 tools/pipeline_pcie.py --out "$OUT/pipeline_pcie.json" > "$OUT/pipeline_pcie.log" 2>&1
 python3 tools/pipe_file_rate.py --pairs 64000000 --reps 2 --out "$OUT/pipe_file_rate.json" > "$OUT/pipe_file_rate.log" 2>&1
 python3 tools/pipe_file_rate.py --pairs 64000000 --reps 2 --sink /dev/null --out "$OUT/pipe_null_rate.json" > "$OUT/pipe_null_rate.log" 2>&1
+# the same run dealt to two workers on this box's one GPU (pamd_pipe_run_multi: chunk boundaries by counting lines on the host; both share one PCIe link)
+PAMD_PIPE_DEVICES=0,0 python3 tools/pipe_file_rate.py --pairs 64000000 --reps 2 --sink /dev/null --out "$OUT/pipe_null_rate_multi.json" > "$OUT/pipe_null_rate_multi.log" 2>&1
 python3 tools/pipe_file_rate.py --pairs 8000000 --reps 2 --gzip --sink /dev/null --out "$OUT/pipe_gzip_rate.json" > "$OUT/pipe_gzip_rate.log" 2>&1
 python3 bench.py --io --no-e2e --cpu-seconds 0 --steps 3 --warmup 1 2> /dev/null | tail -1 | python3 -c "import json,sys; json.dump(json.load(sys.stdin)['io'], open(sys.argv[1], 'w'), indent=1)" "$OUT/io_bench.json"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_io" -o t -- python3 "$ROOT/tools/bench_io.py" --pairs 4000000 > "$OUT/prof_io.log" 2>&1)
