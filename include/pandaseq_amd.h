@@ -187,9 +187,14 @@ long long pamd_last_deferred(pamd_assembler *a);
 /* which instantiation of the lean kernel served the most recent launch (a probe for tests and profiles; DESIGN.md 3.1, docs/NOTEBOOK.md 3.1-3.1e):
  * 0 = none (the general kernel took the launch whole); else PAMD_LEAN_SHORT (reads of at most 256 bases), PAMD_LEAN_LONG (at
  * most 320), PAMD_LEAN_PRIMERS (the same with `-p` / `-q` primers or trims found inside it) or PAMD_LEAN_AFTER (`-a`), plus
- * PAMD_LEAN_NARROW when reads of at most 192 bases were seeded three bases per lane */
-enum { PAMD_LEAN_SHORT = 1, PAMD_LEAN_LONG = 2, PAMD_LEAN_PRIMERS = 3, PAMD_LEAN_AFTER = 4, PAMD_LEAN_NARROW = 0x100 };
+ * PAMD_LEAN_NARROW when reads of at most 192 bases were seeded three bases per lane, | PAMD_LEAN_DUAL when reads of at most 160
+ * bases were assembled two pairs per wavefront (a counting scorer, any-order sums, no min_phred module, no maximum overlap) */
+enum { PAMD_LEAN_SHORT = 1, PAMD_LEAN_LONG = 2, PAMD_LEAN_PRIMERS = 3, PAMD_LEAN_AFTER = 4, PAMD_LEAN_NARROW = 0x100, PAMD_LEAN_DUAL = 0x200 };
 int pamd_last_lean_variant(pamd_assembler *a);
+/* Two pairs per wavefront for reads of at most 160 bases (pamd_fast_dual.h).  OFF by default: the geometry is parity-green and
+ * measured 22 % slower than a pair per wave on BASELINE's 2 x 150 configuration; results do not depend on
+ * it.  Tests run both geometries on the same pairs through this switch. */
+int pamd_set_two_pairs_per_wave(pamd_assembler *a, int enable);
 
 /* The probability tables this library computes (host side; works without a GPU).
  * Order: qual_nn, qual_score[47], qual_score_err[47], then eight 47x47 row-major matrices:

@@ -69,7 +69,7 @@ SYMBOLS = [
     "pamd_set_primer_penalty", "pamd_set_primers_after", "pamd_add_module_min_phred", "pamd_add_module_min_overlapbits",
     "pamd_clear_modules", "pamd_set_exact_sums", "pamd_tables_get", "pamd_assemble_device", "pamd_assemble_host",
     "pamd_last_kernel_ms", "pamd_last_launch_info", "pamd_synth_generate", "pamd_debug_phase_cycles",
-    "pamd_assemble_status", "pamd_set_log_threshold", "pamd_set_fast_path", "pamd_last_deferred", "pamd_last_lean_variant", "pamd_assemble_device_range", "pamd_encode_rows_device", "pamd_table_image",
+    "pamd_assemble_status", "pamd_set_log_threshold", "pamd_set_fast_path", "pamd_last_deferred", "pamd_last_lean_variant", "pamd_set_two_pairs_per_wave", "pamd_assemble_device_range", "pamd_encode_rows_device", "pamd_table_image",
 ]
 
 

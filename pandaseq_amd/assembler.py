@@ -233,7 +233,11 @@ class Assembler:
     def last_lean_variant(self) -> str:
         """Which instantiation of the lean kernel served the last launch: general (none), short, short+narrow, long, primers, after."""
         v = int(lib().pamd_last_lean_variant(self._h))
-        return self.LEAN_NAMES[v & 0xFF] + ("+narrow" if v & 0x100 else "")
+        return self.LEAN_NAMES[v & 0xFF] + ("+narrow" if v & 0x100 else "") + ("+dual" if v & 0x200 else "")
+
+    def set_two_pairs_per_wave(self, enable: bool):
+        """Reads of at most 160 bases are assembled two pairs per wavefront where the configuration allows (default OFF: measured slower)."""
+        check(lib().pamd_set_two_pairs_per_wave(self._h, 1 if enable else 0))
 
     def check_overflow(self):
         """After synchronising: raise if pairs of the last launch did not fit in the output arena

@@ -65,6 +65,8 @@ struct pamd_assembler {
 	int exact_sums = 1;
 	int post_primers = 0;
 	int fast_path = 1;		// ordinary pairs go through the lean kernel when the configuration allows (pamd_fast.hip)
+	int two_pairs = 0;		// ... two pairs per wave where reads are short (pamd_fast_dual.h): built, parity-green and 22 % SLOWER than a pair per wave
+					// on config 4 (profiles/r06_two_pairs_per_wave_ab.txt): off unless pamd_set_two_pairs_per_wave() or PAMD_DUAL=1 asks for it
 	double *d_count_table = nullptr;	// ea_util / stitch: every value an overlap's score can take (PamdKernelParams::count_table) ...
 	int count_table_algo = -1;	// ... built for this scorer
 	uint32_t *d_primer_off = nullptr;	// `-p` / `-q`: the primer kernel's word per pair ...
@@ -350,6 +352,13 @@ int pamd_set_exact_sums(pamd_assembler *a, int exact) {
 	return PAMD_OK;
 }
 
+int pamd_set_two_pairs_per_wave(pamd_assembler *a, int enable) {
+	if (a == nullptr)
+		return PAMD_EINVAL;
+	a->two_pairs = enable ? 1 : 0;
+	return PAMD_OK;
+}
+
 int pamd_set_fast_path(pamd_assembler *a, int enable) {
 	if (a == nullptr)
 		return PAMD_EINVAL;
@@ -578,6 +587,7 @@ static int assemble_device_impl(pamd_assembler *a, const pamd_batch *b, void *st
 	p.sb_pmismatch = a->algo == PAMD_ALGO_UPARSE ? a->up_pmismatch : a->sb_pmismatch;
 	p.pear_random_base = a->pear_random_base;
 	p.exact_sums = a->exact_sums;
+	p.two_pairs = (a->two_pairs || (getenv("PAMD_DUAL") && getenv("PAMD_DUAL")[0] == '1')) ? 1 : 0;	// (the environment: measurements only)
 	if (a->algo == PAMD_ALGO_PEAR || a->algo == PAMD_ALGO_RDP_MLE) {
 		// upper bounds of one term of an overlap's score (PamdKernelParams::many_*): algo_pear.c:47-55 adds -random_base
 		// for an N and a table entry otherwise, algo_rdp_mle.c:60-70 a table entry minus qual_nn
@@ -797,7 +807,7 @@ static int assemble_device_impl(pamd_assembler *a, const pamd_batch *b, void *st
 		}
 	}
 	a->last_two_kernels = two;
-	a->last_variant = two ? (variant | ((variant == PAMD_FAST_SHORT && smax <= 192) ? PAMD_LEAN_NARROW : 0)) : 0;
+	a->last_variant = two ? (variant | ((variant == PAMD_FAST_SHORT && smax <= 192) ? PAMD_LEAN_NARROW : 0) | (pamd_fast_dual(p) ? PAMD_LEAN_DUAL : 0)) : 0;
 	rc = pamd_launch_assemble(p, wgs, waves, lds_bytes, stream);
 	if (rc != PAMD_OK)
 		return rc;

@@ -2525,6 +2525,10 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	}
 }
 
+#ifndef FK_NO_DUAL	/* (tests that only look at the single-pair kernels' ISA compile without the dual geometry) */
+#include "pamd_fast_dual.h"
+#endif
+
 // PHRED: a min_phred module is loaded, the merge tracks the row's smallest log-p (plugin_min_phred.c:8-22)
 // (one 16-wave workgroup fills a CU's LDS: four waves per SIMD whatever the registers allow, so the compiler is told to
 // spend all 128 vector registers on scheduling instead of saving them for waves that cannot come -- 1 % on a 16 M-pair
@@ -2703,6 +2707,20 @@ int pamd_fast_supports(const PamdKernelParams &p) {
 	return 0;
 }
 
+// Two pairs per wave (pamd_fast_dual.h): reads of at most 160 bases, a counting scorer, any-order sums, no min_phred module, no
+// configured maximum overlap (and the short geometry to begin with: no primers, no trims)
+bool pamd_fast_dual(const PamdKernelParams &p) {
+#ifdef FK_NO_DUAL
+	return false;
+#else
+	if (!p.two_pairs || pamd_fast_supports(p) != PAMD_FAST_SHORT || p.smax > (uint32_t) dual::D_MAXLEN)
+		return false;
+	if (p.algo == PAMD_ALGO_PEAR || p.algo == PAMD_ALGO_RDP_MLE || p.exact_sums || p.has_min_phred || p.maxoverlap != 0)
+		return false;
+	return true;
+#endif
+}
+
 // The launch geometry of the lean kernel for this configuration on a device of `cu_count` CUs: workgroups, waves per workgroup,
 // LDS bytes per workgroup -- and the LDS offsets of `p` set to what its kernel expects.
 void pamd_fast_geometry(PamdKernelParams &p, int cu_count, size_t lds_limit, int max_waves, int *workgroups, int *waves_per_wg, size_t *lds_bytes) {
@@ -2751,6 +2769,32 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 						   : variant == PAMD_FAST_SHORT ? (p.exact_sums ? FK_PICK3(A, PH, true) : FK_PICK3(A, PH, false)) \
 										: (p.exact_sums ? FK_PICK4(A, PH, true) : FK_PICK4(A, PH, false)))
 #define FK_PICK(A) (p.has_min_phred ? FK_PICK2(A, true) : FK_PICK2(A, false))
+#ifndef FK_NO_DUAL
+	if (pamd_fast_dual(p)) {
+		switch (p.algo) {
+		case PAMD_ALGO_SIMPLE_BAYES:
+			kern = pamd_fast2_kernel<PAMD_ALGO_SIMPLE_BAYES>;
+			break;
+#ifndef FK_DEV_ONE
+		case PAMD_ALGO_UPARSE:
+			kern = pamd_fast2_kernel<PAMD_ALGO_UPARSE>;
+			break;
+		case PAMD_ALGO_FLASH:
+			kern = pamd_fast2_kernel<PAMD_ALGO_FLASH>;
+			break;
+		case PAMD_ALGO_EA_UTIL:
+			kern = pamd_fast2_kernel<PAMD_ALGO_EA_UTIL>;
+			break;
+		case PAMD_ALGO_STITCH:
+			kern = pamd_fast2_kernel<PAMD_ALGO_STITCH>;
+			break;
+#endif
+		default:
+			break;
+		}
+	}
+#endif
+	if (kern == nullptr) {
 #ifdef FK_DEV_ONE	/* development: one instantiation family, for quick compiles */
 #ifndef FK_DEV_EXACT
 #define FK_DEV_EXACT false
@@ -2784,6 +2828,7 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 		return PAMD_EINVAL;
 	}
 #endif	// FK_DEV_ONE
+	}
 #undef FK_PICK
 #undef FK_PICK2
 #undef FK_PICK3

@@ -121,3 +121,62 @@ def test_every_instantiation_of_the_lean_kernel(built, algo, geometry):
                 assert asm.last_lean_variant() == (want if fast else "general"), (algo, geometry, exact, phred, asm.last_lean_variant())
                 compare_results(b.results_numpy(), *b.rows_numpy(), o_res, o_nt, o_p, exact_sums=exact)
                 compare_counters(b.counters_dict(), o_ctr)
+
+
+@pytest.mark.parametrize("algo", ["simple_bayesian", "uparse", "flash", "ea_util", "stitch"])
+def test_two_pairs_per_wave(built, algo):
+    """The lean kernel's geometry for short reads, two pairs per wavefront (pamd_fast_dual.h; off by default: it is parity-green
+    and measured slower): on 2 x 150 pairs of configs 0 and 4, on adversarial pairs (Ns, IUPAC codes, nt 0,
+    qualities outside 0..46, quality-2 tails, ragged and too-short reads: the pairs a pass does not settle are assembled right
+    behind it by fast_pair()), on tandem repeats and unrelated reads, on an odd number of pairs and on one pair -- every record,
+    merged base, log-p and counter equal to the oracle's, and to a pair per wave."""
+    import torch
+    import pandaseq_amd as pa
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import adversarial_pairs, compare_counters, compare_results
+    spec4 = synth.config_spec(4)
+    cases = []
+    for cfg, n in ((0, 3000), (4, 2999), (4, 1)):
+        cases.append(synth.generate_host(synth.config_spec(cfg), 777, n))
+    cases.append(adversarial_pairs(spec4, 2500, seed=91))
+    f, r, fl, rl = synth.generate_host(spec4, 5000, 1800)
+    rng = np.random.default_rng(17)
+    L = spec4.read_len
+    for i in range(0, 1800, 3):     # tandem repeats of every unit length (k-mers that occur dozens of times in both pairs of a pass)
+        unit = rng.choice(np.array([1, 2, 4, 8], np.uint8), size=int(rng.integers(1, 14)))
+        rep = np.tile(unit, L // len(unit) + 2)
+        off = int(rng.integers(0, len(unit)))
+        f[i, :L, 0] = rep[:L]
+        r[i, :L, 0] = rep[off:off + L]
+    for i in range(1, 1800, 3):     # unrelated reads: no vote at all, every overlap a candidate
+        r[i, :L, 0] = rng.choice(np.array([1, 2, 4, 8], np.uint8), size=L)
+    cases.append((f, r, fl, rl))
+    for fwd, rev, flen, rlen in cases:
+        n = len(flen)
+        o_res, o_nt, o_p, o_ctr = po.assemble_batch(po.make_config(algo), fwd, rev, flen, rlen)
+        for dual in (True, False):
+            asm = pa.Assembler(0)
+            asm.set_algorithm(algo)
+            asm.set_exact_sums(False)
+            asm.set_two_pairs_per_wave(dual)
+            b = pa.upload_batch(fwd, rev, flen, rlen, device="cuda:0", seq_stride=0, capacity=n * 640 + (1 << 25))
+            asm.assemble_device(b)
+            torch.cuda.synchronize()
+            asm.check_overflow()
+            assert asm.last_lean_variant() == ("short+narrow+dual" if dual else "short+narrow"), asm.last_lean_variant()
+            compare_results(b.results_numpy(), *b.rows_numpy(), o_res, o_nt, o_p, exact_sums=False)
+            compare_counters(b.counters_dict(), o_ctr)
+    # what the geometry does not serve stays with a pair per wave: reference-order sums, a min_phred module, a maximum overlap, pear
+    fwd, rev, flen, rlen = cases[1]
+    for tweak in (lambda a: a.set_exact_sums(True), lambda a: a.add_module("min_phred:2"), lambda a: a.set_maximum_overlap(120), lambda a: a.set_algorithm("pear")):
+        asm = pa.Assembler(0)
+        asm.set_algorithm(algo)
+        asm.set_exact_sums(False)
+        asm.set_two_pairs_per_wave(True)
+        tweak(asm)
+        b = pa.upload_batch(fwd, rev, flen, rlen, device="cuda:0", seq_stride=0, capacity=len(flen) * 640 + (1 << 25))
+        asm.assemble_device(b)
+        torch.cuda.synchronize()
+        assert "dual" not in asm.last_lean_variant() and asm.last_lean_variant() != "general"

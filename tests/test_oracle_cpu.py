@@ -409,7 +409,7 @@ def test_the_bench_kernels_do_not_spill(built, tmp_path):
     src = os.path.join(ROOT, "pandaseq_amd", "csrc", "pamd_fast.hip")
     flags = subprocess.check_output(["make", "-s", "-C", os.path.dirname(src), "fast-flags"], text=True).split()
     assert "-ffp-contract=off" in flags
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + flags + ["-DPAMD_MARK", "-x", "hip", src, "-S",     # (PAMD_MARK: phase names as ISA comments)
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + flags + ["-DPAMD_MARK", "-DFK_NO_DUAL", "-x", "hip", src, "-S",     # (PAMD_MARK: phase names as ISA comments)
                           "--cuda-device-only", "-o", str(tmp_path / "fast.s"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     usage = {}
