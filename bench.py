@@ -255,7 +255,7 @@ def main():
     # (one file per measured workload: a scorer override, `-a` or another min_phred is a different kernel and gets no other's figure)
     variant = (f"_{args.algo}" if args.algo else "") + ("_after" if args.primers_after else "") + (f"_minphred{args.min_phred}" if cfg_index == 3 and args.min_phred != 2 else "")
     tname = tpath = None
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         cand = f"{rnd}_traffic_config{cfg_index}{variant}_{args.sums}.json"
         if os.path.exists(os.path.join(ROOT, "profiles", cand)):
             tname, tpath = cand, os.path.join(ROOT, "profiles", cand)

@@ -2279,7 +2279,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			for (int k = 0; k < N; k++) {
 				if (k > 1 && 64 * (R0 + k) >= seqlen)
 					break;
-				lds_write_u8(nN + 64u * (R0 + k), ntv[k]);
+				lds_write_u8(nN + 64u * (R0 + k), ntv[k]);	// (measured and not kept, round 6: the base stored to HBM from here, a byte per lane, no staging and no round trip before the row leaves: -0.8 % config 1, -1 % config 4)
 				if constexpr (POST) {
 					// (the row leaves once the primers are off it: until then it is its table indices, beside the nt bytes)
 					*reinterpret_cast<__attribute__((address_space(3))) uint16_t *>(lN + (L::PIDX - L::NT) + 2u * (unsigned) (64 * (R0 + k) + lane)) = (uint16_t) qi[k];

@@ -1084,8 +1084,11 @@ extern "C" int pamd_pipe_run_multi(pamd_assembler *const *assemblers, const int 
 	stats->seconds_pump = t_end - t_ready;
 	for (auto &p : run.pumps)
 		p->destroy();
-	if (!run.sh.failed.load() && run.out.seekable && ftruncate(run.out.fd, (off_t) out_bytes) != 0)	// (pieces of chunks dealt beyond the one the reader gave up in were never written; this is the file's size)
-		run.sh.fail(PAMD_EIO, "ftruncate", strerror(errno));
+	{	// (a regular file: what was written is its size -- nothing was written beyond it, the pieces of chunks dealt behind the one the reader gave up in never left)
+		struct stat sb;
+		if (!run.sh.failed.load() && run.out.seekable && fstat(run.out.fd, &sb) == 0 && S_ISREG(sb.st_mode) && ftruncate(run.out.fd, (off_t) out_bytes) != 0)
+			run.sh.fail(PAMD_EIO, "ftruncate", strerror(errno));
+	}
 	close_all();
 	if (run.sh.failed.load()) {
 		pamd_set_error("pamd_pipe_run_multi: %s", run.sh.msg.c_str());

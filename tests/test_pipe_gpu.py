@@ -417,6 +417,8 @@ def test_multi_device_run_into_a_pipe_and_from_gzip(pipe, tmp_path):
     subprocess.check_call([pipe, str(f), str(r), str(fifo), "0", "fastq", "400"], timeout=300, env=env, stdout=subprocess.DEVNULL)
     reader.join()
     assert got[0] == want[0]
+    # ... and one that is no file at all
+    subprocess.check_call([pipe, str(f), str(r), "/dev/null", "0", "fastq", "400"], timeout=300, env=env, stdout=subprocess.DEVNULL)
     (tmp_path / "f.gz").write_bytes(gzip.compress(ft, 1))
     (tmp_path / "r.gz").write_bytes(gzip.compress(rt, 1))
     subprocess.check_call([pipe, str(tmp_path / "f.gz"), str(tmp_path / "r.gz"), str(tmp_path / "gz.txt"), "0", "fastq", "400"], timeout=300, env=env, stdout=subprocess.DEVNULL)
