@@ -666,10 +666,17 @@ template <int ALGO>
 __device__ __attribute__((noinline)) Redone redo_pair(const PamdKernelParams *kernarg, const double *ltab, unsigned char *wb, unsigned arena_cur_v, unsigned arena_end_v, int slot_v, u64 pair_v, int lane) {
 	// (a function's arguments arrive in vector registers: what is wave-uniform is made scalar again)
 	const PamdKernelParams &P = *kernarg;
+	auto uni_u64 = [](u64 v) -> u64 {
+		return (u64) (unsigned) uni((int) (unsigned) v) | ((u64) (unsigned) uni((int) (unsigned) (v >> 32)) << 32);
+	};
 	const unsigned arena_cur = (unsigned) uni((int) arena_cur_v), arena_end = (unsigned) uni((int) arena_end_v);
 	const int slot = uni(slot_v);
-	const u64 pair = (u64) (unsigned) uni((int) (unsigned) pair_v) | ((u64) (unsigned) uni((int) (unsigned) (pair_v >> 32)) << 32);
-	const HotArgs H = { P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.threshold, P.seq_stride, P.seq_capacity, P.seq_nt, P.seq_p };
+	const u64 pair = uni_u64(pair_v);
+	// (read through a pointer these arrive in vector registers too; as scalars the row's offset is scalar arithmetic -- as vectors it
+	// was a 64-bit multiply-add whose undefined upper addend the allocator put in a register with a bare LDS read pending, which
+	// tools/isa_hazards.py refuses)
+	const HotArgs H = { uni_f64(P.qual_nn), uni_f64(P.sb_pmatch), uni_f64(P.sb_pmismatch), uni_f64(P.threshold), uni_u64(P.seq_stride), uni_u64(P.seq_capacity),
+			    reinterpret_cast<uint8_t *>(uni_u64((u64) P.seq_nt)), reinterpret_cast<double *>(uni_u64((u64) P.seq_p)) };
 	unsigned epoch = 0;
 	if (lane < 4)	// what lies before fast_pair()'s forward N map reads as N (the pass's rows lay there)
 		reinterpret_cast<unsigned *>(wb + FK_PAD0)[lane] = 0x55555555u;

@@ -68,3 +68,35 @@ def test_sharded_counters_allreduce_equals_single_run(built):
         assert d[k] == int(ctr[k]), k
     assert np.array_equal(d["overlapcount"], ctr["overlapcount"])
     assert d["longest_overlap"] == int(ctr["longest_overlap"])  # max recovered from the summed histogram
+
+
+def test_stat_block_in_c_equals_the_python_one(built):
+    """pamd_stat_block() (pamd_pipe_multi.cpp: pool.c:86-104's lines, OVERLAPS as proxy.c:175-190 prints it) against
+    pandaseq_amd.stats.format_stat_block on counter blocks as a run produces them -- primers set and not, modules that rejected
+    and did not, an assembler name, an empty histogram -- and its refusal of a buffer that is too small."""
+    import ctypes as C
+    import numpy as np
+    from pandaseq_amd import _lib, stats
+    L = _lib.lib()
+    L.pamd_stat_block.restype = C.c_int
+    L.pamd_stat_block.argtypes = [C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]
+    rng = np.random.default_rng(3)
+    for case in range(6):
+        ctr = np.zeros(_lib.NUM_COUNTERS, dtype=np.int64)
+        ctr[:8] = rng.integers(0, 1_000_000_000_000, size=8)
+        if case != 4:
+            hi = int(rng.integers(1, 2 * _lib.MAX_LEN))
+            ctr[_lib.CTR_OVERLAP0:_lib.CTR_OVERLAP0 + hi] = rng.integers(0, 50_000, size=hi)
+            ctr[_lib.CTR_OVERLAP0 + hi - 1] = 7
+        mods = [b"min_phred", b"min_overlapbits", b"empty"][:case % 4]
+        for m in range(len(mods)):
+            ctr[_lib.CTR_REJECTED0 + m] = 0 if m == 1 else int(rng.integers(1, 1000))
+        names = (C.c_char_p * max(1, len(mods)))(*mods) if mods else None
+        name = b"worker3" if case % 2 else None
+        buf = C.create_string_buffer(1 << 16)
+        n = L.pamd_stat_block(ctr.ctypes.data_as(C.POINTER(C.c_int64)), case & 1, (case >> 1) & 1, names, len(mods), name, buf, len(buf))
+        want = stats.format_stat_block(ctr, has_forward_primer=bool(case & 1), has_reverse_primer=bool((case >> 1) & 1),
+                                       module_names=[m.decode() for m in mods], name=name.decode() if name else None) + "\n"
+        assert n == len(want) and buf.value.decode() == want, (case, buf.value.decode()[:300], want[:300])
+    small = C.create_string_buffer(16)
+    assert L.pamd_stat_block(ctr.ctypes.data_as(C.POINTER(C.c_int64)), 0, 0, None, 0, None, small, len(small)) == -1     # PAMD_EINVAL

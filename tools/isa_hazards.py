@@ -50,7 +50,7 @@ def scan_bare_reads(listing, only=None):
             if t.split(";")[0].strip().startswith("s_endpgm"):
                 pass
     for name, lines in kernels:
-        if "pamd_fast_kernel" not in name or (only and only not in name):
+        if only and only not in name:     # (every function of the listing: the kernels, and what they call out of line -- redo_pair() holds fast_pair()'s reads too)
             continue
         # instructions and blocks
         blocks, label_of, block = [], {}, None
@@ -138,13 +138,13 @@ def scan_bare_reads(listing, only=None):
 
 
 def scan_m0(listing):
-    """[(line, text)] of every instruction outside an inline-asm block that mentions m0, in the pamd_fast_kernel kernels."""
+    """[(line, text)] of every instruction outside an inline-asm block that mentions m0, in every function of the listing."""
     out, in_asm, on = [], False, False
     for no, raw in enumerate(listing, 1):
         t = raw.strip()
         m = re.match(r"^(_Z\w+):", t)
         if m:
-            on = "pamd_fast_kernel" in m.group(1)
+            on = True   # (every function of the listing)
             continue
         if t.startswith(";;#ASMSTART"):
             in_asm = True
