@@ -1781,6 +1781,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			unsigned m1[BPL], m2[BPL], xk[BPL];
 			bool ok[BPL];
 			const unsigned l1 = lds_addr(t1), l2 = lds_addr(t2);
+			// (measured and not kept, round 6: the second insert level's atomics left in flight -- bare `ds_min_rtn`, their returns collected
+			// behind these lookups, which read the tables' state in issue order whether or not the atomics have returned: one exposed
+			// round trip fewer, and -1.7 % on config 1, -1 % on config 4: the deep-table inserts then wait behind the lookups)
 			// (the compiler issues these 2 BPL reads k-mer by k-mer, three LDS round trips; all eight under way before the first
 			// use -- bare reads, one wait -- measured in round 4: nothing on configs 1, 2 and 4, -1.5 % on config 3; as volatile
 			// reads in round 6: +-0.5 % on configs 1 and 4.  The other waves cover it.)
@@ -2312,6 +2315,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 #endif
 			}
 		};
+		// (measured and not kept, round 6: the second trip's rounds and table reads issued before the first trip's stores -- no spill,
+		// one exposed round trip fewer on rows of more than 256 bases: +0.4 % on config 1, inside the noise)
 		typedef std::integral_constant<int, 2> two;
 		typedef std::integral_constant<int, 4> four;
 		if constexpr (LONG) {
