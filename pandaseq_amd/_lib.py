@@ -119,6 +119,8 @@ def lib():
     L.pamd_table_image.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.pamd_assemble_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.pamd_set_fast_path.argtypes = [C.c_void_p, C.c_int]
+    L.pamd_set_two_pairs_per_wave.argtypes = [C.c_void_p, C.c_int]
+    L.pamd_set_two_pairs_per_wave.restype = C.c_int
     L.pamd_last_deferred.restype = C.c_longlong
     L.pamd_last_deferred.argtypes = [C.c_void_p]
     L.pamd_last_lean_variant.restype = C.c_int
