@@ -168,6 +168,28 @@ def test_two_pairs_per_wave(built, algo):
             assert asm.last_lean_variant() == ("short+narrow+dual" if dual else "short+narrow"), asm.last_lean_variant()
             compare_results(b.results_numpy(), *b.rows_numpy(), o_res, o_nt, o_p, exact_sums=False)
             compare_counters(b.counters_dict(), o_ctr)
+    if algo == "simple_bayesian":
+        # at a size where every wave goes through hundreds of passes -- the epochs of the shared k-mer tables used up and started
+        # over, pairs redone by fast_pair() between passes, finishes of 64 parked pairs: an odd 700 001 pairs against the oracle
+        # on all host cores, every record field and the rows through their checksums
+        n = 700_001
+        fwd, rev, flen, rlen = synth.generate_host(spec4, 12_000_000, n)
+        ocfg = po.make_config(algo)
+        o_res, o_cs_nt, o_cs_p = po.row_checksums(ocfg, fwd, rev, flen, rlen, threads=os.cpu_count() or 1)
+        o_ctr = po.assemble_batch(ocfg, fwd, rev, flen, rlen, want_seq=False, threads=os.cpu_count() or 1)[3]
+        asm = pa.Assembler(0)
+        asm.set_algorithm(algo)
+        asm.set_exact_sums(False)
+        asm.set_two_pairs_per_wave(True)
+        b = pa.upload_batch(fwd, rev, flen, rlen, device="cuda:0", seq_stride=0, capacity=n * 330 + (1 << 27))
+        asm.assemble_device(b)
+        torch.cuda.synchronize()
+        asm.check_overflow()
+        assert asm.last_lean_variant() == "short+narrow+dual"
+        compare_results(b.results_numpy(), None, None, o_res, None, None, exact_sums=False, check_seq=False)
+        d_nt, d_p = pa.row_checksums(b.results, b.seq_nt, b.seq_p)
+        assert np.array_equal(d_nt.cpu().numpy().view(np.uint64), o_cs_nt) and np.array_equal(d_p.cpu().numpy().view(np.uint64), o_cs_p), "row checksums"
+        compare_counters(b.counters_dict(), o_ctr)
     # what the geometry does not serve stays with a pair per wave: reference-order sums, a min_phred module, a maximum overlap, pear
     fwd, rev, flen, rlen = cases[1]
     for tweak in (lambda a: a.set_exact_sums(True), lambda a: a.add_module("min_phred:2"), lambda a: a.set_maximum_overlap(120), lambda a: a.set_algorithm("pear")):

@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 pytestmark = pytest.mark.gpu
 
-ROUND = 5   # the build round: every campaign starts at a round number derived from it
+ROUND = 6   # the build round: every campaign starts at a round number derived from it
 
 
 def _log(lines):
