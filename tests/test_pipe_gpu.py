@@ -145,6 +145,23 @@ def test_pump_fails_cleanly(pipe, tmp_path):
         assert out.returncode == 3 and "cannot" in out.stderr, (args, out.returncode, out.stderr[-300:])
     out = subprocess.run([pipe, str(f), str(r), str(tmp_path / "o.txt"), "0", "fasta", "4000000"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 3 and "3 000 000" in out.stderr     # more pairs per chunk than a text chunk below 4 GiB can hold
+    # an input that fails in mid-stream -- gzip text with a damaged block, read by ONE thread that nobody else would ever wake for: the
+    # failure is recorded, every waiter is notified under its own lock, and the run returns the I/O error instead of hanging
+    import gzip
+    big_f, big_r = util.random_fastq(40_000, 5)
+    def damaged(text):
+        z = bytearray(gzip.compress(text, 1))
+        for k in range(len(z) // 2, len(z) // 2 + 64):
+            z[k] ^= 0x5A
+        return bytes(z)
+    (tmp_path / "f.gz").write_bytes(gzip.compress(big_f, 1))
+    (tmp_path / "r.gz").write_bytes(gzip.compress(big_r, 1))
+    (tmp_path / "f_bad.gz").write_bytes(damaged(big_f))
+    (tmp_path / "r_bad.gz").write_bytes(damaged(big_r))
+    for args in ((str(tmp_path / "f_bad.gz"), str(tmp_path / "r.gz")), (str(tmp_path / "f.gz"), str(tmp_path / "r_bad.gz"))):
+        out = subprocess.run([pipe, *args, str(tmp_path / "o.txt"), "0", "fasta", "1000"], capture_output=True, text=True, timeout=120)
+        # (zlib reports the damage -- an I/O error, exit 3 -- unless what it inflated before noticing already stopped the reader at a record)
+        assert (out.returncode == 3 and "gzread" in out.stderr) or (out.returncode == 0 and "STOP\t0\t" not in out.stdout), (out.returncode, out.stderr[-300:])
 
 
 # ---- the reference's own file-level API: panda_assembler_open() + panda_assembler_next() ------------------
