@@ -201,6 +201,17 @@ __device__ __forceinline__ unsigned lshl_add(unsigned x, unsigned y) {
 	asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(S), "v"(y));
 	return r;
 }
+// the smallest / the middle one of three (one instruction each)
+__device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c) {
+	unsigned r;
+	asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+	unsigned r;
+	asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
 __device__ __forceinline__ unsigned lds_read_u32(unsigned addr) {
 	return *reinterpret_cast<__attribute__((address_space(3))) const unsigned *>(addr);
 }
@@ -209,6 +220,16 @@ __device__ __forceinline__ unsigned lds_read_u32_early(unsigned addr) {	// (vola
 }
 #ifndef FK_DEEP_BATCH
 #define FK_DEEP_BATCH 1
+#endif
+// FK_BUCKETS: the first k-mer table as buckets of two slots (the same 4 KB: 2^(T1B-1) buckets): a word goes to its bucket's first
+// slot, what that displaces to the second (the same address + 4), what that displaces to the second table.  A bucket keeps the two
+// smallest of its words, in order; 250 k-mers overflow 512 buckets of two by 7 words where they overflow 1 024 single slots by 27,
+// and the second table's 256 slots then pass on 0.1 words a pair instead of 1.3: the last two tables (two more inserts with a round
+// trip each, eight more lookups and fifty-six vector instructions for every lane) are reached by a pair in ten instead of two in
+// three, for one more insert level (no address arithmetic: an offset) and a 64-bit lookup where a 32-bit one was.
+// 1: the geometries of four and five k-mers per lane; 2: three per lane (NARROW) too
+#ifndef FK_BUCKETS
+#define FK_BUCKETS 1
 #endif
 #ifndef FK_LAZY_FLAGS
 #define FK_LAZY_FLAGS 1
@@ -1362,8 +1383,8 @@ __device__ __forceinline__ unsigned insert_at(unsigned lds_byte_addr, unsigned c
 // waits for each atomic inside its own branch: eight exposed LDS round trips per pair instead of two.  (The wait sits inside
 // the statement: between issue and wait nothing may touch the destination registers, and the compiler's own counter
 // bookkeeping does not see into an asm statement.)
-#define FK_INS(W, A, C) "v_cmp_ne_u32_e32 vcc, -1, " C "\n\ts_and_saveexec_b64 %[sv], vcc\n\tds_min_rtn_u32 " W ", " A ", " C "\n\ts_mov_b64 exec, %[sv]\n\t"
-template <int BPL>
+#define FK_INS(W, A, C) "v_cmp_ne_u32_e32 vcc, -1, " C "\n\ts_and_saveexec_b64 %[sv], vcc\n\tds_min_rtn_u32 " W ", " A ", " C " offset:%[off]\n\ts_mov_b64 exec, %[sv]\n\t"
+template <int BPL, int OFF = 0>
 __device__ __forceinline__ void insert_all(const unsigned (&addr)[BPL], unsigned (&carry)[BPL]) {
 	unsigned was[BPL];
 #pragma unroll
@@ -1374,17 +1395,17 @@ __device__ __forceinline__ void insert_all(const unsigned (&addr)[BPL], unsigned
 	if constexpr (BPL == 3)
 		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") "s_waitcnt lgkmcnt(0)"
 			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [sv] "=&s"(sv)
-			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2])
+			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [off] "n"(OFF)
 			     : "vcc", "scc", "memory");
 	else if constexpr (BPL == 4)
 		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") FK_INS("%[w3]", "%[a3]", "%[c3]") "s_waitcnt lgkmcnt(0)"
 			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [w3] "+v"(was[3]), [sv] "=&s"(sv)
-			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [a3] "v"(addr[3]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [c3] "v"(carry[3])
+			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [a3] "v"(addr[3]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [c3] "v"(carry[3]), [off] "n"(OFF)
 			     : "vcc", "scc", "memory");
 	else
 		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") FK_INS("%[w3]", "%[a3]", "%[c3]") FK_INS("%[w4]", "%[a4]", "%[c4]") "s_waitcnt lgkmcnt(0)"
 			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [w3] "+v"(was[3]), [w4] "+v"(was[4]), [sv] "=&s"(sv)
-			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [a3] "v"(addr[3]), [a4] "v"(addr[4]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [c3] "v"(carry[3]), [c4] "v"(carry[4])
+			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [a3] "v"(addr[3]), [a4] "v"(addr[4]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [c3] "v"(carry[3]), [c4] "v"(carry[4]), [off] "n"(OFF)
 			     : "vcc", "scc", "memory");
 #pragma unroll
 	for (int j = 0; j < BPL; j++)
@@ -1392,8 +1413,8 @@ __device__ __forceinline__ void insert_all(const unsigned (&addr)[BPL], unsigned
 }
 #undef FK_INS
 // (FK_EPOCH: a word is live -- this pair's, not EMPTY, not a stale one just displaced -- when it lies below the epoch's upper limit)
-#define FK_INS(W, A, C) "v_cmp_gt_u32_e32 vcc, %[lim], " C "\n\ts_and_saveexec_b64 %[sv], vcc\n\tds_min_rtn_u32 " W ", " A ", " C "\n\ts_mov_b64 exec, %[sv]\n\t"
-template <int BPL>
+#define FK_INS(W, A, C) "v_cmp_gt_u32_e32 vcc, %[lim], " C "\n\ts_and_saveexec_b64 %[sv], vcc\n\tds_min_rtn_u32 " W ", " A ", " C " offset:%[off]\n\ts_mov_b64 exec, %[sv]\n\t"
+template <int BPL, int OFF = 0>
 __device__ __forceinline__ void insert_all_live(const unsigned (&addr)[BPL], unsigned (&carry)[BPL], unsigned limit) {
 	unsigned was[BPL];
 #pragma unroll
@@ -1404,12 +1425,12 @@ __device__ __forceinline__ void insert_all_live(const unsigned (&addr)[BPL], uns
 	if constexpr (BPL == 3)
 		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") "s_waitcnt lgkmcnt(0)"
 			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [sv] "=&s"(sv)
-			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [lim] "s"(limit)
+			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [lim] "s"(limit), [off] "n"(OFF)
 			     : "vcc", "scc", "memory");
 	else
 		asm volatile(FK_INS("%[w0]", "%[a0]", "%[c0]") FK_INS("%[w1]", "%[a1]", "%[c1]") FK_INS("%[w2]", "%[a2]", "%[c2]") FK_INS("%[w3]", "%[a3]", "%[c3]") "s_waitcnt lgkmcnt(0)"
 			     : [w0] "+v"(was[0]), [w1] "+v"(was[1]), [w2] "+v"(was[2]), [w3] "+v"(was[3]), [sv] "=&s"(sv)
-			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [a3] "v"(addr[3]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [c3] "v"(carry[3]), [lim] "s"(limit)
+			     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [a3] "v"(addr[3]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [c3] "v"(carry[3]), [lim] "s"(limit), [off] "n"(OFF)
 			     : "vcc", "scc", "memory");
 #pragma unroll
 	for (int j = 0; j < BPL; j++)
@@ -1496,6 +1517,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	bool slow = false;
 	const int minov = P.minoverlap;
 	constexpr int T1B = t1_bits<ALGO, LONG>();
+	constexpr bool BUCK = FK_BUCKETS == 2 || (FK_BUCKETS == 1 && !NARROW);
 	constexpr bool EP = FK_EPOCH != 0 && !LONG;	// (the LONG geometry lays its primer scan and its merged row over the first table: cleared per pair as ever)
 	constexpr unsigned KSH = EP ? 9u : 16u, POS_END = EP ? 0x200u : 0x10000u;	// a table word is key << KSH | position; an entry of the k-mer looked for reads as its bare position, below POS_END
 	typedef Geo<LONG, T1B> G;
@@ -1699,8 +1721,10 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				unsigned addr[BPL];
 #pragma unroll
 				for (int j = 0; j < BPL; j++)
-					addr[j] = lshl_add<2>(mul24(key[j], HASH_C) >> (32 - T1B), l1);
+					addr[j] = BUCK ? lshl_add<3>(mul24(key[j], HASH_C) >> (33 - T1B), l1) : lshl_add<2>(mul24(key[j], HASH_C) >> (32 - T1B), l1);
 				insert_all_live<BPL>(addr, carry, limit);
+				if constexpr (BUCK)
+					insert_all_live<BPL, 4>(addr, carry, limit);	// what the bucket's first slot displaced, to its second
 #pragma unroll
 				for (int j = 0; j < BPL; j++)
 					addr[j] = lshl_add<2>(__builtin_amdgcn_ubfe(mul24(carry[j] >> 9, HASH_C), 14, 8), l2);
@@ -1715,8 +1739,12 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				unsigned addr[BPL];
 #pragma unroll
 				for (int j = 0; j < BPL; j++)
-					addr[j] = lshl_add<2>(mul24(carry[j] >> 16, HASH_C) >> (32 - T1B), l1);
+					addr[j] = BUCK ? lshl_add<3>(mul24(carry[j] >> 16, HASH_C) >> (33 - T1B), l1) : lshl_add<2>(mul24(carry[j] >> 16, HASH_C) >> (32 - T1B), l1);
 				insert_all<BPL>(addr, carry);
+				if constexpr (BUCK) {
+					// (the second slot's word has another k-mer, usually: its hash is taken below, from what moved on)
+					insert_all<BPL, 4>(addr, carry);
+				}
 #pragma unroll
 				for (int j = 0; j < BPL; j++)
 					addr[j] = lshl_add<2>(__builtin_amdgcn_ubfe(mul24(carry[j] >> 16, HASH_C), 14, 8), l2);
@@ -1736,7 +1764,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 						// keeps its minimum), so a k-mer with two of them in the tables loses nothing the reference keeps
 						// (assembler.c:94-99 drops a third position as well): tandem repeats pass here.
 						const unsigned k = carry[j] >> KSH, kk = carry[j] & ~(POS_END - 1u);
-						const int kept = (int) ((t1[slot1<T1B>(k)] ^ kk) < POS_END) + (int) ((t2[slot2(k)] ^ kk) < POS_END) + (int) ((t3[slot3(k)] ^ kk) < POS_END) + (int) ((t4[slot4(k)] ^ kk) < POS_END);
+						const unsigned s1 = BUCK ? (slot1<T1B>(k) & ~1u) : slot1<T1B>(k);
+						const int kept = (int) ((t1[s1] ^ kk) < POS_END) + (BUCK ? (int) ((t1[s1 + 1u] ^ kk) < POS_END) : 0) + (int) ((t2[slot2(k)] ^ kk) < POS_END) + (int) ((t3[slot3(k)] ^ kk) < POS_END) + (int) ((t4[slot4(k)] ^ kk) < POS_END);
 						lost |= ballot(carry[j] < limit && kept < 2) != 0;
 					}
 				}
@@ -1794,11 +1823,18 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 				if constexpr (EP)
 					xk[j] = __builtin_amdgcn_alignbit(epoch, xk[j], 16);	// the key, epoch | k-mer: what this pair's words of the k-mer carry above their position
 				const unsigned prod = mul24(EP ? xk[j] : xk[j] >> 16, HASH_C), kk = EP ? xk[j] << 9 : xk[j] & 0xFFFF0000u;
-				const unsigned e1 = lds_read_u32(lshl_add<2>(prod >> (32 - T1B), l1)) ^ kk;
 				const unsigned e2 = lds_read_u32(lshl_add<2>(__builtin_amdgcn_ubfe(prod, 14, 8), l2)) ^ kk;
 				// an entry of this k-mer reads as its bare position (< 0x10000), anything else as >= 0x10000
-				m1[j] = e1 < e2 ? e1 : e2;
-				m2[j] = e1 < e2 ? e2 : e1;
+				if constexpr (BUCK) {
+					const u32x2 b = *reinterpret_cast<__attribute__((address_space(3))) const u32x2 *>(lshl_add<3>(prod >> (33 - T1B), l1));	// the bucket, one 8-byte read
+					const unsigned ea = b.x ^ kk, eb = b.y ^ kk;
+					m1[j] = umin3(ea, eb, e2);	// the smallest and the second smallest of three
+					m2[j] = umed3(ea, eb, e2);
+				} else {
+					const unsigned e1 = lds_read_u32(lshl_add<2>(prod >> (32 - T1B), l1)) ^ kk;
+					m1[j] = e1 < e2 ? e1 : e2;
+					m2[j] = e1 < e2 ? e2 : e1;
+				}
 			}
 			if (deep) {	// wave-uniform: the last two tables hold something
 #if FK_DEEP_BATCH
