@@ -495,6 +495,12 @@ __device__ __forceinline__ unsigned primer_tier1(unsigned code_addr, unsigned ca
 	return packed;
 }
 
+// (measured and not kept, round 6: a pass BEFORE the counts that only asks whether an alignment has a disagreement at all -- xor,
+// a three-input and, a compare into a scalar pair: three instructions where the count takes nine -- and settles the read when
+// exactly one alignment has none and its value leaves every other alignment a budget of zero.  On config 2's reads a primer base
+// of quality 2 or two of quality 8 -- a read in three -- leave late alignments a budget of one or two and the pass is wasted:
+// 22 vector instructions fewer per pair of 1 236, 125 scalar ones more of 595 (the five masks' validity, counts and index):
+// -2.6 %, profiles/r06_experiments_ab.txt.  A scalar instruction costs a wave what a vector one does.)
 // The sums of one alignment of each read at once, in ANY order (|error| < 1e-12: good for a bound and for a verdict with
 // a margin; values that are compared with each other are summed in the reference's order, primer_exact): lanes 0..31 look up
 // the terms of the forward read's alignment s0f (lane x: primer base x), lanes 32..63 those of the reverse read's s0r; no
@@ -2840,7 +2846,11 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 #ifndef FK_DEV_EXACT
 #define FK_DEV_EXACT false
 #endif
+#ifdef FK_DEV_PRIM	/* ... config 2's: pear, the primers' geometry */
+	kern = pamd_fast_kernel<PAMD_ALGO_PEAR, FK_DEV_EXACT, false, true, true, false>;
+#else
 	kern = narrow ? pamd_fast_kernel<PAMD_ALGO_SIMPLE_BAYES, FK_DEV_EXACT, false, false, false, true> : pamd_fast_kernel<PAMD_ALGO_SIMPLE_BAYES, FK_DEV_EXACT, false, false, false, false>;
+#endif
 #else
 	switch (variant == 0 ? -1 : p.algo) {
 	case PAMD_ALGO_SIMPLE_BAYES:
