@@ -1443,6 +1443,26 @@ __device__ __forceinline__ void insert_all_live(const unsigned (&addr)[BPL], uns
 		carry[j] = was[j] > carry[j] ? was[j] : carry[j];
 }
 #undef FK_INS
+// FK_INS_PLAIN (short geometry, four words per lane): the levels at which most words are live -- the bucket's two slots -- without
+// the test: a word that is not live (EMPTY, or a stale one just displaced) loses its ds_min against anything live and leaves a slot
+// that was not live not live, and max(previous, word) is not live either.  Per word a compare and two scalar instructions (exec
+// saved and restored) fewer, and no zeroed result register: 16 vector and 16 scalar instructions a pair, +1.2 % on config 1 (the
+// first slot alone: nothing; profiles/r06_experiments_ab.txt).  Not where lanes idle -- three k-mers per lane, or five: their words
+// would all meet on one slot.  1: the first slot; 2: the second slot too
+#ifndef FK_INS_PLAIN
+#define FK_INS_PLAIN 2
+#endif
+template <int OFF>
+__device__ __forceinline__ void insert_all_plain(const unsigned (&addr)[4], unsigned (&carry)[4]) {
+	unsigned was[4];
+	asm volatile("ds_min_rtn_u32 %[w0], %[a0], %[c0] offset:%[off]\n\tds_min_rtn_u32 %[w1], %[a1], %[c1] offset:%[off]\n\tds_min_rtn_u32 %[w2], %[a2], %[c2] offset:%[off]\n\tds_min_rtn_u32 %[w3], %[a3], %[c3] offset:%[off]\n\ts_waitcnt lgkmcnt(0)"
+		     : [w0] "=&v"(was[0]), [w1] "=&v"(was[1]), [w2] "=&v"(was[2]), [w3] "=&v"(was[3])
+		     : [a0] "v"(addr[0]), [a1] "v"(addr[1]), [a2] "v"(addr[2]), [a3] "v"(addr[3]), [c0] "v"(carry[0]), [c1] "v"(carry[1]), [c2] "v"(carry[2]), [c3] "v"(carry[3]), [off] "n"(OFF)
+		     : "memory");
+#pragma unroll
+	for (int j = 0; j < 4; j++)
+		carry[j] = was[j] > carry[j] ? was[j] : carry[j];
+}
 
 // why pairs are deferred, counted in P.phase_cycles[0..5] (read back with pamd_debug_phase_cycles): 0 an nt or quality
 // outside the lean domain, 1 a k-mer found no slot, 2 a score comparison too close to call (pear, rdp_mle), 3 more than four
@@ -1728,9 +1748,16 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 #pragma unroll
 				for (int j = 0; j < BPL; j++)
 					addr[j] = BUCK ? lshl_add<3>(mul24(key[j], HASH_C) >> (33 - T1B), l1) : lshl_add<2>(mul24(key[j], HASH_C) >> (32 - T1B), l1);
-				insert_all_live<BPL>(addr, carry, limit);
-				if constexpr (BUCK)
-					insert_all_live<BPL, 4>(addr, carry, limit);	// what the bucket's first slot displaced, to its second
+				if constexpr (FK_INS_PLAIN >= 1 && BPL == 4)
+					insert_all_plain<0>(addr, carry);
+				else
+					insert_all_live<BPL>(addr, carry, limit);
+				if constexpr (BUCK) {	// what the bucket's first slot displaced, to its second
+					if constexpr (FK_INS_PLAIN >= 2 && BPL == 4)
+						insert_all_plain<4>(addr, carry);
+					else
+						insert_all_live<BPL, 4>(addr, carry, limit);
+				}
 #pragma unroll
 				for (int j = 0; j < BPL; j++)
 					addr[j] = lshl_add<2>(__builtin_amdgcn_ubfe(mul24(carry[j] >> 9, HASH_C), 14, 8), l2);
