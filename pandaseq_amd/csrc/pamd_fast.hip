@@ -255,8 +255,24 @@ __device__ __forceinline__ unsigned lds_read_u32_early(unsigned addr) {	// (vola
 // The reverse stream stores every code with its two bits swapped (C=2, G=1) and its N flags on the odd bits: a
 // bit-reversed window of it then reads as forward codes in reversed base order, which is how a reverse k-mer meets a
 // forward one (base t against base 7-t) and how the scan pairs forward position fi with reverse position ri.
+// FK_LEN_MASKS: what stage() needs of a read's length alone -- which of the lane's four bases exist: their bytes, their code
+// bits -- stays in registers from pair to pair and is made again only when the length changes (eight vector instructions a read)
+#ifndef FK_LEN_MASKS
+#define FK_LEN_MASKS 1
+#endif
+struct LenMasks {
+	int len;	// (-1: not made yet)
+	unsigned bm, in2;
+};
+__device__ __forceinline__ void len_masks(LenMasks &m, int len, int lane) {
+	int cnt = len - 4 * lane;
+	cnt = cnt < 0 ? 0 : (cnt > 4 ? 4 : cnt);	// how many of this lane's bases exist
+	m.bm = (unsigned) ((0xFFFFFFFFull << (8 * cnt)) >> 32);	// their bytes
+	m.in2 = (1u << (2 * cnt)) - 1u;	// their code bits
+	m.len = len;
+}
 template <bool FORWARD>
-__device__ __forceinline__ int stage(const uint2 v, const int len, int lane, unsigned char *wb, unsigned &codes, unsigned &nmap, unsigned &weird) {
+__device__ __forceinline__ int stage(const uint2 v, const int len, int lane, unsigned char *wb, unsigned &codes, unsigned &nmap, unsigned &weird, const LenMasks &lm) {
 	reinterpret_cast<uint2 *>(wb + (FORWARD ? FK_F : FK_R))[lane] = v;
 	const unsigned n4 = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u);	// the four nt bytes
 	const unsigned q4 = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);	// the four quality bytes
@@ -265,14 +281,18 @@ __device__ __forceinline__ int stage(const uint2 v, const int len, int lane, uns
 	const unsigned lo = __builtin_amdgcn_perm(lut_word<FORWARD>(1), lut_word<FORWARD>(0), sel);
 	const unsigned hi = __builtin_amdgcn_perm(lut_word<FORWARD>(3), lut_word<FORWARD>(2), sel);
 	const unsigned r4 = (hi & m3) | (lo & ~m3);
+#if FK_LEN_MASKS
+	const unsigned bm = lm.bm, in2 = lm.in2;
+#else
 	int cnt = len - 4 * lane;
 	cnt = cnt < 0 ? 0 : (cnt > 4 ? 4 : cnt);	// how many of this lane's bases exist
 	const unsigned bm = (unsigned) ((0xFFFFFFFFull << (8 * cnt)) >> 32);	// their bytes
+	const unsigned in2 = (1u << (2 * cnt)) - 1u;
+#endif
 	const unsigned wq = (((q4 & 0x7F7F7F7Fu) + 0x51515151u) | q4) & 0x80808080u;	// a quality outside 0..46
 	weird |= ((r4 & 0x08080808u) | wq | (n4 & 0xF0F0F0F0u)) & bm;
 	const unsigned c4 = r4 & 0x03030303u, isn4 = (r4 >> 2) & 0x01010101u;
 	const unsigned cy = c4 | (c4 >> 6), ny = isn4 | (isn4 >> 6);
-	const unsigned in2 = (1u << (2 * cnt)) - 1u;
 	codes = (cy | (cy >> 12)) & in2;
 	const unsigned nb = ((ny | (ny >> 12)) | ~in2) & 0x55u;
 	nmap = FORWARD ? nb : nb << 1;
@@ -285,7 +305,9 @@ __device__ __forceinline__ int stage(const uint2 v, const int len, int lane, uns
 	const unsigned x = q4 ^ 0x02020202u;
 	const unsigned t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);	// 0x80 where quality == 2
 	const unsigned is2 = (((t >> 7) * 0x00204081u) >> 21) & 0xFu;
-	const unsigned not2 = ~is2 & ((1u << cnt) - 1u);
+	int have = len - 4 * lane;
+	have = have < 0 ? 0 : (have > 4 ? 4 : have);
+	const unsigned not2 = ~is2 & ((1u << have) - 1u);
 	const int mine = not2 ? lane * 4 + (31 - __builtin_clz(not2)) + 1 : 0;
 	const u64 has = ballot(not2 != 0);
 	if (has == 0)
@@ -297,8 +319,9 @@ __device__ __forceinline__ int stage(const uint2 v, const int len, int lane, uns
 // Four bases of a row (x: nt0 q0 nt1 q1, y: nt2 q2 nt3 q3), of which the first `cnt` exist: their k-mer codes (2 bits each),
 // N flags (bit 2k forward, 2k+1 reverse; a base that does not exist reads as N), whether one is outside the lean domain;
 // the nt and the quality bytes for the caller.  The arithmetic of stage() above.
+// (bm: the bytes of the bases that exist, in2: their code bits -- len_masks())
 template <bool FORWARD>
-__device__ __forceinline__ void pack4(unsigned x, unsigned y, int cnt, unsigned &codes, unsigned &nmap, unsigned &weird, unsigned &skip4, unsigned &q4) {
+__device__ __forceinline__ void pack4m(unsigned x, unsigned y, unsigned bm, unsigned in2, unsigned &codes, unsigned &nmap, unsigned &weird, unsigned &skip4, unsigned &q4) {
 	unsigned n4;
 	n4 = __builtin_amdgcn_perm(y, x, 0x06040200u);
 	q4 = __builtin_amdgcn_perm(y, x, 0x07050301u);
@@ -307,16 +330,18 @@ __device__ __forceinline__ void pack4(unsigned x, unsigned y, int cnt, unsigned 
 	const unsigned lo = __builtin_amdgcn_perm(lut_word<FORWARD>(1), lut_word<FORWARD>(0), sel);
 	const unsigned hi = __builtin_amdgcn_perm(lut_word<FORWARD>(3), lut_word<FORWARD>(2), sel);
 	const unsigned r4 = (hi & m3) | (lo & ~m3);
-	const unsigned bm = (unsigned) ((0xFFFFFFFFull << (8 * cnt)) >> 32);
 	const unsigned wq = (((q4 & 0x7F7F7F7Fu) + 0x51515151u) | q4) & 0x80808080u;
 	weird |= ((r4 & 0x08080808u) | wq | (n4 & 0xF0F0F0F0u)) & bm;
 	const unsigned c4 = r4 & 0x03030303u, isn4 = (r4 >> 2) & 0x01010101u;
 	skip4 = isn4 | ~bm;	// (bit 0 of a byte: an N, or no base at all)
 	const unsigned cy = c4 | (c4 >> 6), ny = isn4 | (isn4 >> 6);
-	const unsigned in2 = (1u << (2 * cnt)) - 1u;
 	codes = (cy | (cy >> 12)) & in2;
 	const unsigned nb = ((ny | (ny >> 12)) | ~in2) & 0x55u;
 	nmap = FORWARD ? nb : nb << 1;
+}
+template <bool FORWARD>
+__device__ __forceinline__ void pack4(unsigned x, unsigned y, int cnt, unsigned &codes, unsigned &nmap, unsigned &weird, unsigned &skip4, unsigned &q4) {
+	pack4m<FORWARD>(x, y, (unsigned) ((0xFFFFFFFFull << (8 * cnt)) >> 32), (1u << (2 * cnt)) - 1u, codes, nmap, weird, skip4, q4);
 }
 
 // which of four bases count in the primer scan's filter (bit 2k+1): a definite base of quality >= qthr that exists; an N,
@@ -334,19 +359,31 @@ __device__ __forceinline__ unsigned is2_mask(unsigned q4) {	// bit k: quality by
 	return (((t >> 7) * 0x00204081u) >> 21) & 0xFu;
 }
 
-// Writes the row, its code stream and N map (and, PRIM, its 4-bit nt stream) to LDS; returns the B-cliff length.
-template <bool FORWARD, bool PRIM>
-__device__ __forceinline__ int stage8(const uint4 v, const int len, int lane, unsigned char *wb, unsigned &weird, unsigned qadd) {
-	typedef Lay<true> L;
-	if (lane < 40)
-		reinterpret_cast<uint4 *>(wb + (FORWARD ? L::F : L::R))[lane] = v;
+// (FK_LEN_MASKS, eight bases per lane: the two halves' masks)
+struct LenMasks8 {
+	int len;
+	unsigned bm0, in0, bm1, in1;
+};
+__device__ __forceinline__ void len_masks8(LenMasks8 &m, int len, int lane) {
 	int c0 = len - 8 * lane;
 	int c1 = c0 - 4;
 	c0 = c0 < 0 ? 0 : (c0 > 4 ? 4 : c0);
 	c1 = c1 < 0 ? 0 : (c1 > 4 ? 4 : c1);
+	m.bm0 = (unsigned) ((0xFFFFFFFFull << (8 * c0)) >> 32);
+	m.in0 = (1u << (2 * c0)) - 1u;
+	m.bm1 = (unsigned) ((0xFFFFFFFFull << (8 * c1)) >> 32);
+	m.in1 = (1u << (2 * c1)) - 1u;
+	m.len = len;
+}
+// Writes the row, its code stream and N map (and, PRIM, its 4-bit nt stream) to LDS; returns the B-cliff length.
+template <bool FORWARD, bool PRIM>
+__device__ __forceinline__ int stage8(const uint4 v, const int len, int lane, unsigned char *wb, unsigned &weird, unsigned qadd, const LenMasks8 &lm) {
+	typedef Lay<true> L;
+	if (lane < 40)
+		reinterpret_cast<uint4 *>(wb + (FORWARD ? L::F : L::R))[lane] = v;
 	unsigned ca, na, n4a, q4a, cb, nb, n4b, q4b;
-	pack4<FORWARD>(v.x, v.y, c0, ca, na, weird, n4a, q4a);
-	pack4<FORWARD>(v.z, v.w, c1, cb, nb, weird, n4b, q4b);
+	pack4m<FORWARD>(v.x, v.y, lm.bm0, lm.in0, ca, na, weird, n4a, q4a);
+	pack4m<FORWARD>(v.z, v.w, lm.bm1, lm.in1, cb, nb, weird, n4b, q4b);
 	if (lane < 48) {	// (lanes past the row: all N)
 		reinterpret_cast<uint16_t *>(wb + (FORWARD ? L::FC : L::RC))[lane] = (uint16_t) (ca | (cb << 8));
 		reinterpret_cast<uint16_t *>(wb + (FORWARD ? L::FN : L::RN))[lane] = (uint16_t) (na | (nb << 8));
@@ -500,7 +537,8 @@ __device__ __forceinline__ unsigned primer_tier1(unsigned code_addr, unsigned ca
 // exactly one alignment has none and its value leaves every other alignment a budget of zero.  On config 2's reads a primer base
 // of quality 2 or two of quality 8 -- a read in three -- leave late alignments a budget of one or two and the pass is wasted:
 // 22 vector instructions fewer per pair of 1 236, 125 scalar ones more of 595 (the five masks' validity, counts and index):
-// -2.6 %, profiles/r06_experiments_ab.txt.  A scalar instruction costs a wave what a vector one does.)
+// -2.6 %, profiles/r06_experiments_ab.txt.  Scalar work is not free at four waves a SIMD: 0.6-0.8 cycles an instruction beside a
+// 4.2-cycle vector one, and a dependent chain of it is latency the wave's vector work queues behind.)
 // The sums of one alignment of each read at once, in ANY order (|error| < 1e-12: good for a bound and for a verdict with
 // a margin; values that are compared with each other are summed in the reference's order, primer_exact): lanes 0..31 look up
 // the terms of the forward read's alignment s0f (lane x: primer base x), lanes 32..63 those of the reverse read's s0r; no
@@ -1524,7 +1562,7 @@ struct HotArgs {
 // POST (LONG only): `-a`, the primers are looked for in the merged sequence and cut off it (reference-order sums since round 5:
 // `quality` is the whole merge's, assembler.c:244 precedes the clipping, and comes from the group walk like any other row's)
 template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW, bool POST>
-__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, const unsigned char *places, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases, uint16_t *xs, const HotArgs &H, bool &flags_dirty, unsigned &epoch) {
+__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, const unsigned char *places, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases, uint16_t *xs, const HotArgs &H, bool &flags_dirty, unsigned &epoch, std::conditional_t<LONG, LenMasks8, LenMasks> &lmf, std::conditional_t<LONG, LenMasks8, LenMasks> &lmr) {
 	typedef Lay<LONG> L;
 	constexpr int BPL = NARROW ? 3 : L::BPL;
 	constexpr bool WINDOWS = BPL != 4;	// k-mers from unaligned words of the code streams (else from the neighbouring lanes' registers)
@@ -1574,11 +1612,21 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		int uf, ur;
 		if constexpr (LONG) {
 			const unsigned qadd = (unsigned) (0x80 - P.primer_qthr) * 0x01010101u;
-			uf = stage8<true, PRIM>(fv, flen, lane, wb, weird, qadd);
-			ur = stage8<false, PRIM>(rv, rlen, lane, wb, weird, qadd);
+			if (!FK_LEN_MASKS || flen != lmf.len)
+				len_masks8(lmf, flen, lane);
+			if (!FK_LEN_MASKS || rlen != lmr.len)
+				len_masks8(lmr, rlen, lane);
+			uf = stage8<true, PRIM>(fv, flen, lane, wb, weird, qadd, lmf);
+			ur = stage8<false, PRIM>(rv, rlen, lane, wb, weird, qadd, lmr);
 		} else {
-			uf = stage<true>(fv, flen, lane, wb, fcodes, fnm, weird);
-			ur = stage<false>(rv, rlen, lane, wb, rcodes, rnm, weird);
+#if FK_LEN_MASKS
+			if (flen != lmf.len)
+				len_masks(lmf, flen, lane);
+			if (rlen != lmr.len)
+				len_masks(lmr, rlen, lane);
+#endif
+			uf = stage<true>(fv, flen, lane, wb, fcodes, fnm, weird, lmf);
+			ur = stage<false>(rv, rlen, lane, wb, rcodes, rnm, weird, lmr);
 		}
 		if (__builtin_expect(ballot(weird != 0) != 0, 0)) {	// an IUPAC ambiguity code, nt 0, a quality outside 0..46: the general kernel's pair
 			note(P, 0, lane);
@@ -1761,7 +1809,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 #pragma unroll
 				for (int j = 0; j < BPL; j++)
 					addr[j] = lshl_add<2>(__builtin_amdgcn_ubfe(mul24(carry[j] >> 9, HASH_C), 14, 8), l2);
-				insert_all_live<BPL>(addr, carry, limit);
+				insert_all_live<BPL>(addr, carry, limit);	// (the second table without the test: eight vector instructions fewer, and -1.5 %: its 256 slots take 256 atomics a pair badly)
 			} else {
 #pragma unroll
 				for (int j = 0; j < BPL; j++) {
@@ -2380,6 +2428,8 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 					}
 				}
 #ifndef FK_NO_COUNTS
+				// (measured and not kept, round 6: counted after the merge, from the staged row, and only for pairs one of whose reads holds
+				// an N -- nine pairs in ten of config 1 do, two or three bases of 500: -6 %)
 				degen += __popcll(ballot((ntv[k] & 0xFFu) == 15u));	// PANDA_NT_IS_DEGN: only N here
 #endif
 			}
@@ -2680,6 +2730,7 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 	bool deep_dirty = true;	// the first pair clears all four tables
 	bool flags_dirty = true;	// ... and the candidate flags
 	unsigned epoch = 0;	// FK_EPOCH: the epoch of the words the last pair wrote (0: the next pair clears the tables and starts over at 126)
+	std::conditional_t<LONG, LenMasks8, LenMasks> lmf = { -1 }, lmr = { -1 };	// FK_LEN_MASKS
 	HotArgs H = { P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.threshold, P.seq_stride, P.seq_capacity, P.seq_nt, P.seq_p };
 #if FK_KARGS
 	asm volatile("" : "+s"(H.qual_nn), "+s"(H.pmatch), "+s"(H.pmismatch), "+s"(H.threshold), "+s"(H.stride), "+s"(H.capacity), "+s"(H.nt), "+s"(H.p));
@@ -2710,7 +2761,7 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 			// here, the lane number's derivatives are recomputed where they are used (an instruction or two each).
 			asm volatile("" : "+v"(lane_now));
 		}
-		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST>(P, ltab, places, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases, EXACT ? xs + (unsigned) xg * fk_xstride<LONG, XSCORE>() : nullptr, H, flags_dirty, epoch);
+		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST>(P, ltab, places, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases, EXACT ? xs + (unsigned) xg * fk_xstride<LONG, XSCORE>() : nullptr, H, flags_dirty, epoch, lmf, lmr);
 		MARK("loop");
 		npend++;
 		if (EXACT && ++xg == XG) {	// sums in the reference's order: a group of pairs is complete

@@ -690,7 +690,8 @@ __device__ __attribute__((noinline)) Redone redo_pair(const PamdKernelParams *ke
 	WaveArena arena;
 	arena.cur = arena_cur;
 	arena.end = arena_end;
-	fast_pair<ALGO, false, false, false, false, true, false>(P, ltab, nullptr, wb, arena, out.pd, slot, tables_dirty, pair, lane, flen, rlen, one, one, 0u, nullptr, H, flags_dirty, epoch);
+	LenMasks lmf = { -1, 0u, 0u }, lmr = { -1, 0u, 0u };
+	fast_pair<ALGO, false, false, false, false, true, false>(P, ltab, nullptr, wb, arena, out.pd, slot, tables_dirty, pair, lane, flen, rlen, one, one, 0u, nullptr, H, flags_dirty, epoch, lmf, lmr);
 	out.arena_cur = arena.cur;
 	out.arena_end = arena.end;
 	return out;

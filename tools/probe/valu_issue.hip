@@ -217,6 +217,13 @@ DEFK32(v_mbcnt_lo, SAME8(F_MBCNT))
 // one fast and one slow class interleaved 1 : 1 -- do they share one issue budget?
 DEFK32(v_add_u32_plus_v_perm_1to1, F_ADD("%0"), F_PERM("%1"), F_ADD("%2"), F_PERM("%3"), F_ADD("%4"), F_PERM("%5"), F_ADD("%6"), F_PERM("%7"))
 DEFK32(v_add_u32_plus_v_add_f64_like_min, F_ADD("%0"), F_MIN("%1"), F_ADD("%2"), F_MIN("%3"), F_ADD("%4"), F_MIN("%5"), F_ADD("%6"), F_MIN("%7"))
+// ... and in runs: do two fast ones side by side get their short slots back?
+DEFK32(v_add_x2_plus_v_perm_x2, F_ADD("%0"), F_ADD("%1"), F_PERM("%2"), F_PERM("%3"), F_ADD("%4"), F_ADD("%5"), F_PERM("%6"), F_PERM("%7"))
+DEFK32(v_add_x4_plus_v_perm_x4, F_ADD("%0"), F_ADD("%1"), F_ADD("%2"), F_ADD("%3"), F_PERM("%4"), F_PERM("%5"), F_PERM("%6"), F_PERM("%7"))
+DEFK32(v_add_x3_plus_v_perm_x1, F_ADD("%0"), F_ADD("%1"), F_ADD("%2"), F_PERM("%3"), F_ADD("%4"), F_ADD("%5"), F_ADD("%6"), F_PERM("%7"))
+// a vector instruction of the slow class and a scalar one, 1 : 1 and 3 : 1 -- does the scalar one ride along?
+DEFK32(v_perm_plus_s_add_1to1, F_PERM("%0"), F_SADD("40"), F_PERM("%1"), F_SADD("41"), F_PERM("%2"), F_SADD("42"), F_PERM("%3"), F_SADD("43"))
+DEFK32(v_perm_x3_plus_s_add, F_PERM("%0"), F_PERM("%1"), F_PERM("%2"), F_SADD("40"), F_PERM("%3"), F_PERM("%4"), F_PERM("%5"), F_SADD("41"))
 
 typedef void (*kern_t)(Rec *, unsigned *, int);
 struct Class {
@@ -235,6 +242,7 @@ static const Class classes[] = {
 	C(v_add_u32_literal, 64), C(v_and_b32_literal, 64), C(v_add_u32_inline, 64), C(v_add_u32_sgpr, 64), C(v_add_u32_e64, 64), C(v_add_co_u32, 64), C(v_mul_u32_u24, 64), C(v_cndmask_vcc, 64), C(v_bfi_b32, 64), C(v_add3_u32, 64),
 	C(v_or3_b32, 64), C(v_bfrev_b32, 64), C(v_bcnt_u32_b32, 64), C(v_ffbh_u32, 64), C(v_add_f32, 64), C(v_mul_f32, 64), C(v_fma_f32, 64), C(v_fmac_f32, 64), C(v_cvt_f32_u32, 64), C(v_rcp_f32, 64), C(v_cmp_vcc_only, 64),
 	C(v_writelane, 64), C(v_mbcnt_lo, 64), C(v_add_u32_plus_v_perm_1to1, 64), C(v_add_u32_plus_v_add_f64_like_min, 64),
+	C(v_add_x2_plus_v_perm_x2, 64), C(v_add_x4_plus_v_perm_x4, 64), C(v_add_x3_plus_v_perm_x1, 64), C(v_perm_plus_s_add_1to1, 64), C(v_perm_x3_plus_s_add, 64),
 	C(ds_read_b32, 64), C(ds_read_u16, 64), C(ds_read_b64, 64), C(ds_read_b64_gather, 64), C(ds_write_b32, 64), C(ds_min_rtn_u32, 64), C(v_add_x6_plus_ds_read_x2, 64),
 };
 
