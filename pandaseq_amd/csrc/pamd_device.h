@@ -218,12 +218,16 @@ __device__ __forceinline__ double ordered_row_sum(const double *row, int lo, int
 // EXACTQ (the lean kernel with exact sums): the quality sums are made here, in the reference's order, every lane walking
 // the three chains of its own pair's row (which this wave wrote; pd.pid says where the overlap region begins and ends).
 // QUEUED: the pairs' indices are in pd.pid (the wave took them from a work queue).
-template <bool LIST, bool DEFER, bool EXACTQ = false, bool QUEUED = false>
-__device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64 &pd, int npend, u64 first_pair, u64 pair_step, int lane) {
+// LAZYQ (the lean kernel's any-order sums, pamd_fast.hip qsum_insert()): the s-th parked pair sits in lane bitrev6(s) -- that is
+// where the merge tree of the pairs' quality sums leaves its sum --, and the test "is the quality too close to the LOWQ threshold
+// to call from a sum in any order" is made here, for 64 pairs at once: such a pair is deferred.
+template <bool LIST, bool DEFER, bool EXACTQ = false, bool QUEUED = false, bool LAZYQ = false>
+__device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64 &pd, int npend, u64 first_pair, u64 pair_step, int lane_id) {
 	int status = -1, reject = -1;
 	bool slow = false;
 	if (EXACTQ)
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// this wave's row stores have reached L2
+	const int lane = LAZYQ ? (int) (__builtin_bitreverse32((unsigned) lane_id) >> 26) : lane_id;	// which parked pair this lane finishes
 	u64 pair = first_pair + (u64) lane * pair_step;
 	if (QUEUED)
 		pair = (u64) pd.pid;
@@ -232,14 +236,28 @@ __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64
 	bool deferred = false;
 	if (DEFER) {
 		deferred = lane < npend && ((pd.ro_st >> 16) & 0xFFu) == (unsigned) PAMD_ST_DEFER;
+		if (LAZYQ) {
+			union {
+				double d;
+				unsigned u[2];
+			} qs;
+			qs.u[0] = pd.q_lo;
+			qs.u[1] = pd.q_hi;
+			const double len1 = (double) ((int) (pd.len_bo & 0xFFFFu) + 1);
+			const bool close = lane < npend && ((pd.ro_st >> 16) & 0xFFu) == (unsigned) PAMD_ST_OK && fabs(qs.d - P.threshold * len1) <= 1e-9 * len1;
+			const u64 cmask = ballot(close);
+			if (cmask != 0 && lane_id == 0 && P.phase_cycles != nullptr)
+				atomicAdd(&P.phase_cycles[4], (unsigned long long) __popcll(cmask));
+			deferred |= close;	// (its row stays behind in the arena as a hole)
+		}
 		const u64 dmask = ballot(deferred);
 		if (dmask != 0) {
 			unsigned base = 0;
-			if (lane == 0)
+			if (lane_id == 0)
 				base = atomicAdd(P.defer_count, (unsigned) __popcll(dmask));
 			base = (unsigned) uni((int) base);
 			if (deferred)
-				P.defer_list[base + (unsigned) __popcll(dmask & ((1ull << lane) - 1ull))] = (uint32_t) pair;
+				P.defer_list[base + (unsigned) __popcll(dmask & ((1ull << lane_id) - 1ull))] = (uint32_t) pair;
 		}
 	}
 	if (lane < npend && !deferred) {
@@ -318,12 +336,12 @@ __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64
 #pragma unroll
 	for (int st = 0; st < 6; st++) {
 		const int c = __popcll(ballot(status == st));
-		if (c != 0 && lane == 0)
+		if (c != 0 && lane_id == 0)
 			atomicAdd(&lctr[ctr_of[st]], (unsigned) c);
 	}
 	const int nslow = __popcll(ballot(slow));
 	const int ndefer = DEFER ? __popcll(ballot(deferred)) : 0;
-	if (lane == 0) {
+	if (lane_id == 0) {
 		atomicAdd(&lctr[PAMD_CTR_COUNT], (unsigned) (npend - ndefer));
 		if (nslow)
 			atomicAdd(&lctr[PAMD_CTR_SLOW], (unsigned) nslow);

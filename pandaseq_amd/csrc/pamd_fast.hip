@@ -1547,6 +1547,99 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 #define DEBUG_DUMP(...)
 #endif
 
+// FK_LAZYQ (any-order sums, short geometry): a pair's quality sum is not reduced over the wave when the pair is done -- six DPP steps,
+// twenty vector instructions -- but merged with the other pairs' of its group of 64 in a binary tree: two vectors of 64 partial sums
+// become one that holds 32 of each, two of those one that holds 16 of four pairs each, ... and after the 64th pair one vector holds
+// the 64 pairs' sums, one per lane: 63 merges for 64 pairs.  The two levels that merge most often go through v_permlane32_swap /
+// v_permlane16_swap (two swaps and an add); the rest through DPP moves with bank masks or quad permutations (seven instructions,
+// seven times in 64 pairs).  A level merges along one bit of the lane number: the s-th pair's sum ends in lane bitrev6(s), which
+// is where park() puts the pair's other scalars and where finish64<.., LAZYQ> looks for them.
+#ifndef FK_LAZYQ
+#define FK_LAZYQ 1
+#endif
+struct QTree {
+	double lvl[6];	// level L: the merged partial sums of 2^L pairs, waiting for the next 2^L (held while bit L of the slot count is set)
+};
+union F64Pair {
+	double d;
+	unsigned u[2];
+};
+// one vector from two: lanes whose bit D is clear keep x[i] + x[i ^ D], the others y[i] + y[i ^ D]
+template <int D>
+__device__ __forceinline__ double qsum_merge(double xd, double yd, int lane) {
+	F64Pair x, y, t, w;
+	x.d = xd;
+	y.d = yd;
+	if constexpr (D == 32 || D == 16) {
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			// (D = 32: the upper half of x trades places with the lower half of y; D = 16: x's odd rows with y's even rows)
+			const auto r = D == 32 ? __builtin_amdgcn_permlane32_swap(x.u[k], y.u[k], false, false) : __builtin_amdgcn_permlane16_swap(x.u[k], y.u[k], false, false);
+			t.u[k] = r[0];
+			w.u[k] = r[1];
+		}
+	} else if constexpr (D == 8) {
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			unsigned v = (unsigned) __builtin_amdgcn_update_dpp(0, (int) y.u[k], 0x128, 0xF, 0xF, false);	// row_ror:8, every lane: y's other half-row
+			v = (unsigned) __builtin_amdgcn_update_dpp((int) v, (int) x.u[k], 0x128, 0xF, 0x3, false);	// ... lanes 0-7 of a row: x's
+			w.u[k] = v;
+			t.u[k] = (unsigned) __builtin_amdgcn_update_dpp((int) x.u[k], (int) y.u[k], 0xE4, 0xF, 0xC, false);	// x, lanes 8-15 of a row from y
+		}
+	} else if constexpr (D == 4) {
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			unsigned v = (unsigned) __builtin_amdgcn_update_dpp(0, (int) x.u[k], 0x104, 0xF, 0x5, false);	// row_shl:4 into banks 0 and 2: x[i + 4]
+			v = (unsigned) __builtin_amdgcn_update_dpp((int) v, (int) y.u[k], 0x114, 0xF, 0xA, false);	// row_shr:4 into banks 1 and 3: y[i - 4]
+			w.u[k] = v;
+			t.u[k] = (unsigned) __builtin_amdgcn_update_dpp((int) x.u[k], (int) y.u[k], 0xE4, 0xF, 0xA, false);	// x, banks 1 and 3 from y
+		}
+	} else {
+		const bool up = (lane & D) != 0;
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			const unsigned moving = up ? x.u[k] : y.u[k];	// x's upper and y's lower lanes of each pair of lanes
+			w.u[k] = (unsigned) __builtin_amdgcn_update_dpp(0, (int) moving, D == 2 ? 0x4E : 0xB1, 0xF, 0xF, false);	// quad_perm [2,3,0,1] / [1,0,3,2]
+			t.u[k] = up ? y.u[k] : x.u[k];
+		}
+	}
+	return t.d + w.d;
+}
+// the s-th pair of a group of 64 hands in its 64 partial sums; true when the group's sums are complete (s == 63): they are `q`'s
+__device__ __forceinline__ bool qsum_insert(QTree &qt, int s, double q, int lane, double &out) {
+	if ((s & 1) == 0) {
+		qt.lvl[0] = q;
+		return false;
+	}
+	q = qsum_merge<32>(qt.lvl[0], q, lane);
+	if ((s & 2) == 0) {
+		qt.lvl[1] = q;
+		return false;
+	}
+	q = qsum_merge<16>(qt.lvl[1], q, lane);
+	if ((s & 4) == 0) {
+		qt.lvl[2] = q;
+		return false;
+	}
+	q = qsum_merge<8>(qt.lvl[2], q, lane);
+	if ((s & 8) == 0) {
+		qt.lvl[3] = q;
+		return false;
+	}
+	q = qsum_merge<4>(qt.lvl[3], q, lane);
+	if ((s & 16) == 0) {
+		qt.lvl[4] = q;
+		return false;
+	}
+	q = qsum_merge<2>(qt.lvl[4], q, lane);
+	if ((s & 32) == 0) {
+		qt.lvl[5] = q;
+		return false;
+	}
+	out = qsum_merge<1>(qt.lvl[5], q, lane);
+	return true;
+}
+
 // launch parameters every pair needs, read ONCE per wave into scalar registers (FK_KARGS): left as kernel arguments, the compiler
 // re-reads them from the argument segment inside the pair loop -- three of the five scalar loads per pair with their wait right
 // behind them (the counter is shared with the LDS reads that follow: the wait cannot be put off)
@@ -1561,9 +1654,12 @@ struct HotArgs {
 // NARROW (short geometry only): reads of at most 192 bases seed three bases per lane, on windows of the code streams
 // POST (LONG only): `-a`, the primers are looked for in the merged sequence and cut off it (reference-order sums since round 5:
 // `quality` is the whole merge's, assembler.c:244 precedes the clipping, and comes from the group walk like any other row's)
-template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW, bool POST>
-__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, const unsigned char *places, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases, uint16_t *xs, const HotArgs &H, bool &flags_dirty, unsigned &epoch, std::conditional_t<LONG, LenMasks8, LenMasks> &lmf, std::conditional_t<LONG, LenMasks8, LenMasks> &lmr) {
+template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW, bool POST, bool LAZYQ = false>
+__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, const unsigned char *places, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases, uint16_t *xs, const HotArgs &H, bool &flags_dirty, unsigned &epoch, std::conditional_t<LONG, LenMasks8, LenMasks> &lmf, std::conditional_t<LONG, LenMasks8, LenMasks> &lmr, double *qlane = nullptr) {
 	typedef Lay<LONG> L;
+	static_assert(!LAZYQ || (!EXACT && !POST), "the merge tree holds sums in any order, of whole rows");
+	if constexpr (LAZYQ)
+		*qlane = 0.0;	// (a pair that does not get as far as its row hands in nothing)
 	constexpr int BPL = NARROW ? 3 : L::BPL;
 	constexpr bool WINDOWS = BPL != 4;	// k-mers from unaligned words of the code streams (else from the neighbouring lanes' registers)
 	static_assert(!NARROW || !LONG, "three bases per lane belong to the short geometry");
@@ -2584,7 +2680,9 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 			if (seqlen <= 0)
 				phmin = 127;	// an empty row passes any threshold
 		}
-		if (!EXACT) {
+		if constexpr (LAZYQ) {
+			*qlane = qacc;	// this lane's share; the wave's sum comes out of the group's merge tree, the LOWQ guard is finish64's
+		} else if (!EXACT) {
 			qsum = wave_sum_any_order(qacc);	// divided by len in finish64() ...
 			// ... unless the quotient could land within 1e-9 of the LOWQ threshold (tested without dividing): the general
 			// kernel then makes the three sums in reference order (assembler.c:171,226,236,244,334)
@@ -2627,6 +2725,16 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	const unsigned f_dg_fo = (unsigned) degen | ((unsigned) fo << 16);
 	// (POST: bit 25, "the quality is final": finish64 does not divide it by the clipped length)
 	const unsigned f_ro_st = (unsigned) ro | ((unsigned) status << 16) | ((unsigned) slow << 24) | (POST ? 1u << 25 : 0u) | ((unsigned) (phmin > 63 ? 63 : phmin) << 26);
+	if constexpr (LAZYQ) {	// (the quality sums come out of the merge tree, in lane bitrev6(slot): the other scalars go there too)
+		slot_idx = (int) (__builtin_bitreverse32((unsigned) slot_idx) >> 26);
+		asm volatile("s_mov_b32 m0, %4\n\t"
+			     "v_writelane_b32 %0, %5, m0\n\t"
+			     "v_writelane_b32 %1, %6, m0\n\t"
+			     "v_writelane_b32 %2, %7, m0\n\t"
+			     "v_writelane_b32 %3, %8, m0"
+			     : "+v"(pd.off_lo), "+v"(pd.off_hi), "+v"(pd.b_lo), "+v"(pd.b_hi)
+			     : "s"(slot_idx), "s"(uni((int) (unsigned) off)), "s"(uni((int) (unsigned) (off >> 32))), "s"(uni((int) bb.u[0])), "s"(uni((int) bb.u[1])));
+	} else
 	asm volatile("s_mov_b32 m0, %6\n\t"
 		     "v_writelane_b32 %0, %7, m0\n\t"
 		     "v_writelane_b32 %1, %8, m0\n\t"
@@ -2731,6 +2839,9 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 	bool flags_dirty = true;	// ... and the candidate flags
 	unsigned epoch = 0;	// FK_EPOCH: the epoch of the words the last pair wrote (0: the next pair clears the tables and starts over at 126)
 	std::conditional_t<LONG, LenMasks8, LenMasks> lmf = { -1 }, lmr = { -1 };	// FK_LEN_MASKS
+	constexpr bool LQ = FK_LAZYQ != 0 && !EXACT && !POST && !LONG;	// (the LONG geometry has no registers for the tree's six levels)
+	static_assert(!LQ || F == 64u, "the merge tree closes after 64 pairs");
+	QTree qt;
 	HotArgs H = { P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.threshold, P.seq_stride, P.seq_capacity, P.seq_nt, P.seq_p };
 #if FK_KARGS
 	asm volatile("" : "+s"(H.qual_nn), "+s"(H.pmatch), "+s"(H.pmismatch), "+s"(H.threshold), "+s"(H.stride), "+s"(H.capacity), "+s"(H.nt), "+s"(H.p));
@@ -2761,15 +2872,23 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 			// here, the lane number's derivatives are recomputed where they are used (an instruction or two each).
 			asm volatile("" : "+v"(lane_now));
 		}
-		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST>(P, ltab, places, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases, EXACT ? xs + (unsigned) xg * fk_xstride<LONG, XSCORE>() : nullptr, H, flags_dirty, epoch, lmf, lmr);
+		double qlane;
+		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST, LQ>(P, ltab, places, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases, EXACT ? xs + (unsigned) xg * fk_xstride<LONG, XSCORE>() : nullptr, H, flags_dirty, epoch, lmf, lmr, &qlane);
 		MARK("loop");
+		if constexpr (LQ) {
+			F64Pair sums;
+			if (qsum_insert(qt, npend, qlane, lane, sums.d)) {
+				pd.q_lo = sums.u[0];
+				pd.q_hi = sums.u[1];
+			}
+		}
 		npend++;
 		if (EXACT && ++xg == XG) {	// sums in the reference's order: a group of pairs is complete
 			take_group(npend - XG, XG);
 			xg = 0;
 		}
 		if (npend == (int) F) {
-			finish64<false, true, false>(P, lctr, pd, npend, group_first, step_in, lane);
+			finish64<false, true, false, false, LQ>(P, lctr, pd, npend, group_first, step_in, lane);
 			npend = 0;
 			group_first = next;
 		}
@@ -2777,8 +2896,17 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 	}
 	if (EXACT && xg != 0)
 		take_group(npend - xg, xg);
-	if (npend > 0)
-		finish64<false, true, false>(P, lctr, pd, npend, group_first, step_in, lane);
+	if (npend > 0) {
+		if constexpr (LQ) {	// the last group is not full: the tree is closed with pairs that hand in nothing
+			F64Pair sums;
+			sums.d = 0.0;
+			for (int s = npend; s < 64; s++)
+				qsum_insert(qt, s, 0.0, lane, sums.d);
+			pd.q_lo = sums.u[0];
+			pd.q_hi = sums.u[1];
+		}
+		finish64<false, true, false, false, LQ>(P, lctr, pd, npend, group_first, step_in, lane);
+	}
 	__syncthreads();
 	if (P.counters != nullptr) {
 		for (unsigned i = tid; i < PAMD_NUM_COUNTERS; i += blockDim.x) {
