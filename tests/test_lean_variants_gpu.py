@@ -202,3 +202,37 @@ def test_two_pairs_per_wave(built, algo):
         asm.assemble_device(b)
         torch.cuda.synchronize()
         assert "dual" not in asm.last_lean_variant() and asm.last_lean_variant() != "general"
+
+
+@pytest.mark.parametrize("cfg", [1, 4])
+def test_quality_sums_through_the_merge_tree(built, cfg):
+    """Any-order sums in the short geometry (pamd_fast.hip FK_LAZYQ): a pair's quality sum comes out of a merge tree over the 64
+    pairs a wave parks between two finishes, in lane bitrev6(slot), and a wave's last group is closed with pairs that hand in
+    nothing.  Launches in which every wave's pairs fill its groups to every level of the tree -- 1, 2, 3, 5, 17, 31 .. 33 and
+    63 .. 66 pairs per wave, a quarter of the waves one more -- against the oracle: every record (statuses and counts exactly,
+    the two summed doubles within the any-order tolerance), the LOWQ verdicts among them, and all counters."""
+    import torch
+    import pandaseq_amd as pa
+    from oracle import pyoracle as po
+    from pandaseq_amd import synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import compare_counters, compare_results
+    spec = synth.config_spec(cfg)
+    waves = 4096      # (256 workgroups of 16 waves; small launches hand pairs out strided, wave w takes w, w + 4096, ..)
+    ocfg = po.make_config("simple_bayesian")
+    for k in (1, 2, 3, 5, 17, 31, 32, 33, 63, 64, 65, 66):
+        n = waves * k + waves // 4 + 7
+        fwd, rev, flen, rlen = synth.generate_host(spec, 31_000_000 + 1000 * k, n)
+        o_res, _, _, o_ctr = po.assemble_batch(ocfg, fwd, rev, flen, rlen, want_seq=False, threads=os.cpu_count() or 1)
+        asm = pa.Assembler(0)
+        asm.set_algorithm("simple_bayesian")
+        asm.set_exact_sums(False)
+        b = pa.upload_batch(fwd, rev, flen, rlen, device="cuda:0", seq_stride=0, capacity=n * (520 if cfg == 1 else 330) + (1 << 26))
+        asm.assemble_device(b)
+        torch.cuda.synchronize()
+        asm.check_overflow()
+        assert asm.last_lean_variant() == ("short" if cfg == 1 else "short+narrow")
+        info = asm.last_launch_info()
+        assert info["workgroups"] * info["waves_per_workgroup"] == waves, info
+        compare_results(b.results_numpy(), None, None, o_res, None, None, exact_sums=False, check_seq=False)
+        compare_counters(b.counters_dict(), o_ctr)
