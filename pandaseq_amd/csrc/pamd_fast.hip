@@ -3015,7 +3015,11 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	void (*kern)(const PamdKernelParams) = nullptr;
 	const int variant = pamd_fast_supports(p);
+#ifdef FK_NO_NARROW	/* measurement: reads of at most 192 bases in the geometry of four bases per lane */
+	const bool narrow = false;
+#else
 	const bool narrow = p.smax <= 192;	// three bases per lane cover the reads
+#endif
 #define FK_PICK3(A, PH, E) (narrow ? pamd_fast_kernel<A, E, PH, false, false, true> : pamd_fast_kernel<A, E, PH, false, false, false>)
 #define FK_PICK4(A, PH, E) (variant == PAMD_FAST_LONG ? pamd_fast_kernel<A, E, PH, true, false, false> : pamd_fast_kernel<A, E, PH, true, true, false>)
 #define FK_PICK2(A, PH) (variant == PAMD_FAST_POST ? (p.exact_sums ? pamd_fast_kernel<A, true, PH, true, false, false, true> : pamd_fast_kernel<A, false, PH, true, false, false, true>) \
