@@ -29,10 +29,15 @@ ap.add_argument("--no-compare", action="store_true")
 ap.add_argument("--primers-after", action="store_true", help="`-a` (config 2 has primers)")
 ap.add_argument("--min-phred", type=int, default=2)
 ap.add_argument("--only", default=None, help="two-kernel or general: run just that mode (implies --no-compare)")
+ap.add_argument("--read-len", type=int, default=int(os.environ.get("PAMD_PROBE_READ_LEN", "0")), help="shorter reads in the configuration's rows (the stride stays): what idle lanes cost")
 args = ap.parse_args()
 
 n = args.pairs
 spec = synth.config_spec(args.config)
+if args.read_len:
+    import dataclasses
+    cut = spec.read_len - args.read_len
+    spec = dataclasses.replace(spec, read_len=args.read_len, stride=spec.row_stride(), tmin=spec.tmin - cut, tmax=spec.tmax - 2 * cut if spec.tmax - 2 * cut > spec.tmin - cut else spec.tmin - cut + 40)
 f, r, fl, rl = synth.generate_device(spec, 0, n)
 out = {}
 if args.only:
