@@ -175,6 +175,7 @@ struct Pend64 {
 	unsigned ro_st;			// reverse offset | status << 16 | slow << 24 | "q is final" << 25 | smallest phred (63 = none) << 26
 	unsigned pid;			// the pair's index, where a wave takes its pairs from a work queue (general kernel); the lean kernel with
 					// exact sums: where the row's overlap region begins | ends << 16
+	unsigned p_lo, p_hi;		// (finish64<.., LAZYP>) the row's smallest log-p above qual_score[0]
 };
 
 __device__ __forceinline__ unsigned put_lane(unsigned reg, unsigned value, bool mine) {
@@ -221,8 +222,10 @@ __device__ __forceinline__ double ordered_row_sum(const double *row, int lo, int
 // LAZYQ (the lean kernel's any-order sums, pamd_fast.hip qsum_insert()): the s-th parked pair sits in lane bitrev6(s) -- that is
 // where the merge tree of the pairs' quality sums leaves its sum --, and the test "is the quality too close to the LOWQ threshold
 // to call from a sum in any order" is made here, for 64 pairs at once: such a pair is deferred.
-template <bool LIST, bool DEFER, bool EXACTQ = false, bool QUEUED = false, bool LAZYQ = false>
-__device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64 &pd, int npend, u64 first_pair, u64 pair_step, int lane_id) {
+// LAZYP (with LAZYQ and a min_phred module): pd.p_lo / p_hi hold the row's smallest log-p above qual_score[0] (out of a merge tree
+// of its own), bit 26 of pd.ro_st says whether one lay at or below it; the phred (nt.c:126-150) is looked up here, in `score`.
+template <bool LIST, bool DEFER, bool EXACTQ = false, bool QUEUED = false, bool LAZYQ = false, bool LAZYP = false>
+__device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64 &pd, int npend, u64 first_pair, u64 pair_step, int lane_id, const double *score = nullptr) {
 	int status = -1, reject = -1;
 	bool slow = false;
 	if (EXACTQ)
@@ -304,7 +307,23 @@ __device__ void finish64(const PamdKernelParams &P, unsigned *lctr, const Pend64
 			if (quality < P.threshold) {	// assembler.c:334-338
 				status = PAMD_ST_LOWQ;
 			} else {
-				const int ph6 = (int) (pd.ro_st >> 26), phmin = ph6 == 63 ? 127 : ph6;
+				int phmin;
+				if (LAZYP) {
+					union {
+						double d;
+						unsigned u[2];
+					} pm;
+					pm.u[0] = pd.p_lo;
+					pm.u[1] = pd.p_hi;
+					phmin = result_phred(score, pm.d);
+					if (((pd.ro_st >> 26) & 1u) != 0 && phmin > 1)
+						phmin = 1;
+					if (seqlen <= 0)
+						phmin = 127;	// an empty row passes any threshold
+				} else {
+					const int ph6 = (int) (pd.ro_st >> 26);
+					phmin = ph6 == 63 ? 127 : ph6;
+				}
 				for (int mi = 0; mi < P.n_modules && reject < 0; mi++) {	// module.c:124-136
 					const PamdModule md = P.modules[mi];
 					if (md.kind == 1) {	// plugin_min_phred.c:8-22

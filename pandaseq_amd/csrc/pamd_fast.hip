@@ -1560,6 +1560,13 @@ __device__ __forceinline__ void debug_dump(const PamdKernelParams &P, const unsi
 #ifndef FK_LAZYQ
 #define FK_LAZYQ 1
 #endif
+// FK_LAZYP (with FK_LAZYQ, a min_phred module): the row's smallest log-p goes through a merge tree of its own (minimum instead of
+// sum) and becomes a phred in finish64, 64 pairs at once: the six DPP steps, the lookup of its place among the score table's values
+// and that lookup's two LDS round trips leave the pair loop.  What the pair still says itself: whether one of its values lay at or
+// below qual_score[0] (bit 26 of the parked ro_st; panda_result_phred answers 1 there, nt.c:126-150).
+#ifndef FK_LAZYP
+#define FK_LAZYP 1
+#endif
 struct QTree {
 	double lvl[6];	// level L: the merged partial sums of 2^L pairs, waiting for the next 2^L (held while bit L of the slot count is set)
 };
@@ -1568,7 +1575,8 @@ union F64Pair {
 	unsigned u[2];
 };
 // one vector from two: lanes whose bit D is clear keep x[i] + x[i ^ D], the others y[i] + y[i ^ D]
-template <int D>
+// (MIN: the smaller of the two instead of their sum -- the tree of the rows' smallest log-p, FK_LAZYP)
+template <int D, bool MIN = false>
 __device__ __forceinline__ double qsum_merge(double xd, double yd, int lane) {
 	F64Pair x, y, t, w;
 	x.d = xd;
@@ -1606,40 +1614,46 @@ __device__ __forceinline__ double qsum_merge(double xd, double yd, int lane) {
 			t.u[k] = up ? y.u[k] : x.u[k];
 		}
 	}
+	if constexpr (MIN) {
+		double r;
+		asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(t.d), "v"(w.d));	// (the bare instruction: no NaNs here, see min_f64)
+		return r;
+	}
 	return t.d + w.d;
 }
 // the s-th pair of a group of 64 hands in its 64 partial sums; true when the group's sums are complete (s == 63): they are `q`'s
+template <bool MIN = false>
 __device__ __forceinline__ bool qsum_insert(QTree &qt, int s, double q, int lane, double &out) {
 	if ((s & 1) == 0) {
 		qt.lvl[0] = q;
 		return false;
 	}
-	q = qsum_merge<32>(qt.lvl[0], q, lane);
+	q = qsum_merge<32, MIN>(qt.lvl[0], q, lane);
 	if ((s & 2) == 0) {
 		qt.lvl[1] = q;
 		return false;
 	}
-	q = qsum_merge<16>(qt.lvl[1], q, lane);
+	q = qsum_merge<16, MIN>(qt.lvl[1], q, lane);
 	if ((s & 4) == 0) {
 		qt.lvl[2] = q;
 		return false;
 	}
-	q = qsum_merge<8>(qt.lvl[2], q, lane);
+	q = qsum_merge<8, MIN>(qt.lvl[2], q, lane);
 	if ((s & 8) == 0) {
 		qt.lvl[3] = q;
 		return false;
 	}
-	q = qsum_merge<4>(qt.lvl[3], q, lane);
+	q = qsum_merge<4, MIN>(qt.lvl[3], q, lane);
 	if ((s & 16) == 0) {
 		qt.lvl[4] = q;
 		return false;
 	}
-	q = qsum_merge<2>(qt.lvl[4], q, lane);
+	q = qsum_merge<2, MIN>(qt.lvl[4], q, lane);
 	if ((s & 32) == 0) {
 		qt.lvl[5] = q;
 		return false;
 	}
-	out = qsum_merge<1>(qt.lvl[5], q, lane);
+	out = qsum_merge<1, MIN>(qt.lvl[5], q, lane);
 	return true;
 }
 
@@ -1658,8 +1672,11 @@ struct HotArgs {
 // POST (LONG only): `-a`, the primers are looked for in the merged sequence and cut off it (reference-order sums since round 5:
 // `quality` is the whole merge's, assembler.c:244 precedes the clipping, and comes from the group walk like any other row's)
 template <int ALGO, bool EXACT, bool PHRED, bool LONG, bool PRIM, bool NARROW, bool POST, bool LAZYQ = false>
-__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, const unsigned char *places, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases, uint16_t *xs, const HotArgs &H, bool &flags_dirty, unsigned &epoch, std::conditional_t<LONG, LenMasks8, LenMasks> &lmf, std::conditional_t<LONG, LenMasks8, LenMasks> &lmr, double *qlane = nullptr) {
+__device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const double *ltab, const unsigned char *places, unsigned char *wb, WaveArena &arena, Pend64 &pd, int slot_idx, bool &deep_dirty, u64 pair, int lane, const int flen, const int rlen, Carry<LONG> &cur, const Carry<LONG> &nxt, unsigned primer_bases, uint16_t *xs, const HotArgs &H, bool &flags_dirty, unsigned &epoch, std::conditional_t<LONG, LenMasks8, LenMasks> &lmf, std::conditional_t<LONG, LenMasks8, LenMasks> &lmr, double *qlane = nullptr, double *plane = nullptr) {
 	typedef Lay<LONG> L;
+	constexpr bool LAZYP = FK_LAZYP != 0 && LAZYQ && PHRED;
+	if constexpr (LAZYP)
+		*plane = 0.0;	// (nothing below 0.0: the neutral element of the tree's minimum)
 	static_assert(!LAZYQ || (!EXACT && !POST), "the merge tree holds sums in any order, of whole rows");
 	if constexpr (LAZYQ)
 		*qlane = 0.0;	// (a pair that does not get as far as its row hands in nothing)
@@ -1677,6 +1694,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	u64 off = ~0ull;
 	double best = 0.0, qsum = 0.0;
 	int seqlen = 0, bo = -1, examined = 0, mism = 0, degen = 0, phmin = 127;
+	bool phflag = false;	// (FK_LAZYP) one of the row's log-p lies at or below qual_score[0]
 	bool slow = false;
 	const int minov = P.minoverlap;
 	constexpr int T1B = t1_bits<ALGO, LONG>();
@@ -2686,7 +2704,10 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 		// the nt row leaves LDS in 16-byte stores (rows are 16-base aligned)
 		if (store && lane * 16 < seqlen)
 			store_stream(&((gbl_u128 *) row_nt)[lane], reinterpret_cast<const u32x4 *>(nts)[lane]);
-		if (PHRED) {
+		if constexpr (LAZYP) {
+			*plane = pmin;	// this lane's smallest log-p above qual_score[0]; the row's, and its phred, are finish64's
+			phflag = ballot(pall <= qs0) != 0;
+		} else if (PHRED) {
 			// one lookup per pair instead of one walk per base (see above)
 			phmin = fk_phred_of(ltab + PAMD_LT_SCORE, places, wave_min_nonpositive(pmin), lane);
 			if (ballot(pall <= qs0) != 0 && phmin > 1)
@@ -2738,7 +2759,7 @@ __device__ __forceinline__ void fast_pair(const PamdKernelParams &P, const doubl
 	const unsigned f_len_bo = (unsigned) seqlen | ((unsigned) (bo < 0 ? 0 : bo) << 16), f_ex_mm = (unsigned) examined | ((unsigned) mism << 16);
 	const unsigned f_dg_fo = (unsigned) degen | ((unsigned) fo << 16);
 	// (POST: bit 25, "the quality is final": finish64 does not divide it by the clipped length)
-	const unsigned f_ro_st = (unsigned) ro | ((unsigned) status << 16) | ((unsigned) slow << 24) | (POST ? 1u << 25 : 0u) | ((unsigned) (phmin > 63 ? 63 : phmin) << 26);
+	const unsigned f_ro_st = (unsigned) ro | ((unsigned) status << 16) | ((unsigned) slow << 24) | (POST ? 1u << 25 : 0u) | (LAZYP ? (phflag ? 1u << 26 : 0u) : (unsigned) (phmin > 63 ? 63 : phmin) << 26);
 	if constexpr (LAZYQ) {	// (the quality sums come out of the merge tree, in lane bitrev6(slot): the other scalars go there too)
 		slot_idx = (int) (__builtin_bitreverse32((unsigned) slot_idx) >> 26);
 		asm volatile("s_mov_b32 m0, %4\n\t"
@@ -2855,12 +2876,13 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 	std::conditional_t<LONG, LenMasks8, LenMasks> lmf = { -1 }, lmr = { -1 };	// FK_LEN_MASKS
 	constexpr bool LQ = FK_LAZYQ != 0 && !EXACT && !POST && !LONG;	// (the LONG geometry has no registers for the tree's six levels)
 	static_assert(!LQ || F == 64u, "the merge tree closes after 64 pairs");
-	QTree qt;
+	constexpr bool LP = FK_LAZYP != 0 && LQ && PHRED;
+	QTree qt, pt;
 	HotArgs H = { P.qual_nn, P.sb_pmatch, P.sb_pmismatch, P.threshold, P.seq_stride, P.seq_capacity, P.seq_nt, P.seq_p };
 #if FK_KARGS
 	asm volatile("" : "+s"(H.qual_nn), "+s"(H.pmatch), "+s"(H.pmismatch), "+s"(H.threshold), "+s"(H.stride), "+s"(H.capacity), "+s"(H.nt), "+s"(H.p));
 #endif
-	Pend64 pd = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+	Pend64 pd = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
 	auto take_group = [&](int base, int count) __attribute__((always_inline)) {
 		const GroupSums g = exact_sums_group<LONG, XSCORE, ALGO == PAMD_ALGO_RDP_MLE>(lds_addr(ltab), xs, pd.len_bo, pd.pid, pd.ro_st, pd.off_lo, pd.off_hi, P.qual_nn, base, count, lane);
 		pd.q_lo = g.done ? g.q_lo : pd.q_lo;
@@ -2886,14 +2908,20 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 			// here, the lane number's derivatives are recomputed where they are used (an instruction or two each).
 			asm volatile("" : "+v"(lane_now));
 		}
-		double qlane;
-		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST, LQ>(P, ltab, places, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases, EXACT ? xs + (unsigned) xg * fk_xstride<LONG, XSCORE>() : nullptr, H, flags_dirty, epoch, lmf, lmr, &qlane);
+		double qlane, plane;
+		fast_pair<ALGO, EXACT, PHRED, LONG, PRIM, NARROW, POST, LQ>(P, ltab, places, wb, arena, pd, npend, deep_dirty, pair, lane_now, flen, rlen, cur, nxt, primer_bases, EXACT ? xs + (unsigned) xg * fk_xstride<LONG, XSCORE>() : nullptr, H, flags_dirty, epoch, lmf, lmr, &qlane, &plane);
 		MARK("loop");
 		if constexpr (LQ) {
 			F64Pair sums;
 			if (qsum_insert(qt, npend, qlane, lane, sums.d)) {
 				pd.q_lo = sums.u[0];
 				pd.q_hi = sums.u[1];
+			}
+			if constexpr (LP) {
+				if (qsum_insert<true>(pt, npend, plane, lane, sums.d)) {
+					pd.p_lo = sums.u[0];
+					pd.p_hi = sums.u[1];
+				}
 			}
 		}
 		npend++;
@@ -2902,7 +2930,7 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 			xg = 0;
 		}
 		if (npend == (int) F) {
-			finish64<false, true, false, false, LQ>(P, lctr, pd, npend, group_first, step_in, lane);
+			finish64<false, true, false, false, LQ, LP>(P, lctr, pd, npend, group_first, step_in, lane, ltab + PAMD_LT_SCORE);
 			npend = 0;
 			group_first = next;
 		}
@@ -2918,8 +2946,15 @@ void pamd_fast_kernel(const PamdKernelParams P) {
 				qsum_insert(qt, s, 0.0, lane, sums.d);
 			pd.q_lo = sums.u[0];
 			pd.q_hi = sums.u[1];
+			if constexpr (LP) {
+				sums.d = 0.0;
+				for (int s = npend; s < 64; s++)
+					qsum_insert<true>(pt, s, 0.0, lane, sums.d);
+				pd.p_lo = sums.u[0];
+				pd.p_hi = sums.u[1];
+			}
 		}
-		finish64<false, true, false, false, LQ>(P, lctr, pd, npend, group_first, step_in, lane);
+		finish64<false, true, false, false, LQ, LP>(P, lctr, pd, npend, group_first, step_in, lane, ltab + PAMD_LT_SCORE);
 	}
 	__syncthreads();
 	if (P.counters != nullptr) {
@@ -3072,6 +3107,8 @@ int pamd_launch_fast(const PamdKernelParams &p, int workgroups, int waves_per_wg
 #endif
 #ifdef FK_DEV_PRIM	/* ... config 2's: pear, the primers' geometry */
 	kern = pamd_fast_kernel<PAMD_ALGO_PEAR, FK_DEV_EXACT, false, true, true, false>;
+#elif defined(FK_DEV_PHRED)	/* ... config 3's: rdp_mle with a min_phred module */
+	kern = pamd_fast_kernel<PAMD_ALGO_RDP_MLE, FK_DEV_EXACT, true, false, false, false>;
 #else
 	kern = narrow ? pamd_fast_kernel<PAMD_ALGO_SIMPLE_BAYES, FK_DEV_EXACT, false, false, false, true> : pamd_fast_kernel<PAMD_ALGO_SIMPLE_BAYES, FK_DEV_EXACT, false, false, false, false>;
 #endif
